@@ -1,0 +1,285 @@
+"""Generates ``tests/golden/*.npz`` by RUNNING THE REFERENCE (container only).
+
+TEST INFRASTRUCTURE.  The reference (``/root/reference``, superscreen v0.13.0) is imported
+unmodified under the inert stubs of ``oracle/_ref_stubs.py`` and driven on small synthetic
+meshes in float64; inputs and the reference's outputs are recorded as fixtures (data only --
+no reference source is copied).  Run from the repo root:
+
+    python oracle/make_golden.py
+
+Reference entry points exercised (all unmodified):
+  * ``Mesh.from_triangulation`` (device/mesh.py:111) => ``q_matrix`` (distance.py:87),
+    ``C_vector``/``Q_matrix`` (device/mesh.py:401,435), ``laplace_operator`` (fem.py:259),
+    ``gradient_triangles``/``gradient_vertices`` (fem.py:299,350), ``vertex_areas``
+    (device/utils.py:251)
+  * ``factorize_linear_systems`` (solver/solve_film.py:151) with hand-built ``FilmInfo``
+    (``make_film_info`` itself needs shapely/pint; its index logic, solver/utils.py:271-304,
+    is replayed here with ``matplotlib.path.Path.contains_points`` exactly as
+    ``Polygon.contains_points`` does, device/polygon.py:138-162)
+  * ``solve_film`` (solver/solve_film.py:440), ``biot_savart_film_to_film``
+    (solver/solve.py:28); the Jacobi loop of ``solve`` (solver/solve.py:491-536) is replayed
+    around them because ``solve`` itself needs a real pint registry.
+"""
+from __future__ import annotations
+
+import itertools
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+from matplotlib.path import Path
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_stubs  # noqa: E402
+
+_ref_stubs.install()
+
+from superscreen.device.mesh import Mesh  # noqa: E402  (the reference)
+from superscreen.solver.solve import biot_savart_film_to_film  # noqa: E402
+from superscreen.solver.solve_film import factorize_linear_systems, solve_film  # noqa: E402
+from superscreen.solver.utils import FilmInfo, LambdaInfo  # noqa: E402
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "_synthetic", os.path.join(ROOT, "superscreen_amd", "synthetic.py")
+)
+synthetic = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synthetic)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MU_0 = 1.25663706212e-6
+FIELD_CONV = 1e-3 / MU_0  # mT -> uA/um   (solver/utils.py:407-437 with pint's mu_0)
+VORTEX_FLUX = 2.067833848461929e-15 / MU_0 * 1e12
+
+
+def csr_parts(m, prefix):
+    m = m.tocsr()
+    m.sort_indices()
+    return {
+        f"{prefix}_data": m.data,
+        f"{prefix}_indices": m.indices.astype(np.int64),
+        f"{prefix}_indptr": m.indptr.astype(np.int64),
+    }
+
+
+def contains(poly_points, pts):
+    return Path(poly_points, closed=True).contains_points(np.atleast_2d(pts))
+
+
+def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ, dtype):
+    """Index logic of ``make_film_info`` (solver/utils.py:261-304) for a constant Lambda."""
+    dtype = np.dtype(dtype)
+    n = len(mesh.sites)
+    Lambda = (Lambda_value * np.ones(n)).astype(dtype)[:, np.newaxis]
+    hole_indices = {h: np.where(contains(p, mesh.sites))[0] for h, p in hole_polys.items()}
+    in_hole = np.zeros(n, dtype=bool)
+    if hole_indices:
+        in_hole[np.concatenate(list(hole_indices.values()))] = True
+    interior = np.setdiff1d(np.where(contains(film_poly, mesh.sites))[0], mesh.boundary_indices)
+    return FilmInfo(
+        name=name,
+        layer=layer,
+        lambda_info=LambdaInfo(film=name, Lambda=Lambda),
+        vortices=[],
+        interior_indices=interior,
+        boundary_indices=mesh.boundary_indices,
+        hole_indices=hole_indices,
+        in_hole=in_hole,
+        circulating_currents={h: c for h, c in circ.items() if h in hole_indices},
+        weights=mesh.operators.weights.astype(dtype, copy=False),
+        kernel=mesh.operators.Q.astype(dtype, copy=False),
+        laplacian=mesh.operators.laplacian.toarray().astype(dtype, copy=False),
+        gradient=None,
+        terminal_currents=None,
+    )
+
+
+def polygons_for(K, sites_dr, washer):
+    Kf = synthetic.film_rings(K)
+    film_poly = synthetic.circle_points((Kf + 0.5) * sites_dr)
+    holes = {}
+    if washer:
+        holes["hole"] = synthetic.circle_points((Kf // 3 + 0.5) * sites_dr, 201)
+    return film_poly, holes
+
+
+def sample_rows(n, count=8):
+    return np.unique(np.linspace(0, n - 1, count).astype(np.int64))
+
+
+def single_film_fixture(K, washer, Lambdas, circs, fname, full_Q):
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = Mesh.from_triangulation(sites, elements)  # reference operators
+    ops = mesh.operators
+    film_poly, holes = polygons_for(K, dr, washer)
+    n = len(sites)
+    rows = sample_rows(n)
+    out = dict(
+        K=K, washer=washer, sites=sites, elements=elements, dr=dr,
+        boundary_indices=mesh.boundary_indices,
+        triangle_areas=mesh.triangle_areas, weights=ops.weights,
+        C=type(ops).C_vector(sites),
+        Q_diag=np.diag(ops.Q).copy(), sample_rows=rows, Q_rows=ops.Q[rows].copy(),
+        film_poly=film_poly, Lambdas=np.asarray(Lambdas, float), circs=np.asarray(circs, float),
+        field_conversion=FIELD_CONV,
+    )
+    if full_Q:
+        out["Q"] = ops.Q
+    if washer:
+        out["hole_poly"] = holes["hole"]
+    out.update(csr_parts(ops.laplacian, "lap"))
+    out.update(csr_parts(ops.gradient_x, "gx"))
+    out.update(csr_parts(ops.gradient_y, "gy"))
+    out.update(csr_parts(ops.gradient_tri_x, "Gx"))
+    out.update(csr_parts(ops.gradient_tri_y, "Gy"))
+    device_like = SimpleNamespace(terminals={}, meshes={"film": mesh})
+    applied = (1.0 * FIELD_CONV) * np.ones(n)  # ConstantField(1) mT
+    for li, Lam in enumerate(Lambdas):
+        for ci, circ in enumerate(circs):
+            info = make_film_info("film", "layer", mesh, film_poly, holes, Lam,
+                                  {"hole": circ}, "float64")
+            film_systems, hole_systems, _ = factorize_linear_systems(device_like, {"film": info})
+            fs = film_systems["film"]
+            sol = solve_film(
+                device=device_like, applied_field=applied, film_info=info,
+                film_system=fs, hole_systems=hole_systems["film"],
+                field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX,
+            )
+            tag = f"L{li}_c{ci}"
+            if ci == 0:
+                ni = len(fs.indices)
+                arows = sample_rows(ni)
+                out[f"A_rows_idx_L{li}"] = arows
+                out[f"A_rows_L{li}"] = fs.A[arows].copy()
+                out[f"A_diag_L{li}"] = np.diag(fs.A).copy()
+                out[f"piv_L{li}"] = fs.lu_piv[1].astype(np.int64)
+                if li == 0:
+                    out["film_indices"] = fs.indices
+                    for h, hs in hole_systems["film"].items():
+                        out["hole_indices"] = hs.indices
+                if washer:
+                    hs = hole_systems["film"]["hole"]
+                    out[f"A_hole_rows_L{li}"] = hs.A[rows].copy()
+            out[f"g_{tag}"] = sol.stream
+            out[f"J_{tag}"] = sol.current_density
+            out[f"self_field_{tag}"] = sol.self_field
+            out[f"applied_field_{tag}"] = sol.applied_field
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "n =", n)
+
+
+def stack_fixture(K, kinds, z0s, Lambda, iterations, fname, circ=0.0, field_mT=1.0):
+    """Replays solver/solve.py:459-547 (first pass + Jacobi loop) around the reference's
+    ``solve_film`` and ``biot_savart_film_to_film``."""
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = Mesh.from_triangulation(sites, elements)
+    n = len(sites)
+    names = [f"{k}{i}" for i, k in enumerate(kinds)]
+    meshes = {nm: mesh for nm in names}
+    device_like = SimpleNamespace(terminals={}, meshes=meshes)
+    infos, z0 = {}, {}
+    film_poly = None
+    for nm, kind, z in zip(names, kinds, z0s):
+        film_poly, holes = polygons_for(K, dr, kind == "washer")
+        holes = {f"hole_{nm}": p for p in holes.values()}
+        infos[nm] = make_film_info(nm, f"layer_{nm}", mesh, film_poly, holes, Lambda,
+                                   {f"hole_{nm}": circ}, "float64")
+        z0[nm] = z
+    film_systems, hole_systems, _ = factorize_linear_systems(device_like, infos)
+    applied = {nm: (field_mT * FIELD_CONV) * np.ones(n) for nm in names}
+
+    def run(other):
+        return {
+            nm: solve_film(
+                device=device_like, applied_field=applied[nm], film_info=infos[nm],
+                film_system=film_systems[nm], hole_systems=hole_systems[nm],
+                field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX,
+                field_from_other_films=None if other is None else other[nm],
+            )
+            for nm in names
+        }
+
+    out = dict(K=K, kinds=np.array(kinds), z0s=np.asarray(z0s, float), Lambda=Lambda,
+               iterations=iterations, circ=circ, field_mT=field_mT, names=np.array(names),
+               field_conversion=FIELD_CONV)
+    sols = run(None)
+    trace = [sols]
+    for it in range(iterations):
+        other = {nm: np.zeros(n) for nm in names}
+        for src, tgt in itertools.product(names, repeat=2):
+            if src == tgt:
+                continue
+            other[tgt] += biot_savart_film_to_film(
+                film1_sites=mesh.sites, film1_z0=z0[src], film1_areas=infos[src].weights,
+                film1_J=sols[src].current_density, film2_sites=mesh.sites, film2_z0=z0[tgt],
+            )
+        sols = run(other)
+        trace.append(sols)
+    for it, s in enumerate(trace):
+        for nm in names:
+            out[f"g_{nm}_it{it}"] = s[nm].stream
+            out[f"J_{nm}_it{it}"] = s[nm].current_density
+            out[f"self_field_{nm}_it{it}"] = s[nm].self_field
+            if s[nm].field_from_other_films is not None:
+                out[f"other_{nm}_it{it}"] = s[nm].field_from_other_films
+    # Fluxoid raw parts (solution.py:535-559) for a circle around the washer hole, computed
+    # from the reference's own arrays with the reference's formulas.
+    if "washer" in kinds:
+        from matplotlib.tri import LinearTriInterpolator, Triangulation
+
+        nm = names[list(kinds).index("washer")]
+        Kf = synthetic.film_rings(K)
+        r_poly = (Kf // 3 + (Kf - Kf // 3) / 2 + 0.25) * dr
+        poly = synthetic.circle_points(r_poly, 101)
+        s = trace[-1][nm]
+        total = s.applied_field + s.self_field + s.field_from_other_films
+        ix = contains(poly, mesh.sites)
+        flux_part = np.einsum("i, i ->", total[ix], mesh.vertex_areas[ix])
+        tri = Triangulation(sites[:, 0], sites[:, 1], elements)
+        J = s.current_density
+        Jp = np.array([LinearTriInterpolator(tri, J[:, 0])(poly[:, 0], poly[:, 1]).data,
+                       LinearTriInterpolator(tri, J[:, 1])(poly[:, 0], poly[:, 1]).data]).T
+        Jp[~contains(film_poly, poly)] = 0
+        Jp[~np.isfinite(Jp).all(axis=1)] = 0
+        dl = np.diff(poly, axis=0)
+        int_J = np.trapezoid(Lambda * np.ones(len(poly))[:-1] * np.sum(Jp[:-1] * dl, axis=1))
+        out.update(fluxoid_film=np.array(nm), fluxoid_poly=poly, flux_part_raw=flux_part,
+                   int_J_raw=int_J)
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "n =", n, "films", names)
+
+
+def biot_savart_fixture(fname):
+    rng = np.random.default_rng(0)
+    s1, _, _ = synthetic.ring_disk_mesh(9)
+    s2, _, _ = synthetic.ring_disk_mesh(7)
+    s2 = s2 * 0.8 + np.array([0.3, -0.2])
+    J = rng.standard_normal((len(s1), 2))
+    areas = rng.uniform(0.5, 1.5, len(s1))
+    out = dict(sites1=s1, sites2=s2, J=J, areas=areas)
+    for tag, (za, zb, shift) in {"dz05": (0.0, 0.5, 0.0), "dz0_disjoint": (0.0, 0.0, 30.0),
+                                 "dzneg": (1.5, 0.25, 0.0)}.items():
+        tgt = s2 + np.array([shift, 0.0])
+        out[f"H_{tag}"] = biot_savart_film_to_film(
+            film1_sites=s1, film1_z0=za, film1_areas=areas, film1_J=J,
+            film2_sites=tgt, film2_z0=zb)
+        out[f"args_{tag}"] = np.array([za, zb, shift])
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN, exist_ok=True)
+    single_film_fixture(10, False, [0.0, 0.1, 1.0], [0.0], "disk_K10.npz", full_Q=True)
+    single_film_fixture(26, False, [0.1], [0.0], "disk_K26.npz", full_Q=False)
+    single_film_fixture(17, True, [0.1, 1.0], [0.0, 1.0], "washer_K17.npz", full_Q=False)
+    stack_fixture(12, ("washer", "disk"), (0.0, 0.5), 0.1, 5, "stack2_K12.npz")
+    stack_fixture(8, ("disk", "washer", "disk"), (0.0, 0.5, 1.0), 0.1, 3, "stack3_K8.npz",
+                  circ=2.0, field_mT=0.5)
+    biot_savart_fixture("biot_savart.npz")

@@ -1,0 +1,487 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain numpy/scipy restatement of the reference algorithm for the hot path named in
+BASELINE.json (``north_star``): mesh operators -> dense kernel matrix Q -> per-film system
+``A = Q.w^T - Lambda.Del2`` -> ``lu_factor(-A)`` -> ``solve_film`` -> inter-film Biot-Savart
+-> Jacobi iteration -> fluxoid.  Every function cites the reference ``file:line`` it follows
+(paths relative to ``/root/reference/superscreen/``, reference v0.13.0).
+
+Rules (task statement, item 3):
+  * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+    import this module -- always as the checker / baseline, never as the thing shipped;
+  * the product package ``superscreen_amd`` never imports it and has no CPU fallback.
+
+Parity pinning: the reference holds NO golden vectors for this path (SURVEY.md section 4:
+its tests are physics invariants at 5e-2).  This oracle is therefore pinned against outputs
+of the *reference itself*, run in the build container under inert import stubs
+(``oracle/_ref_stubs.py``), recorded by ``oracle/make_golden.py`` into ``tests/golden/*.npz``
+and re-checked by ``tests/test_oracle_golden.py`` (runs anywhere) and
+``tests/test_oracle_vs_reference.py`` (runs only where ``/root/reference`` exists).
+
+Third-party arithmetic on the path (not under /root/reference, versions unpinned there,
+``setup.py:30-45``): ``scipy.linalg.lu_factor/lu_solve`` (LAPACK getrf/getrs); this oracle
+calls the same routines (scipy 1.15.3 / numpy 2.2.6 in this image).
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.linalg as la
+import scipy.sparse as sp
+
+# --------------------------------------------------------------------------------------
+# Unit constants (reference: pint registry, units.py:1-3; solver/utils.py:407-437).
+# CODATA 2018 values as shipped with pint's default registry.
+# --------------------------------------------------------------------------------------
+MU_0 = 1.25663706212e-6  # N / A^2
+PHI_0 = 2.067833848461929e-15  # Wb  (h / 2e)
+
+
+def field_conversion_mT_to_uA_per_um() -> float:
+    """``field_conversion_factor("mT", "uA", "um")`` (solver/utils.py:407-437):
+    B = 1 mT -> H = B/mu0 in A/m; 1 A/m == 1 uA/um."""
+    return 1e-3 / MU_0
+
+
+def vortex_flux_uA_um() -> float:
+    """``ureg("Phi_0 / mu_0").to("uA * um")`` (solver/solve.py:441-442)."""
+    return PHI_0 / MU_0 * 1e6 * 1e6
+
+
+# --------------------------------------------------------------------------------------
+# Mesh geometry (device/utils.py, device/mesh.py)
+# --------------------------------------------------------------------------------------
+def triangle_areas(points: np.ndarray, triangles: np.ndarray) -> np.ndarray:
+    """device/utils.py:230-248 -- signed area 1/2 det[[p2-p1],[p0-p2]]."""
+    xy = points[triangles]
+    s = xy[:, [2, 0]] - xy[:, [1, 2]]
+    return 0.5 * (s[:, 0, 0] * s[:, 1, 1] - s[:, 0, 1] * s[:, 1, 0])
+
+
+def vertex_areas(points: np.ndarray, triangles: np.ndarray,
+                 tri_areas: Optional[np.ndarray] = None) -> np.ndarray:
+    """device/utils.py:251-273 -- w_i = 1/3 sum of adjacent triangle areas."""
+    if tri_areas is None:
+        tri_areas = triangle_areas(points, triangles)
+    third = tri_areas / 3
+    n = len(points)
+    out = np.zeros(n, dtype=float)
+    for c in range(3):
+        out += np.bincount(triangles[:, c], weights=third, minlength=n)
+    return out
+
+
+def get_edges(triangles: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """device/utils.py:139-152."""
+    edges = np.concatenate([triangles[:, e] for e in [(0, 1), (1, 2), (2, 0)]])
+    edges = np.sort(edges, axis=1)
+    edges, counts = np.unique(edges, return_counts=True, axis=0)
+    return edges, counts == 1
+
+
+def find_boundary_indices(triangles: np.ndarray) -> np.ndarray:
+    """device/mesh.py:158-170 -- vertices on edges that belong to one triangle only."""
+    edges, is_boundary = get_edges(triangles)
+    return np.unique(edges[is_boundary].ravel())
+
+
+# --------------------------------------------------------------------------------------
+# FEM operators (fem.py)
+# --------------------------------------------------------------------------------------
+def _corner_angles(points: np.ndarray, triangles: np.ndarray, corner: int) -> np.ndarray:
+    """Interior angle of every triangle at its ``corner``-th vertex, computed exactly the
+    way fem.py:188-224 does (arccos of the normalised dot product)."""
+    a, b, c = corner, (corner + 1) % 3, (corner + 2) % 3
+    v1 = points[triangles[:, b]] - points[triangles[:, a]]
+    v2 = points[triangles[:, c]] - points[triangles[:, a]]
+    cosang = np.sum(v1 * v2, axis=1) / (la.norm(v1, axis=1) * la.norm(v2, axis=1))
+    return np.arccos(cosang)
+
+
+def weights_half_cotangent(points: np.ndarray, triangles: np.ndarray) -> sp.csr_array:
+    """fem.py:165-224 -- W_ij += 1/2 cot(angle opposite edge ij), symmetric."""
+    n = len(points)
+    rows, cols, vals = [], [], []
+    for corner in range(3):
+        w = 0.5 / np.tan(_corner_angles(points, triangles, corner))
+        i = triangles[:, (corner + 1) % 3]
+        j = triangles[:, (corner + 2) % 3]
+        rows += [i, j]
+        cols += [j, i]
+        vals += [w, w]
+    W = sp.coo_array(
+        (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)
+    )
+    return W.tocsr()
+
+
+def laplace_operator(points: np.ndarray, triangles: np.ndarray,
+                     masses: Optional[np.ndarray] = None) -> sp.csr_array:
+    """fem.py:259-296 -- L = W - diag(rowsum W);  Del2 = diag(1/masses) @ L (row scaling)."""
+    if masses is None:
+        masses = vertex_areas(points, triangles)
+    W = weights_half_cotangent(points, triangles).tolil()
+    W.setdiag(0)
+    W = W.tocsr()
+    W.eliminate_zeros()
+    rowsum = np.asarray(W.sum(axis=1)).ravel()
+    L = (W - sp.diags_array(rowsum, format="csr")).tocsr()
+    return (sp.diags_array(1.0 / masses, format="csr") @ L).tocsr()
+
+
+def gradient_triangles(points: np.ndarray, triangles: np.ndarray,
+                       areas: Optional[np.ndarray] = None) -> Tuple[sp.csr_array, sp.csr_array]:
+    """fem.py:299-347 -- per-triangle linear gradient, 3 nnz/row."""
+    if areas is None:
+        areas = triangle_areas(points, triangles)
+    xy = points[triangles]
+    edges = np.roll(xy, 2, axis=1) - np.roll(xy, 1, axis=1)
+    rot = np.empty_like(edges)
+    rot[:, :, 0] = +edges[:, :, 1]
+    rot[:, :, 1] = -edges[:, :, 0]
+    data = (rot / (2 * areas[:, None, None])).reshape(-1, 2).T
+    m, n = len(triangles), len(points)
+    row = np.repeat(np.arange(m), 3)
+    col = triangles.ravel()
+    Gx = sp.csr_array((data[0], (row, col)), shape=(m, n), dtype=float)
+    Gy = sp.csr_array((data[1], (row, col)), shape=(m, n), dtype=float)
+    return Gx, Gy
+
+
+def gradient_vertices(points: np.ndarray, triangles: np.ndarray,
+                      gradient_tri: Optional[Tuple[sp.csr_array, sp.csr_array]] = None
+                      ) -> Tuple[sp.csr_array, sp.csr_array]:
+    """fem.py:350-402 -- vertex gradient = weighted mean of adjacent triangle gradients.
+
+    Quirk reproduced (fem.py:393-399): the weight of triangle t for vertex i is the angle at
+    t's *first* vertex (``vec1 = p[t1]-p[t0]``, ``vec2 = p[t2]-p[t0]``), whatever i is,
+    normalised over the triangles adjacent to i.
+    """
+    if gradient_tri is None:
+        gradient_tri = gradient_triangles(points, triangles)
+    Gx, Gy = gradient_tri
+    m, n = len(triangles), len(points)
+    angle0 = _corner_angles(points, triangles, 0)
+    vert = triangles.ravel()
+    tri = np.repeat(np.arange(m), 3)
+    wsum = np.bincount(vert, weights=angle0[tri], minlength=n)
+    W = sp.csr_array((angle0[tri] / wsum[vert], (vert, tri)), shape=(n, m))
+    return (W @ Gx).tocsr(), (W @ Gy).tocsr()
+
+
+# --------------------------------------------------------------------------------------
+# Kernel matrix (distance.py, device/mesh.py)
+# --------------------------------------------------------------------------------------
+def q_matrix(points: np.ndarray, block: int = 2048) -> np.ndarray:
+    """distance.py:87-115 -- q_ij = (1/4pi) |r_i - r_j|^-3, q_ii = 0; dtype of ``points``."""
+    n = len(points)
+    out = np.empty((n, n), dtype=points.dtype)
+    one_over_4pi = 1 / (4 * np.pi)
+    x, y = points[:, 0], points[:, 1]
+    for i0 in range(0, n, block):
+        i1 = min(n, i0 + block)
+        dx = x[i0:i1, None] - x[None, :]
+        dy = y[i0:i1, None] - y[None, :]
+        r2 = dx * dx + dy * dy
+        with np.errstate(divide="ignore"):
+            blk = one_over_4pi * r2 ** (-1.5)
+        blk[np.arange(i1 - i0), np.arange(i0, i1)] = 0.0
+        out[i0:i1] = blk
+    return out
+
+
+def C_vector(points: np.ndarray) -> np.ndarray:
+    """device/mesh.py:401-432 -- edge vector; centred on the *mean* of the coordinates
+    (:421-422), ``inf -> 1e30`` before the division by 4 pi (:430-431)."""
+    x = points[:, 0] - points[:, 0].mean()
+    y = points[:, 1] - points[:, 1].mean()
+    a = np.ptp(x) / 2
+    b = np.ptp(y) / 2
+    with np.errstate(divide="ignore"):
+        C = sum(
+            np.sqrt((a - p * x) ** (-2) + (b - q * y) ** (-2))
+            for p, q in itertools.product((-1, 1), repeat=2)
+        )
+    C[np.isinf(C)] = 1e30
+    C /= 4 * np.pi
+    return C
+
+
+def Q_matrix(points: np.ndarray, weights: np.ndarray) -> np.ndarray:
+    """device/mesh.py:435-458 -- Q_ij = -q_ij (i != j); Q_ii = (C_i + sum_l q_il w_l)/w_i."""
+    q = q_matrix(points)
+    C = C_vector(points)
+    diag = -(C + np.einsum("ij, j -> i", q, weights)) / weights
+    np.fill_diagonal(q, diag)
+    return -q
+
+
+# --------------------------------------------------------------------------------------
+# Mesh operators container (device/mesh.py:326-394)
+# --------------------------------------------------------------------------------------
+@dataclass
+class OracleMesh:
+    sites: np.ndarray
+    elements: np.ndarray
+    boundary_indices: np.ndarray
+    triangle_areas: np.ndarray
+    weights: np.ndarray  # vertex areas
+    Q: Optional[np.ndarray]
+    laplacian: sp.csr_array
+    gradient_x: sp.csr_array
+    gradient_y: sp.csr_array
+    gradient_tri_x: sp.csr_array
+    gradient_tri_y: sp.csr_array
+
+
+def make_mesh(sites: np.ndarray, elements: np.ndarray, build_Q: bool = True) -> OracleMesh:
+    """``Mesh.from_triangulation`` + ``MeshOperators.from_mesh`` (device/mesh.py:111-155,
+    362-394)."""
+    sites = np.asarray(sites, dtype=float)
+    elements = np.asarray(elements, dtype=np.int64)
+    tri_a = triangle_areas(sites, elements)
+    w = vertex_areas(sites, elements, tri_a)
+    Gx, Gy = gradient_triangles(sites, elements, tri_a)
+    gx, gy = gradient_vertices(sites, elements, (Gx, Gy))
+    return OracleMesh(
+        sites=sites,
+        elements=elements,
+        boundary_indices=find_boundary_indices(elements),
+        triangle_areas=tri_a,
+        weights=w,
+        Q=Q_matrix(sites, w) if build_Q else None,
+        laplacian=laplace_operator(sites, elements, w),
+        gradient_x=gx,
+        gradient_y=gy,
+        gradient_tri_x=Gx,
+        gradient_tri_y=Gy,
+    )
+
+
+# --------------------------------------------------------------------------------------
+# Per-film linear systems (solver/solve_film.py)
+# --------------------------------------------------------------------------------------
+def build_system_2d(Q, weights, Lambda, laplacian, ix) -> np.ndarray:
+    """solver/solve_film.py:296-305 (homogeneous Lambda):
+    ``A = Q[ix,ix]*w[ix] - Lambda[ix]*Del2[ix,ix]`` -- COLUMN scalings w_j, Lambda_j."""
+    sub = laplacian[ix][:, ix]
+    sub = sub.toarray() if sp.issparse(sub) else np.asarray(sub)
+    return Q[np.ix_(ix, ix)] * weights[ix] - Lambda[ix] * sub
+
+
+def build_system_1d(Q, weights, Lambda, laplacian, ix) -> np.ndarray:
+    """solver/solve_film.py:285-293: ``A_h = Q[:,ix]*w[ix] - Lambda[ix]*Del2[:,ix]``."""
+    sub = laplacian[:, ix]
+    sub = sub.toarray() if sp.issparse(sub) else np.asarray(sub)
+    return Q[:, ix] * weights[ix] - Lambda[ix] * sub
+
+
+@dataclass
+class OracleFilm:
+    """What ``make_film_info`` + ``factorize_linear_systems`` hold for one film
+    (solver/utils.py:234-324, solver/solve_film.py:151-282)."""
+
+    name: str
+    mesh: OracleMesh
+    z0: float
+    Lambda: np.ndarray  # (n,)
+    film_indices: np.ndarray  # indices of unknowns (interior minus holes), sorted
+    hole_indices: Dict[str, np.ndarray]
+    dtype: np.dtype
+    weights: np.ndarray = None
+    Q: np.ndarray = None
+    A: np.ndarray = None
+    lu_piv: Tuple[np.ndarray, np.ndarray] = None
+    A_holes: Dict[str, np.ndarray] = field(default_factory=dict)
+
+
+def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.ndarray,
+              holes_mask: Optional[Dict[str, np.ndarray]] = None,
+              dtype="float64", factorize: bool = True) -> OracleFilm:
+    """``make_film_info`` index logic (solver/utils.py:271-304) followed by
+    ``factorize_linear_systems`` (solver/solve_film.py:209-218, 269-281).
+
+    ``in_film`` / ``holes_mask[name]`` are the boolean results of the film / hole polygons'
+    ``contains_points(mesh.sites)``.
+    """
+    dtype = np.dtype(dtype)
+    n = len(mesh.sites)
+    Lambda = np.broadcast_to(np.asarray(Lambda, dtype=float), (n,)).astype(dtype)
+    if np.any(Lambda < 0):
+        raise ValueError(f"Negative Lambda in film {name!r}.")  # solver/utils.py:57-58
+    holes_mask = holes_mask or {}
+    hole_indices = {h: np.where(m)[0] for h, m in holes_mask.items()}
+    interior = np.setdiff1d(np.where(in_film)[0], mesh.boundary_indices)
+    if hole_indices:
+        interior = np.setdiff1d(interior, np.concatenate(list(hole_indices.values())))
+    weights = mesh.weights.astype(dtype, copy=False)
+    Q = mesh.Q.astype(dtype, copy=False)
+    lap = mesh.laplacian.astype(dtype)
+    film = OracleFilm(name=name, mesh=mesh, z0=float(z0), Lambda=Lambda,
+                      film_indices=interior, hole_indices=hole_indices, dtype=dtype,
+                      weights=weights, Q=Q)
+    for h, ix in hole_indices.items():
+        film.A_holes[h] = build_system_1d(Q, weights, Lambda, lap, ix).astype(dtype, copy=False)
+    film.A = build_system_2d(Q, weights, Lambda, lap, interior).astype(dtype, copy=False)
+    if factorize:
+        film.lu_piv = la.lu_factor(-film.A)
+    return film
+
+
+@dataclass
+class OracleFilmSolution:
+    """``FilmSolution`` (solution.py:95-130)."""
+
+    stream: np.ndarray
+    current_density: np.ndarray
+    applied_field: np.ndarray
+    self_field: np.ndarray
+    field_from_other_films: Optional[np.ndarray] = None
+
+    @property
+    def total_field(self) -> np.ndarray:
+        out = self.applied_field + self.self_field
+        if self.field_from_other_films is not None:
+            out = out + self.field_from_other_films
+        return out
+
+
+def solve_film(film: OracleFilm, applied_field: np.ndarray, *, field_conversion: float,
+               circulating_currents: Optional[Dict[str, float]] = None,
+               field_from_other_films: Optional[np.ndarray] = None) -> OracleFilmSolution:
+    """solver/solve_film.py:440-574, main branch (no terminals, no vortices)."""
+    circulating_currents = circulating_currents or {}
+    Hz = applied_field
+    if field_from_other_films is not None:
+        Hz = Hz + field_from_other_films
+    g = np.zeros_like(Hz)
+    Ha_eff = np.zeros_like(Hz)
+    for hname, ix in film.hole_indices.items():  # :498-503 (also when I_circ == 0)
+        g[ix] += circulating_currents.get(hname, 0)
+        Ha_eff += -(film.A_holes[hname] @ g[ix])
+    ix = film.film_indices
+    h = Hz[ix] - Ha_eff[ix]
+    gf = la.lu_solve(film.lu_piv, h)  # :530  => g = -A^-1 h
+    g[ix] += gf
+    J = np.array([film.mesh.gradient_y @ g, -(film.mesh.gradient_x @ g)]).T  # :556
+    screening = film.Q @ (film.weights * g)  # :565
+    other = None
+    if field_from_other_films is not None:
+        other = field_from_other_films / field_conversion
+    return OracleFilmSolution(
+        stream=g,
+        current_density=J,
+        applied_field=applied_field / field_conversion,
+        self_field=screening / field_conversion,
+        field_from_other_films=other,
+    )
+
+
+# --------------------------------------------------------------------------------------
+# Inter-film coupling and the Jacobi loop (solver/solve.py)
+# --------------------------------------------------------------------------------------
+def biot_savart_film_to_film(*, film1_sites, film1_z0, film1_areas, film1_J, film2_sites,
+                             film2_z0, block: int = 2048) -> np.ndarray:
+    """solver/solve.py:28-73 -- H_i = sum_j (1/4pi) a_j (Jx_j dy - Jy_j dx) r^-3,
+    dx = x_i(target) - x_j(source); output dtype = dtype of ``film1_J``."""
+    one_over_4pi = 1 / (4 * np.pi)
+    dz2 = (film2_z0 - film1_z0) ** 2
+    m = film2_sites.shape[0]
+    out = np.empty(m, dtype=film1_J.dtype)
+    xs, ys = film1_sites[:, 0], film1_sites[:, 1]
+    aJx = film1_areas * film1_J[:, 0]
+    aJy = film1_areas * film1_J[:, 1]
+    for i0 in range(0, m, block):
+        i1 = min(m, i0 + block)
+        dx = film2_sites[i0:i1, 0, None] - xs[None, :]
+        dy = film2_sites[i0:i1, 1, None] - ys[None, :]
+        r3 = (dx * dx + dy * dy + dz2) ** (-1.5)
+        out[i0:i1] = one_over_4pi * np.sum((aJx * dy - aJy * dx) * r3, axis=1)
+    return out
+
+
+def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
+          circulating_currents: Optional[Dict[str, float]] = None,
+          field_conversion: Optional[float] = None) -> List[Dict[str, OracleFilmSolution]]:
+    """solver/solve.py:422-547 -- first pass, then ``iterations`` Jacobi rounds.  Returns the
+    per-iteration list (length ``iterations + 1``; 1 for a single film, :486-489).
+
+    ``applied_field_mT``: float (uniform field in mT) or callable ``f(x, y, z)``.
+    """
+    conv = field_conversion_mT_to_uA_per_um() if field_conversion is None else field_conversion
+    applied = {}
+    for f in films:
+        x, y = f.mesh.sites[:, 0], f.mesh.sites[:, 1]
+        z = f.z0 * np.ones(len(x))
+        val = applied_field_mT(x, y, z) if callable(applied_field_mT) else applied_field_mT * np.ones_like(x)
+        applied[f.name] = np.squeeze(val * conv).astype(f.dtype, copy=False)  # :426-430
+
+    def one_pass(other):
+        return {
+            f.name: solve_film(
+                f, applied[f.name], field_conversion=conv,
+                circulating_currents=circulating_currents,
+                field_from_other_films=None if other is None else other[f.name],
+            )
+            for f in films
+        }
+
+    sols = one_pass(None)
+    out = [sols]
+    if len(films) < 2 or iterations < 1:
+        return out
+    for _ in range(iterations):
+        other = {f.name: np.zeros(len(f.mesh.sites), dtype=f.dtype) for f in films}
+        for src, tgt in itertools.product(films, repeat=2):  # :499-515
+            if src is tgt:
+                continue
+            other[tgt.name] += biot_savart_film_to_film(
+                film1_sites=src.mesh.sites, film1_z0=src.z0, film1_areas=src.weights,
+                film1_J=sols[src.name].current_density, film2_sites=tgt.mesh.sites,
+                film2_z0=tgt.z0,
+            )
+        sols = one_pass(other)  # Jacobi: all films use the previous iterate (:520-536)
+        out.append(sols)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Fluxoid (solution.py:484-563, 278-319) in raw units: field_units * length^2
+# --------------------------------------------------------------------------------------
+def polygon_fluxoid_raw(film: OracleFilm, sol: OracleFilmSolution, polygon_points: np.ndarray,
+                        in_polygon: np.ndarray, in_film_poly: np.ndarray) -> Tuple[float, float]:
+    """Returns ``(flux_part [mT um^2], int_J [uA um])``.
+
+    ``flux_part = sum_{i in polygon} total_field_i w_i`` (solution.py:535-538);
+    ``int_J = trapezoid(Lambda_k * sum_xy(J_k * dl_k))`` over polygon vertices k = 0..N-2 with
+    unit spacing (:556-559), J from ``matplotlib.tri.LinearTriInterpolator`` with non-finite /
+    out-of-film values set to 0 (:313-315).  The supercurrent part in field*length^2 is
+    ``mu_0 * int_J``.  ``in_polygon``: polygon.contains_points(sites); ``in_film_poly``:
+    film.contains_points(polygon_points).
+    """
+    from matplotlib.tri import LinearTriInterpolator, Triangulation
+
+    flux_part = float(np.sum(sol.total_field[in_polygon] * film.mesh.weights[in_polygon]))
+    tri = Triangulation(film.mesh.sites[:, 0], film.mesh.sites[:, 1], film.mesh.elements)
+    J = sol.current_density
+    xv, yv = polygon_points[:, 0], polygon_points[:, 1]
+    Jp = np.array([
+        LinearTriInterpolator(tri, J[:, 0])(xv, yv).data,
+        LinearTriInterpolator(tri, J[:, 1])(xv, yv).data,
+    ]).T
+    Jp[~in_film_poly] = 0
+    Jp[~np.isfinite(Jp).all(axis=1)] = 0
+    Lam = float(film.Lambda[0]) * np.ones(len(polygon_points))
+    dl = np.diff(polygon_points, axis=0)
+    int_J = float(np.trapezoid(Lam[:-1] * np.sum(Jp[:-1] * dl, axis=1)))
+    return flux_part, int_J
+
+
+def fluxoid_in_Phi0(flux_part_mT_um2: float, int_J_uA_um: float) -> Tuple[float, float]:
+    """Unit conversion of the two parts to Phi_0 (solution.py:538, 560-561)."""
+    flux = flux_part_mT_um2 * 1e-3 * 1e-12 / PHI_0
+    sc = MU_0 * int_J_uA_um * 1e-6 * 1e-6 / PHI_0
+    return flux, sc

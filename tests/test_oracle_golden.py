@@ -1,0 +1,127 @@
+"""Pins the CPU oracle (oracle/superscreen_oracle.py) against fixtures recorded from the
+reference itself (oracle/make_golden.py).  Runs anywhere (no GPU, no /root/reference)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from matplotlib.path import Path
+
+import superscreen_oracle as orc
+
+RTOL = 1e-11  # fp64 both sides; differences = summation order + LAPACK rounding
+
+
+def csr(d, prefix, shape):
+    return sp.csr_array((d[f"{prefix}_data"], d[f"{prefix}_indices"], d[f"{prefix}_indptr"]), shape=shape)
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def contains(poly, pts):
+    return Path(poly, closed=True).contains_points(pts)
+
+
+@pytest.mark.parametrize("name", ["disk_K10.npz", "disk_K26.npz", "washer_K17.npz"])
+def test_mesh_operators(golden, name):
+    d = golden(name)
+    mesh = orc.make_mesh(d["sites"], d["elements"])
+    n, m = len(d["sites"]), len(d["elements"])
+    assert np.array_equal(mesh.boundary_indices, d["boundary_indices"])
+    assert relerr(mesh.triangle_areas, d["triangle_areas"]) < 1e-14
+    assert relerr(mesh.weights, d["weights"]) < 1e-14
+    assert relerr(orc.C_vector(d["sites"]), d["C"]) < 1e-14
+    assert relerr(np.diag(mesh.Q), d["Q_diag"]) < 1e-13
+    assert relerr(mesh.Q[d["sample_rows"]], d["Q_rows"]) < 1e-13
+    if "Q" in d:
+        assert relerr(mesh.Q, d["Q"]) < 1e-13
+    for prefix, op, shape in [
+        ("lap", mesh.laplacian, (n, n)), ("gx", mesh.gradient_x, (n, n)),
+        ("gy", mesh.gradient_y, (n, n)), ("Gx", mesh.gradient_tri_x, (m, n)),
+        ("Gy", mesh.gradient_tri_y, (m, n)),
+    ]:
+        ref = csr(d, prefix, shape)
+        diff = abs(op - ref)
+        assert diff.max() <= 1e-11 * abs(ref).max(), prefix
+
+
+@pytest.mark.parametrize("name", ["disk_K10.npz", "disk_K26.npz", "washer_K17.npz"])
+def test_film_system_and_solve(golden, name):
+    d = golden(name)
+    mesh = orc.make_mesh(d["sites"], d["elements"])
+    in_film = contains(d["film_poly"], d["sites"])
+    holes = {"hole": contains(d["hole_poly"], d["sites"])} if bool(d["washer"]) else {}
+    conv = float(d["field_conversion"])
+    for li, Lam in enumerate(d["Lambdas"]):
+        film = orc.make_film("film", mesh, z0=0.0, Lambda=Lam, in_film=in_film, holes_mask=holes)
+        assert np.array_equal(film.film_indices, d["film_indices"])
+        if holes:
+            assert np.array_equal(film.hole_indices["hole"], d["hole_indices"])
+            assert relerr(film.A_holes["hole"][d["sample_rows"]], d[f"A_hole_rows_L{li}"]) < 1e-12
+        assert relerr(film.A[d[f"A_rows_idx_L{li}"]], d[f"A_rows_L{li}"]) < 1e-12
+        assert relerr(np.diag(film.A), d[f"A_diag_L{li}"]) < 1e-12
+        assert np.array_equal(film.lu_piv[1], d[f"piv_L{li}"])
+        for ci, circ in enumerate(d["circs"]):
+            applied = conv * np.ones(len(d["sites"]))
+            sol = orc.solve_film(film, applied, field_conversion=conv,
+                                 circulating_currents={"hole": float(circ)})
+            tag = f"L{li}_c{ci}"
+            assert relerr(sol.stream, d[f"g_{tag}"]) < RTOL
+            assert relerr(sol.current_density, d[f"J_{tag}"]) < RTOL
+            assert relerr(sol.self_field, d[f"self_field_{tag}"]) < RTOL
+            assert relerr(sol.applied_field, d[f"applied_field_{tag}"]) < 1e-15
+
+
+def test_biot_savart(golden):
+    d = golden("biot_savart.npz")
+    for tag in ("dz05", "dz0_disjoint", "dzneg"):
+        za, zb, shift = d[f"args_{tag}"]
+        H = orc.biot_savart_film_to_film(
+            film1_sites=d["sites1"], film1_z0=za, film1_areas=d["areas"], film1_J=d["J"],
+            film2_sites=d["sites2"] + np.array([shift, 0.0]), film2_z0=zb)
+        assert relerr(H, d[f"H_{tag}"]) < 1e-12
+
+
+def _stack(d):
+    import importlib.util, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_syn", os.path.join(here, "superscreen_amd", "synthetic.py"))
+    syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(syn)
+    K = int(d["K"])
+    sites, elements, dr = syn.ring_disk_mesh(K)
+    mesh = orc.make_mesh(sites, elements)
+    Kf = syn.film_rings(K)
+    film_poly = syn.circle_points((Kf + 0.5) * dr)
+    hole_poly = syn.circle_points((Kf // 3 + 0.5) * dr, 201)
+    films = []
+    for nm, kind, z in zip(d["names"], d["kinds"], d["z0s"]):
+        holes = {f"hole_{nm}": contains(hole_poly, sites)} if kind == "washer" else {}
+        films.append(orc.make_film(str(nm), mesh, z0=float(z), Lambda=float(d["Lambda"]),
+                                   in_film=contains(film_poly, sites), holes_mask=holes))
+    return films, film_poly
+
+
+@pytest.mark.parametrize("name", ["stack2_K12.npz", "stack3_K8.npz"])
+def test_jacobi_trace_and_fluxoid(golden, name):
+    d = golden(name)
+    films, film_poly = _stack(d)
+    circ = {f"hole_{nm}": float(d["circ"]) for nm in d["names"]}
+    trace = orc.solve(films, float(d["field_mT"]), iterations=int(d["iterations"]),
+                      circulating_currents=circ, field_conversion=float(d["field_conversion"]))
+    assert len(trace) == int(d["iterations"]) + 1
+    for it, sols in enumerate(trace):
+        for nm in d["names"]:
+            nm = str(nm)
+            assert relerr(sols[nm].stream, d[f"g_{nm}_it{it}"]) < RTOL
+            assert relerr(sols[nm].current_density, d[f"J_{nm}_it{it}"]) < RTOL
+            assert relerr(sols[nm].self_field, d[f"self_field_{nm}_it{it}"]) < RTOL
+            if it > 0:
+                assert relerr(sols[nm].field_from_other_films, d[f"other_{nm}_it{it}"]) < RTOL
+    nm = str(d["fluxoid_film"])
+    film = next(f for f in films if f.name == nm)
+    poly = d["fluxoid_poly"]
+    flux, int_J = orc.polygon_fluxoid_raw(film, trace[-1][nm], poly,
+                                          contains(poly, film.mesh.sites), contains(film_poly, poly))
+    assert abs(flux - float(d["flux_part_raw"])) < 1e-10 * abs(float(d["flux_part_raw"]))
+    assert abs(int_J - float(d["int_J_raw"])) < 1e-10 * abs(float(d["int_J_raw"]))
