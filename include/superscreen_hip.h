@@ -1,0 +1,230 @@
+/*
+ * superscreen_hip.h -- C ABI of libsuperscreen_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (loganbvh/superscreen v0.13.0) has no FFI of its own: its hot path is
+ * Python calling numba-JIT kernels and scipy/LAPACK.  Each entry point below replaces one
+ * of those call sites; the reference interface it stands in for is cited as file:line
+ * relative to /root/reference/superscreen/.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add at each of these sites.
+ *
+ * Conventions
+ *   - every function returns an int status: SSA_OK (0) or a negative SSA_ERR_* code;
+ *     nothing throws across the boundary;
+ *   - all pointers are DEVICE pointers (hipMalloc'd / torch CUDA tensors) unless the
+ *     parameter is documented as host; buffers are caller-owned; no hidden allocation:
+ *     scratch space is passed in explicitly and sized by the *_workspace_bytes queries;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only
+ *     enqueue work, they never synchronise; one stream per call, re-entrant across
+ *     streams and devices (the current HIP device of the calling thread is used);
+ *   - matrices are row-major ("C order", numpy default) with an explicit leading
+ *     dimension ld (elements between consecutive rows, ld >= number of columns);
+ *     ld must be even for n x n outputs so that rows stay 16-byte aligned;
+ *   - `dtype` selects the storage/solve precision (device.solve_dtype of the reference,
+ *     device/device.py:57): SSA_F32 or SSA_F64.  Geometry (xy, vertex areas w, edge
+ *     vector C, sparse operator values) is always float64, like mesh.sites in the
+ *     reference (distance.py:101: Q is always evaluated in float64 and cast afterwards,
+ *     solver/utils.py:291);
+ *   - index arrays are int64 (reference: np.int64), LU pivots int32 0-based LAPACK-style
+ *     row interchanges (scipy.linalg.lu_factor's `piv`).
+ */
+#ifndef SUPERSCREEN_HIP_H
+#define SUPERSCREEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSA_F32 0
+#define SSA_F64 1
+
+#define SSA_OK 0
+#define SSA_ERR_INVALID_ARGUMENT (-1)
+#define SSA_ERR_HIP (-2)
+#define SSA_ERR_WORKSPACE_TOO_SMALL (-3)
+#define SSA_ERR_UNSUPPORTED_SIZE (-4)
+
+#define SSA_ABI_VERSION 1
+
+/* Library / device introspection (host-side, no reference counterpart). */
+int ssa_abi_version(void);
+const char *ssa_error_string(int status);
+/* Fills compute-unit count and total HBM bytes of the current device. */
+int ssa_device_info(int *num_cus, size_t *hbm_bytes, char *arch_name, int arch_name_len);
+
+/* ---------------------------------------------------------------------------------- */
+/* (1) Kernel matrix Q                                                                 */
+/* ---------------------------------------------------------------------------------- */
+
+/*
+ * Replaces  MeshOperators.Q_matrix(points, weights)  device/mesh.py:435-458, i.e.
+ *   q = distance.q_matrix(points)        distance.py:87-115   q_ij = 1/(4 pi |r_i-r_j|^3)
+ *   diag = -(C + einsum("ij,j->i", q, w)) / w ; fill_diagonal(q, diag) ; return -q
+ * fused into one pass:  Q_ij = -q_ij (i != j),  Q_ii = (C_i + sum_{l != i} q_il w_l)/w_i.
+ *   xy    [n,2] f64   mesh sites
+ *   w     [n]   f64   vertex areas (mesh.operators.weights)
+ *   C     [n]   f64   edge vector (MeshOperators.C_vector, device/mesh.py:401-432)
+ *   Q     [n,ldq] dtype  out (may be NULL: only the diagonal is produced)
+ *   qdiag [n]   f64   out, Q_ii in float64 (may be NULL)
+ */
+int ssa_q_assemble(const double *xy, const double *w, const double *C, int64_t n, void *Q,
+                   int64_t ldq, int dtype, double *qdiag, void *stream);
+
+/*
+ * Replaces  _build_system_2d / _build_system_1d  solver/solve_film.py:285-305 together with
+ * the dense operands they slice (film_info.kernel, film_info.laplacian -- the latter is
+ * `laplacian.toarray()` in the reference, solver/utils.py:292; here it stays CSR):
+ *   out[r,c] = sign * ( Q[i,j] * w[j] - Lambda[j] * Del2[i,j] ),  i = rows[r], j = cols[c]
+ * with Q_ij regenerated on the fly from the sites (never read from HBM).
+ *   rows/cols  int64 vertex indices (rows may be NULL = identity 0..nr-1)
+ *   qdiag [n] f64 from ssa_q_assemble;  Lambda [n] f64 (cast to dtype inside, like
+ *   solver/utils.py:269);  lap_* CSR of the mesh Laplacian (n x n, f64 values)
+ *   sign = -1 writes -A directly, which is what gets LU-factored (solve_film.py:279).
+ *   workspace: ssa_system_assemble_workspace_bytes(n, nr, nc)
+ */
+size_t ssa_system_assemble_workspace_bytes(int64_t n, int64_t nr, int64_t nc);
+int ssa_system_assemble(const double *xy, const double *w, const double *qdiag,
+                        const double *Lambda, int64_t n, const int64_t *lap_indptr,
+                        const int64_t *lap_indices, const double *lap_data,
+                        const int64_t *rows, int64_t nr, const int64_t *cols, int64_t nc,
+                        double sign, void *out, int64_t ldo, int dtype, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------- */
+/* (2) Dense LU factor / solve                                                         */
+/* ---------------------------------------------------------------------------------- */
+
+/*
+ * Replaces  scipy.linalg.lu_factor(-A)  solver/solve_film.py:279 (LAPACK ?getrf):
+ * in-place blocked right-looking LU with partial (row) pivoting, P*A = L*U, L unit lower.
+ *   A    [n,lda] dtype  in: matrix, out: L\U
+ *   ipiv [n] int32      out: row i was interchanged with row ipiv[i] (0-based)
+ *   info [1] int32      out (device): 0, or k+1 if U[k,k] is exactly zero (LAPACK info)
+ *   aux                 out: ssa_lu_aux_bytes(n, dtype) bytes that ssa_lu_solve needs
+ *                       (inverses of the diagonal blocks of L and U)
+ *   workspace           ssa_lu_factor_workspace_bytes(n, dtype), scratch
+ */
+size_t ssa_lu_factor_workspace_bytes(int64_t n, int dtype);
+size_t ssa_lu_aux_bytes(int64_t n, int dtype);
+int ssa_lu_factor(void *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, void *aux,
+                  int dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Turns LAPACK interchanges into a gather permutation: perm[i] = index of the original row
+ * that ends up in row i (LU == A[perm]).  HOST arrays, pure C, no GPU work.
+ */
+int ssa_lu_pivots_to_permutation(const int32_t *ipiv_host, int64_t n, int64_t *perm_host);
+
+/*
+ * Replaces  scipy.linalg.lu_solve(lu_piv, h)  solver/solve_film.py:530 (LAPACK ?getrs)
+ * for a right-hand side that has ALREADY been row-permuted (b = h[perm]); the permutation
+ * is folded into the gather of ssa_film_rhs.  Solves L U X = B in place.
+ *   B [n,ldb] dtype  in: permuted rhs, out: solution; nrhs >= 1 columns (batched sweeps)
+ *   workspace: ssa_lu_solve_workspace_bytes(n, nrhs, dtype)
+ */
+size_t ssa_lu_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
+int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *B,
+                 int64_t nrhs, int64_t ldb, int dtype, void *workspace,
+                 size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------- */
+/* (3) Per-film vector kernels of solve_film                                           */
+/* ---------------------------------------------------------------------------------- */
+
+/*
+ * Replaces BLAS gemv at  solver/solve_film.py:503 (A_hole @ g[ix]) and :565 (Q @ (w*g)):
+ *   y[r] = alpha * sum_c M[r,c] * (xscale ? xscale[c] : 1) * x[xidx ? xidx[c] : c]
+ *          + beta * y[r]
+ *   M [nr,ldm] dtype; x, y dtype; xscale [nc] dtype or NULL; xidx int64 [nc] or NULL.
+ * (Batched right-hand sides go through ssa_row_scale + ssa_gemm instead.)
+ */
+int ssa_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *x,
+             const void *xscale, const int64_t *xidx, void *y, double alpha, double beta,
+             int dtype, void *stream);
+
+/* y[r,b] = s[r] * x[r,b]  (the w*g of solve_film.py:565 for batched g), row-major [nr,nvec]. */
+int ssa_row_scale(const void *x, const void *s, void *y, int64_t nr, int64_t nvec, int dtype,
+                  void *stream);
+
+/*
+ * Matrix-free form of  Q @ (w * g)  (solver/solve_film.py:565): regenerates q_ij from the
+ * sites instead of reading n^2 stored entries.
+ *   out[i] = alpha * ( qdiag[i] w[i] g[i] - sum_{j != i} q_ij w[j] g[j] )
+ */
+int ssa_self_field(const double *xy, const double *w, const double *qdiag, const void *g,
+                   int64_t n, void *out, double alpha, int dtype, void *workspace,
+                   size_t workspace_bytes, void *stream);
+size_t ssa_self_field_workspace_bytes(int64_t n);
+
+/*
+ * Replaces  h = Hz_applied[indices] - Ha_eff[indices]  solver/solve_film.py:486-488,526-529
+ * with the LU row permutation folded in (see ssa_lu_solve):
+ *   h[k,b] = applied[idx[k], b] + (other ? other[idx[k], b] : 0) - ha_eff[idx[k], b]
+ * idx = film indices composed with the LU permutation; all arrays dtype, row-major [.,nvec].
+ */
+int ssa_film_rhs(const void *applied, const void *other, const void *ha_eff,
+                 const int64_t *idx, int64_t ni, int64_t nvec, void *h, int dtype,
+                 void *stream);
+
+/* g[idx[k], b] += gf[k, b]   (solver/solve_film.py:531)  */
+int ssa_scatter_add(void *g, const int64_t *idx, const void *gf, int64_t ni, int64_t nvec,
+                    int dtype, void *stream);
+
+/* g[idx[k], b] += value[b]  (hole boundary condition g[hole] = I_circ, solve_film.py:498-502);
+ * value is a HOST array of nvec doubles. */
+int ssa_index_add_scalar(void *g, const int64_t *idx, int64_t ni, const double *value_host,
+                         int64_t nvec, int dtype, void *stream);
+
+/*
+ * Replaces the two scipy.sparse CSR SpMVs of  solver/solve_film.py:556
+ *   J = [grad_y @ g, -(grad_x @ g)].T          (float64 operators => float64 J)
+ * gx / gy share one CSR pattern (indptr, indices) with two value arrays.
+ *   g [n,nvec] dtype;  J [n,nvec,2] f64 out.
+ */
+int ssa_current_density(const int64_t *indptr, const int64_t *indices, const double *gx_data,
+                        const double *gy_data, const void *g, int64_t n, int64_t nvec,
+                        double *J, int dtype, void *stream);
+
+/* y[i] = alpha * x[i] (elementwise; the "/ field_conversion" of solve_film.py:566-574). */
+int ssa_scale(const void *x, void *y, double alpha, int64_t count, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------- */
+/* (4) Inter-film Biot-Savart coupling                                                 */
+/* ---------------------------------------------------------------------------------- */
+
+/*
+ * Replaces  biot_savart_film_to_film  solver/solve.py:28-73 and the accumulation
+ * `other_screening_fields[film] += ...` (:508):
+ *   out[i] (+)= sum_{j in [src_begin, src_end)} (1/4pi) a_j (Jx_j dy - Jy_j dx)
+ *                                               (dx^2 + dy^2 + dz^2)^(-3/2)
+ *   dx = tgt_xy[i,0] - src_xy[j,0], dy likewise; dz = z0(target) - z0(source).
+ *   src_areas [ns] dtype (film_info.weights), src_J [ns,2] f64, out [nt] dtype.
+ *   accumulate != 0 adds into out (float64 arithmetic, one rounding to dtype at the end).
+ * [src_begin, src_end) lets several GPUs each sum a slice of the sources; the partial
+ * fields are then summed with one RCCL all-reduce (superscreen_amd.parallel).
+ *   workspace: ssa_biot_savart_workspace_bytes(nt)
+ */
+size_t ssa_biot_savart_workspace_bytes(int64_t nt);
+int ssa_biot_savart(const double *src_xy, const void *src_areas, const double *src_J,
+                    int64_t ns, int64_t src_begin, int64_t src_end, const double *tgt_xy,
+                    int64_t nt, double dz, void *out, int accumulate, int dtype,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------- */
+/* (5) Building blocks exposed for tests and benchmarks                                */
+/* ---------------------------------------------------------------------------------- */
+
+/* C = alpha * A(MxK) * B(KxN) + beta * C, row-major, MFMA tiles (the LU trailing update). */
+int ssa_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64_t lda,
+             const void *B, int64_t ldb, double beta, void *C, int64_t ldc, int dtype,
+             void *stream);
+
+/* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern (roofline peak). */
+int ssa_fill_probe(void *dst, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUPERSCREEN_HIP_H */

@@ -1,0 +1,28 @@
+"""superscreen_amd -- MI355X-native hot path of SuperScreen's London-equation solver.
+
+Drop-in for the ``Device`` / ``Layer`` / ``Polygon`` / ``factorize_model`` / ``solve`` path of
+loganbvh/superscreen (reference v0.13.0); the numerics run in hand-written HIP kernels for
+gfx950 behind the C ABI declared in ``include/superscreen_hip.h``.  See DESIGN.md.
+"""
+from .version import __version__  # noqa: F401
+
+_LAZY = {
+    "Device": "device", "Layer": "device", "Polygon": "device",
+    "Mesh": "mesh", "MeshOperators": "mesh",
+    "Parameter": "parameter", "Constant": "parameter",
+    "ConstantField": "sources",
+    "solve": "solver", "factorize_model": "solver", "FactorizedModel": "solver",
+    "LinearSystem": "solver", "FilmInfo": "solver", "LambdaInfo": "solver",
+    "convert_field": "units", "field_conversion_factor": "units",
+    "Solution": "solution", "FilmSolution": "solution", "Fluxoid": "solution",
+    "Vortex": "solution",
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+
+        mod = importlib.import_module(f".{_LAZY[name]}", __name__)
+        return getattr(mod, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

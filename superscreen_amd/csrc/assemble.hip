@@ -1,0 +1,273 @@
+// Tiled all-pairs assembly of the kernel matrix Q and of the film / hole systems
+//   A = Q[rows, cols] * w[cols] - Lambda[cols] * Del2[rows, cols]
+// for gfx950.  HBM-write bound: every output element is generated from 40 bytes of vertex
+// data held on chip and written exactly once (no intermediate n^2 passes; the reference
+// makes 4: q_matrix, einsum row-sum, fill_diagonal, unary minus -- device/mesh.py:453-458).
+//
+// Work decomposition: one workgroup (4 waves) owns a strip of TR consecutive rows and
+// sweeps all columns; lane <-> two adjacent columns, so each wave-instruction stores 1 KiB
+// (f64) of one row, fully coalesced.  Row coordinates are wave-uniform and come from LDS as
+// broadcast reads; the row sums needed for the diagonal stay in registers (TR per lane) and
+// are reduced once per strip (wave shuffle + one LDS hop), so the diagonal costs no extra
+// pass over memory.
+#include "common.hpp"
+
+namespace ssa {
+
+constexpr int kStripRows = 16;
+constexpr int kAsmThreads = 256;
+
+template <typename OutT>
+struct Pair;
+template <>
+struct Pair<double> {
+    using type = double2;
+};
+template <>
+struct Pair<float> {
+    using type = float2;
+};
+
+template <typename OutT>
+__device__ __forceinline__ void store_pair(OutT *p, OutT a, OutT b) {
+    typename Pair<OutT>::type v;
+    v.x = a;
+    v.y = b;
+    *reinterpret_cast<typename Pair<OutT>::type *>(p) = v;
+}
+
+// Q_ij = -q_ij (i != j), Q_ii = (C_i + sum_{l != i} q_il w_l) / w_i.
+template <typename OutT, int TR>
+__global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
+    const double *__restrict__ xy, const double *__restrict__ w, const double *__restrict__ C,
+    int64_t n, OutT *__restrict__ Q, int64_t ldq, double *__restrict__ qdiag) {
+    __shared__ double s_part[kAsmThreads / kWave][TR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * TR;
+
+    // Row coordinates are workgroup-uniform: scalar loads into SGPRs, no LDS traffic.
+    double xi[TR], yi[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const int64_t i = (i0 + r < n) ? i0 + r : n - 1;
+        xi[r] = xy[2 * i];
+        yi[r] = xy[2 * i + 1];
+    }
+    double acc[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) acc[r] = 0.0;
+
+    for (int64_t j = 2 * tid; j < n; j += 2 * kAsmThreads) {
+        const bool has1 = (j + 1 < n);
+        const double xj0 = xy[2 * j], yj0 = xy[2 * j + 1];
+        const double xj1 = has1 ? xy[2 * j + 2] : 0.0;
+        const double yj1 = has1 ? xy[2 * j + 3] : 0.0;
+        const double w0 = w[j];
+        const double w1 = has1 ? w[j + 1] : 0.0;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int64_t i = i0 + r;
+            const double dx0 = xi[r] - xj0, dy0 = yi[r] - yj0;
+            const double dx1 = xi[r] - xj1, dy1 = yi[r] - yj1;
+            double q0 = inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
+            double q1 = inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
+            q0 = (i == j) ? 0.0 : q0;                  // distance.py:104-105
+            q1 = (i == j + 1 || !has1) ? 0.0 : q1;
+            acc[r] = __builtin_fma(q0, w0, acc[r]);
+            acc[r] = __builtin_fma(q1, w1, acc[r]);
+            if (Q != nullptr && i < n) {
+                store_pair<OutT>(Q + i * ldq + j, static_cast<OutT>(-q0), static_cast<OutT>(-q1));
+            }
+        }
+    }
+    // Row sums: lanes -> waves -> strip.
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const double s = wave_sum(acc[r]);
+        if (lane == 0) s_part[wave][r] = s;
+    }
+    __syncthreads();  // also drains this workgroup's stores (vmcnt(0)) before the diagonal
+    if (tid < TR && i0 + tid < n) {
+        const int64_t i = i0 + tid;
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < kAsmThreads / kWave; ++v) s += s_part[v][tid];
+        const double d = (C[i] + s) / w[i];  // device/mesh.py:455-457
+        if (qdiag != nullptr) qdiag[i] = d;
+        if (Q != nullptr) Q[i * ldq + i] = static_cast<OutT>(d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// System assembly: gather prep + strip kernel + sparse Laplacian fix-up.
+// ---------------------------------------------------------------------------------------
+__global__ void gather_vertex_kernel(const double *__restrict__ xy, const double *__restrict__ a,
+                                     const double *__restrict__ b,
+                                     const int64_t *__restrict__ idx, int64_t count,
+                                     double *__restrict__ ox, double *__restrict__ oy,
+                                     double *__restrict__ oa, double *__restrict__ ob,
+                                     int64_t *__restrict__ oid, int32_t *__restrict__ pos) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t i = idx ? idx[k] : k;
+    ox[k] = xy[2 * i];
+    oy[k] = xy[2 * i + 1];
+    if (oa) oa[k] = a[i];
+    if (ob) ob[k] = b[i];
+    oid[k] = i;
+    if (pos) pos[i] = static_cast<int32_t>(k);
+}
+
+template <typename OutT, int TR>
+__global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
+    const double *__restrict__ row_x, const double *__restrict__ row_y,
+    const double *__restrict__ row_qd, const int64_t *__restrict__ row_id, int64_t nr,
+    const double *__restrict__ col_x, const double *__restrict__ col_y,
+    const double *__restrict__ col_w, const double *__restrict__ col_lam,
+    const int64_t *__restrict__ col_id, int64_t nc, OutT sign, OutT *__restrict__ out,
+    int64_t ldo, const int64_t *__restrict__ lap_indptr, const int64_t *__restrict__ lap_indices,
+    const double *__restrict__ lap_data, const int32_t *__restrict__ col_pos) {
+    __shared__ double s_x[TR];
+    __shared__ double s_y[TR];
+    __shared__ double s_qd[TR];
+    __shared__ int64_t s_id[TR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * TR;
+    if (tid < TR) {
+        const int64_t r = (r0 + tid < nr) ? r0 + tid : nr - 1;
+        s_x[tid] = row_x[r];
+        s_y[tid] = row_y[r];
+        s_qd[tid] = row_qd[r];
+        s_id[tid] = row_id[r];
+    }
+    __syncthreads();
+
+    for (int64_t c = 2 * tid; c < nc; c += 2 * kAsmThreads) {
+        const bool has1 = (c + 1 < nc);
+        const double xj0 = col_x[c], yj0 = col_y[c];
+        const double xj1 = has1 ? col_x[c + 1] : 0.0;
+        const double yj1 = has1 ? col_y[c + 1] : 0.0;
+        const OutT w0 = static_cast<OutT>(col_w[c]);
+        const OutT w1 = has1 ? static_cast<OutT>(col_w[c + 1]) : OutT(0);
+        const int64_t id0 = col_id[c];
+        const int64_t id1 = has1 ? col_id[c + 1] : -1;
+#pragma unroll 8
+        for (int r = 0; r < TR; ++r) {
+            if (r0 + r >= nr) break;
+            const int64_t i = s_id[r];
+            const double xi = s_x[r], yi = s_y[r];
+            const double dx0 = xi - xj0, dy0 = yi - yj0;
+            const double dx1 = xi - xj1, dy1 = yi - yj1;
+            double q0 = -inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
+            double q1 = -inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
+            q0 = (i == id0) ? s_qd[r] : q0;  // Q_ii
+            q1 = (i == id1) ? s_qd[r] : q1;
+            // Q is cast to the solve dtype before the product (solver/utils.py:291,
+            // solve_film.py:305): out = Q[ix,ix] * w[ix]  (column scaling).
+            const OutT v0 = sign * (static_cast<OutT>(q0) * w0);
+            const OutT v1 = has1 ? sign * (static_cast<OutT>(q1) * w1) : OutT(0);
+            OutT *dst = out + (r0 + r) * ldo + c;
+            if (has1 || c + 1 < ldo) {
+                store_pair<OutT>(dst, v0, v1);
+            } else {
+                *dst = v0;
+            }
+        }
+    }
+    __syncthreads();  // stores of this strip are complete (vmcnt(0)) before the fix-up
+
+    // - Lambda[j] * Del2[i, j]: one wave per row walks the CSR row (about 7 entries).
+    for (int r = wave; r < TR; r += kAsmThreads / kWave) {
+        if (r0 + r >= nr) break;
+        const int64_t i = s_id[r];
+        const int64_t p1 = lap_indptr[i + 1];
+        for (int64_t p = lap_indptr[i] + lane; p < p1; p += kWave) {
+            const int32_t c = col_pos[lap_indices[p]];
+            if (c >= 0) {
+                OutT *dst = out + (r0 + r) * ldo + c;
+                const OutT t = static_cast<OutT>(col_lam[c]) * static_cast<OutT>(lap_data[p]);
+                *dst = *dst - sign * t;
+            }
+        }
+    }
+}
+
+}  // namespace ssa
+
+using namespace ssa;
+
+extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C, int64_t n,
+                              void *Q, int64_t ldq, int dtype, double *qdiag, void *stream) {
+    if (n <= 0 || !xy || !w || !C) return SSA_ERR_INVALID_ARGUMENT;
+    if (Q && (ldq < n || (ldq & 1))) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(ceil_div(n, kStripRows)));
+    if (dtype == SSA_F64) {
+        hipLaunchKernelGGL((q_assemble_kernel<double, kStripRows>), grid, dim3(kAsmThreads), 0,
+                           as_stream(stream), xy, w, C, n, static_cast<double *>(Q), ldq, qdiag);
+    } else {
+        hipLaunchKernelGGL((q_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads), 0,
+                           as_stream(stream), xy, w, C, n, static_cast<float *>(Q), ldq, qdiag);
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" size_t ssa_system_assemble_workspace_bytes(int64_t n, int64_t nr, int64_t nc) {
+    size_t b = 0;
+    b += 4 * align_up(static_cast<size_t>(nr) * 8, 256);  // row x, y, qd, id
+    b += 5 * align_up(static_cast<size_t>(nc) * 8, 256);  // col x, y, w, lam, id
+    b += align_up(static_cast<size_t>(n) * 4, 256);       // col_pos
+    return b + 256;
+}
+
+extern "C" int ssa_system_assemble(const double *xy, const double *w, const double *qdiag,
+                                   const double *Lambda, int64_t n, const int64_t *lap_indptr,
+                                   const int64_t *lap_indices, const double *lap_data,
+                                   const int64_t *rows, int64_t nr, const int64_t *cols,
+                                   int64_t nc, double sign, void *out, int64_t ldo, int dtype,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (n <= 0 || nr <= 0 || nc <= 0 || !xy || !w || !qdiag || !Lambda || !out || !cols ||
+        !lap_indptr || !lap_indices || !lap_data)
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (ldo < nc) return SSA_ERR_INVALID_ARGUMENT;
+    if ((ldo & 1) && nc > 1) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_system_assemble_workspace_bytes(n, nr, nc))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = as_stream(stream);
+    Carver cv(workspace);
+    double *row_x = cv.take<double>(nr), *row_y = cv.take<double>(nr);
+    double *row_qd = cv.take<double>(nr);
+    int64_t *row_id = cv.take<int64_t>(nr);
+    double *col_x = cv.take<double>(nc), *col_y = cv.take<double>(nc);
+    double *col_w = cv.take<double>(nc), *col_lam = cv.take<double>(nc);
+    int64_t *col_id = cv.take<int64_t>(nc);
+    int32_t *col_pos = cv.take<int32_t>(n);
+    if (hipMemsetAsync(col_pos, 0xFF, static_cast<size_t>(n) * 4, st) != hipSuccess)
+        return SSA_ERR_HIP;
+    const int tb = 256;
+    hipLaunchKernelGGL(gather_vertex_kernel, dim3(ceil_div(nr, tb)), dim3(tb), 0, st, xy, qdiag,
+                       (const double *)nullptr, rows, nr, row_x, row_y, row_qd,
+                       (double *)nullptr, row_id, (int32_t *)nullptr);
+    hipLaunchKernelGGL(gather_vertex_kernel, dim3(ceil_div(nc, tb)), dim3(tb), 0, st, xy, w,
+                       Lambda, cols, nc, col_x, col_y, col_w, col_lam, col_id, col_pos);
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr, kStripRows)));
+    if (dtype == SSA_F64) {
+        hipLaunchKernelGGL((system_assemble_kernel<double, kStripRows>), grid, dim3(kAsmThreads),
+                           0, st, row_x, row_y, row_qd, row_id, nr, col_x, col_y, col_w, col_lam,
+                           col_id, nc, sign, static_cast<double *>(out), ldo, lap_indptr,
+                           lap_indices, lap_data, col_pos);
+    } else {
+        hipLaunchKernelGGL((system_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads),
+                           0, st, row_x, row_y, row_qd, row_id, nr, col_x, col_y, col_w, col_lam,
+                           col_id, nc, static_cast<float>(sign), static_cast<float *>(out), ldo,
+                           lap_indptr, lap_indices, lap_data, col_pos);
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}

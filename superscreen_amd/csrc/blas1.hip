@@ -1,0 +1,326 @@
+// Bandwidth-bound vector kernels of solve_film (solver/solve_film.py:486-574): dense GEMV,
+// CSR gradient SpMV, gathers / scatters, scaling; plus the HBM fill probe used by bench.py.
+#include "common.hpp"
+
+namespace ssa {
+
+// ---------------------------------------------------------------------------------------
+// GEMV  y = alpha * M (xscale .* x[xidx]) + beta * y,  M row-major.
+// One wave owns ROWS consecutive rows and strides over the columns with 16-byte loads, so
+// each x element fetched from L2 is reused ROWS times; four waves per workgroup.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+    using type = double2;
+    static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+    using type = float4;
+    static constexpr int N = 4;
+};
+
+template <typename T, int ROWS, bool VECTOR>
+__global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int64_t nr,
+                                                   int64_t nc, int64_t ldm,
+                                                   const T *__restrict__ x,
+                                                   const T *__restrict__ xscale,
+                                                   const int64_t *__restrict__ xidx,
+                                                   T *__restrict__ y, T alpha, T beta) {
+    constexpr int VN = VECTOR ? Vec16<T>::N : 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * ROWS;
+    if (row0 >= nr) return;
+    T acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = T(0);
+    const T *rowp[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int64_t rr = (row0 + r < nr) ? row0 + r : nr - 1;
+        rowp[r] = M + rr * ldm;
+    }
+    const int64_t nc_vec = VECTOR ? (nc / VN) * VN : 0;
+    if (VECTOR) {
+        using V = typename Vec16<T>::type;
+#pragma unroll 2
+        for (int64_t c = static_cast<int64_t>(lane) * VN; c < nc_vec; c += 64 * VN) {
+            T xv[VN];
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const int64_t cc = c + k;
+                T v = x[xidx ? xidx[cc] : cc];
+                if (xscale) v *= xscale[cc];
+                xv[k] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const V mv = *reinterpret_cast<const V *>(rowp[r] + c);
+                const T *mp = reinterpret_cast<const T *>(&mv);
+#pragma unroll
+                for (int k = 0; k < VN; ++k) acc[r] += mp[k] * xv[k];
+            }
+        }
+    }
+    for (int64_t c = nc_vec + lane; c < nc; c += 64) {
+        T v = x[xidx ? xidx[c] : c];
+        if (xscale) v *= xscale[c];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r] += rowp[r][c] * v;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const T s = wave_sum(acc[r]);
+        if (lane == 0 && row0 + r < nr) {
+            T out = alpha * s;
+            if (beta != T(0)) out += beta * y[row0 + r];
+            y[row0 + r] = out;
+        }
+    }
+}
+
+template <typename T>
+int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *x,
+                const void *xscale, const int64_t *xidx, void *y, double alpha, double beta,
+                hipStream_t st) {
+    constexpr int ROWS = 4;
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr, 4 * ROWS)));
+    const bool aligned = (reinterpret_cast<uintptr_t>(M) % 16 == 0) &&
+                         ((ldm * sizeof(T)) % 16 == 0);
+    const T *Mp = static_cast<const T *>(M);
+    const T *xp = static_cast<const T *>(x);
+    const T *sp = static_cast<const T *>(xscale);
+    T *yp = static_cast<T *>(y);
+    if (aligned) {
+        hipLaunchKernelGGL((gemv_kernel<T, ROWS, true>), grid, dim3(256), 0, st, Mp, nr, nc, ldm,
+                           xp, sp, xidx, yp, static_cast<T>(alpha), static_cast<T>(beta));
+    } else {
+        hipLaunchKernelGGL((gemv_kernel<T, ROWS, false>), grid, dim3(256), 0, st, Mp, nr, nc, ldm,
+                           xp, sp, xidx, yp, static_cast<T>(alpha), static_cast<T>(beta));
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Small elementwise / gather / scatter kernels
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void row_scale_kernel(const T *__restrict__ x, const T *__restrict__ s,
+                                 T *__restrict__ y, int64_t nr, int64_t nvec) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= nr * nvec) return;
+    y[t] = s[t / nvec] * x[t];
+}
+
+template <typename T>
+__global__ void film_rhs_kernel(const T *__restrict__ applied, const T *__restrict__ other,
+                                const T *__restrict__ ha_eff, const int64_t *__restrict__ idx,
+                                int64_t ni, int64_t nvec, T *__restrict__ h) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= ni * nvec) return;
+    const int64_t k = t / nvec, b = t - k * nvec;
+    const int64_t src = idx[k] * nvec + b;
+    T hz = applied[src];
+    if (other) hz = hz + other[src];  // solve_film.py:486-488
+    h[t] = hz - ha_eff[src];          // :529
+}
+
+template <typename T>
+__global__ void scatter_add_kernel(T *__restrict__ g, const int64_t *__restrict__ idx,
+                                   const T *__restrict__ gf, int64_t ni, int64_t nvec) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= ni * nvec) return;
+    const int64_t k = t / nvec, b = t - k * nvec;
+    g[idx[k] * nvec + b] += gf[t];
+}
+
+constexpr int kMaxScalarVec = 64;
+struct ScalarVec {
+    double v[kMaxScalarVec];
+};
+
+template <typename T>
+__global__ void index_add_scalar_kernel(T *__restrict__ g, const int64_t *__restrict__ idx,
+                                        int64_t ni, int64_t nvec, ScalarVec val) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= ni * nvec) return;
+    const int64_t k = t / nvec, b = t - k * nvec;
+    g[idx[k] * nvec + b] += static_cast<T>(val.v[b]);
+}
+
+template <typename T>
+__global__ void scale_kernel(const T *__restrict__ x, T *__restrict__ y, T alpha, int64_t count) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < count) y[t] = alpha * x[t];
+}
+
+// ---------------------------------------------------------------------------------------
+// J = [gy @ g, -(gx @ g)]: CSR rows hold ~7 entries, so a wave is cut into eight 8-lane
+// segments, one row each; the segment sum is three xor-shuffles.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void current_density_kernel(
+    const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices,
+    const double *__restrict__ gx, const double *__restrict__ gy, const T *__restrict__ g,
+    int64_t n, int64_t nvec, double *__restrict__ J) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int sub = static_cast<int>(t & 7);
+    const int64_t b = blockIdx.y;
+    double sx = 0.0, sy = 0.0;
+    if (row < n) {
+        const int64_t p1 = indptr[row + 1];
+        for (int64_t p = indptr[row] + sub; p < p1; p += 8) {
+            const double gv = static_cast<double>(g[indices[p] * nvec + b]);
+            sx = __builtin_fma(gx[p], gv, sx);
+            sy = __builtin_fma(gy[p], gv, sy);
+        }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64);
+        sy += __shfl_xor(sy, off, 64);
+    }
+    if (row < n && sub == 0) {
+        double2 out;
+        out.x = sy;    // Jx =  dg/dy
+        out.y = -sx;   // Jy = -dg/dx
+        *reinterpret_cast<double2 *>(J + (row * nvec + b) * 2) = out;
+    }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void fill_probe_kernel(u32x4 *__restrict__ dst, size_t count16) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count16;
+         i += stride)
+        __builtin_nontemporal_store(v, dst + i);
+}
+
+}  // namespace ssa
+
+using namespace ssa;
+
+#define SSA_DISPATCH(dtype, CALL_F64, CALL_F32) \
+    do {                                        \
+        if ((dtype) == SSA_F64) {               \
+            CALL_F64;                           \
+        } else if ((dtype) == SSA_F32) {        \
+            CALL_F32;                           \
+        } else {                                \
+            return SSA_ERR_INVALID_ARGUMENT;    \
+        }                                       \
+    } while (0)
+
+extern "C" int ssa_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *x,
+                        const void *xscale, const int64_t *xidx, void *y, double alpha,
+                        double beta, int dtype, void *stream) {
+    if (!M || !x || !y || nr <= 0 || nc <= 0 || ldm < nc) return SSA_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    if (dtype == SSA_F64) return launch_gemv<double>(M, nr, nc, ldm, x, xscale, xidx, y, alpha, beta, st);
+    if (dtype == SSA_F32) return launch_gemv<float>(M, nr, nc, ldm, x, xscale, xidx, y, alpha, beta, st);
+    return SSA_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" int ssa_row_scale(const void *x, const void *s, void *y, int64_t nr, int64_t nvec,
+                             int dtype, void *stream) {
+    if (!x || !s || !y || nr <= 0 || nvec <= 0) return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr * nvec, 256)));
+    SSA_DISPATCH(dtype,
+                 hipLaunchKernelGGL((row_scale_kernel<double>), grid, dim3(256), 0, as_stream(stream),
+                                    (const double *)x, (const double *)s, (double *)y, nr, nvec),
+                 hipLaunchKernelGGL((row_scale_kernel<float>), grid, dim3(256), 0, as_stream(stream),
+                                    (const float *)x, (const float *)s, (float *)y, nr, nvec));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_film_rhs(const void *applied, const void *other, const void *ha_eff,
+                            const int64_t *idx, int64_t ni, int64_t nvec, void *h, int dtype,
+                            void *stream) {
+    if (!applied || !ha_eff || !idx || !h || ni <= 0 || nvec <= 0) return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(ceil_div(ni * nvec, 256)));
+    SSA_DISPATCH(dtype,
+                 hipLaunchKernelGGL((film_rhs_kernel<double>), grid, dim3(256), 0, as_stream(stream),
+                                    (const double *)applied, (const double *)other,
+                                    (const double *)ha_eff, idx, ni, nvec, (double *)h),
+                 hipLaunchKernelGGL((film_rhs_kernel<float>), grid, dim3(256), 0, as_stream(stream),
+                                    (const float *)applied, (const float *)other,
+                                    (const float *)ha_eff, idx, ni, nvec, (float *)h));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_scatter_add(void *g, const int64_t *idx, const void *gf, int64_t ni,
+                               int64_t nvec, int dtype, void *stream) {
+    if (!g || !idx || !gf || ni <= 0 || nvec <= 0) return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(ceil_div(ni * nvec, 256)));
+    SSA_DISPATCH(dtype,
+                 hipLaunchKernelGGL((scatter_add_kernel<double>), grid, dim3(256), 0, as_stream(stream),
+                                    (double *)g, idx, (const double *)gf, ni, nvec),
+                 hipLaunchKernelGGL((scatter_add_kernel<float>), grid, dim3(256), 0, as_stream(stream),
+                                    (float *)g, idx, (const float *)gf, ni, nvec));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_index_add_scalar(void *g, const int64_t *idx, int64_t ni,
+                                    const double *value_host, int64_t nvec, int dtype,
+                                    void *stream) {
+    if (!g || !idx || !value_host || ni <= 0 || nvec <= 0) return SSA_ERR_INVALID_ARGUMENT;
+    if (nvec > kMaxScalarVec) return SSA_ERR_UNSUPPORTED_SIZE;
+    ScalarVec val;
+    for (int64_t b = 0; b < nvec; ++b) val.v[b] = value_host[b];
+    const dim3 grid(static_cast<unsigned>(ceil_div(ni * nvec, 256)));
+    SSA_DISPATCH(dtype,
+                 hipLaunchKernelGGL((index_add_scalar_kernel<double>), grid, dim3(256), 0,
+                                    as_stream(stream), (double *)g, idx, ni, nvec, val),
+                 hipLaunchKernelGGL((index_add_scalar_kernel<float>), grid, dim3(256), 0,
+                                    as_stream(stream), (float *)g, idx, ni, nvec, val));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_scale(const void *x, void *y, double alpha, int64_t count, int dtype,
+                         void *stream) {
+    if (!x || !y || count <= 0) return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(ceil_div(count, 256)));
+    SSA_DISPATCH(dtype,
+                 hipLaunchKernelGGL((scale_kernel<double>), grid, dim3(256), 0, as_stream(stream),
+                                    (const double *)x, (double *)y, alpha, count),
+                 hipLaunchKernelGGL((scale_kernel<float>), grid, dim3(256), 0, as_stream(stream),
+                                    (const float *)x, (float *)y, (float)alpha, count));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_current_density(const int64_t *indptr, const int64_t *indices,
+                                   const double *gx_data, const double *gy_data, const void *g,
+                                   int64_t n, int64_t nvec, double *J, int dtype, void *stream) {
+    if (!indptr || !indices || !gx_data || !gy_data || !g || !J || n <= 0 || nvec <= 0)
+        return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(ceil_div(n * 8, 256)), static_cast<unsigned>(nvec));
+    SSA_DISPATCH(dtype,
+                 hipLaunchKernelGGL((current_density_kernel<double>), grid, dim3(256), 0,
+                                    as_stream(stream), indptr, indices, gx_data, gy_data,
+                                    (const double *)g, n, nvec, J),
+                 hipLaunchKernelGGL((current_density_kernel<float>), grid, dim3(256), 0,
+                                    as_stream(stream), indptr, indices, gx_data, gy_data,
+                                    (const float *)g, n, nvec, J));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_fill_probe(void *dst, size_t bytes, void *stream) {
+    if (!dst || bytes < 16) return SSA_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(fill_probe_kernel, dim3(2048), dim3(256), 0, as_stream(stream),
+                       static_cast<u32x4 *>(dst), bytes / 16);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}

@@ -1,0 +1,63 @@
+// Shared helpers for the gfx950 kernels of libsuperscreen_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/superscreen_hip.h"
+
+namespace ssa {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define SSA_RETURN_IF_LAUNCH_FAILED()                 \
+    do {                                              \
+        if (hipGetLastError() != hipSuccess) {        \
+            return SSA_ERR_HIP;                       \
+        }                                             \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Carves 256-byte aligned sub-buffers out of a caller-provided workspace.
+struct Carver {
+    char *base;
+    size_t used;
+    explicit Carver(void *p) : base(static_cast<char *>(p)), used(0) {}
+    template <typename T>
+    T *take(size_t count) {
+        used = align_up(used, 256);
+        T *p = reinterpret_cast<T *>(base + used);
+        used += count * sizeof(T);
+        return p;
+    }
+};
+
+// 1/sqrt(x) in full double precision: hardware v_rsq_f64 seed + one cubically convergent
+// correction (seed error ~2^-26 or better -> ~2^-78 before rounding).
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    double p = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y * e, p, y);
+}
+
+constexpr double kOneOver4Pi = 0.07957747154594767;  // 1 / (4 pi)
+
+// q = (1/4pi) * r2^(-3/2)
+__device__ __forceinline__ double inv_r3_over_4pi(double r2) {
+    double y = rsqrt_f64(r2);
+    return (kOneOver4Pi * y) * (y * y);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace ssa

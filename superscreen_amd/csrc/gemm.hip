@@ -1,0 +1,280 @@
+// MFMA GEMM for gfx950:  C = alpha * A(MxK) * B(KxN) + beta * C, all row-major.
+// This is the trailing update of the blocked LU (K = panel width) and the block updates of
+// the triangular solves; dtype f64 uses v_mfma_f64_16x16x4_f64, f32 v_mfma_f32_16x16x4_f32.
+//
+// Tiling (wave64): workgroup = 4 waves (2 x 2) -> 128 x 128 tile of C; each wave owns a
+// 64 x 64 sub-tile = 4 x 4 MFMA tiles of 16 x 16 (16 accumulators).  K is consumed in
+// stages of KC = 16, double-buffered in LDS (global -> registers -> LDS; the loads of stage
+// t+1 are issued before the MFMAs of stage t and written after them, one barrier per stage).
+//
+// LDS images (conflict-free for the 16x16x4 operand maps, lane l: i|j = l & 15, k = l >> 4):
+//   A tile [128][KC + pad]   row-major as in memory (k contiguous); pad chosen so that the 16
+//                            rows read by a half-wave land in distinct 8-byte bank pairs
+//   B tile [KC][128 + pad]   row-major (n contiguous); pad makes consecutive k rows differ by
+//                            half a bank row (128 B) so lanes 16..31 use the other 32 banks.
+//
+// Workgroup ids are remapped (a) per XCD: ids that share an L2 get a contiguous range, and
+// (b) in groups of 8 tile-rows, so that the ~64 tiles resident on one XCD form an 8 x 8 block
+// sharing 8 A-panels and 8 B-panels (about 4 MiB at K = 256 in f64: one L2).
+#include "common.hpp"
+
+namespace ssa {
+
+constexpr int kGemmThreads = 256;
+constexpr int BM = 128, BN = 128, KC = 16;
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+    using acc_t = f64x4;
+    using vec_t = double2;
+    static constexpr int VEC = 2;
+    static constexpr int APAD = 2;
+    static constexpr int BPAD = 16;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct Mfma<float> {
+    using acc_t = f32x4;
+    using vec_t = float4;
+    static constexpr int VEC = 4;
+    static constexpr int APAD = 4;
+    static constexpr int BPAD = 16;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+template <typename T>
+struct GemmSmem {
+    static constexpr int SA = KC + Mfma<T>::APAD;
+    static constexpr int SB = BN + Mfma<T>::BPAD;
+    T a[2][BM * SA];
+    T b[2][KC * SB];
+};
+
+// One 16-byte global load with bounds handling; returns VEC elements (zero outside).
+template <typename T, bool ALIGNED>
+__device__ __forceinline__ void load_row_vec(const T *__restrict__ base, int64_t ld, int64_t row,
+                                             int64_t nrows, int64_t col, int64_t ncols,
+                                             T (&out)[Mfma<T>::VEC]) {
+    constexpr int VEC = Mfma<T>::VEC;
+    if (row < nrows && col + VEC <= ncols && ALIGNED) {
+        const typename Mfma<T>::vec_t v =
+            *reinterpret_cast<const typename Mfma<T>::vec_t *>(base + row * ld + col);
+        const T *p = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = p[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            out[k] = (row < nrows && col + k < ncols) ? base[row * ld + col + k] : T(0);
+    }
+}
+
+__device__ __forceinline__ void remap_tile(int64_t pid, int64_t ntm, int64_t ntn, int64_t &tm,
+                                           int64_t &tn) {
+    // (a) XCD-contiguous, bijective for any grid size (hipcc guide, T1).
+    const int64_t nwg = ntm * ntn;
+    const int64_t q = nwg / 8, r = nwg % 8;
+    const int64_t xcd = pid % 8;
+    const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pid / 8;
+    // (b) groups of 8 tile-rows, column-major inside a group.
+    constexpr int64_t G = 8;
+    const int64_t per_group = G * ntn;
+    const int64_t group = wg / per_group;
+    const int64_t first_m = group * G;
+    const int64_t gsize = (ntm - first_m < G) ? ntm - first_m : G;
+    const int64_t in_group = wg % per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+}
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
+    int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
+    const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
+    int64_t ntn) {
+    using MF = Mfma<T>;
+    using acc_t = typename MF::acc_t;
+    constexpr int VEC = MF::VEC;
+    constexpr int SA = GemmSmem<T>::SA, SB = GemmSmem<T>::SB;
+    // global -> register staging shapes
+    constexpr int A_VPR = KC / VEC;                   // vectors per A row
+    constexpr int A_RPP = kGemmThreads / A_VPR;       // A rows per pass
+    constexpr int A_PASS = BM / A_RPP;
+    constexpr int B_VPR = BN / VEC;                   // vectors per B row
+    constexpr int B_RPP = kGemmThreads / B_VPR;       // B rows per pass
+    constexpr int B_PASS = KC / B_RPP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GemmSmem<T> &sm = *reinterpret_cast<GemmSmem<T> *>(smem_raw);
+
+    int64_t tm, tn;
+    remap_tile(blockIdx.x, ntm, ntn, tm, tn);
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // number of live 16-wide sub-tiles of this wave (uniform): skip MFMAs on padding
+    const int64_t mrem = M - (m0 + wm * 64), nrem = N - (n0 + wn * 64);
+    const int mt_cnt = mrem <= 0 ? 0 : (mrem >= 64 ? 4 : static_cast<int>((mrem + 15) / 16));
+    const int nt_cnt = nrem <= 0 ? 0 : (nrem >= 64 ? 4 : static_cast<int>((nrem + 15) / 16));
+
+    const int a_r = tid / A_VPR, a_c = (tid % A_VPR) * VEC;
+    const int b_r = tid / B_VPR, b_c = (tid % B_VPR) * VEC;
+
+    T ra[A_PASS][VEC], rb[B_PASS][VEC];
+    auto load_stage = [&](int64_t k0) {
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p)
+            load_row_vec<T, ALIGNED>(A, lda, m0 + a_r + p * A_RPP, M, k0 + a_c, K, ra[p]);
+#pragma unroll
+        for (int p = 0; p < B_PASS; ++p)
+            load_row_vec<T, ALIGNED>(B, ldb, k0 + b_r + p * B_RPP, K, n0 + b_c, N, rb[p]);
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p) {
+            T *dst = &sm.a[buf][(a_r + p * A_RPP) * SA + a_c];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dst[k] = ra[p][k];
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASS; ++p) {
+            T *dst = &sm.b[buf][(b_r + p * B_RPP) * SB + b_c];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dst[k] = rb[p][k];
+        }
+    };
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+    const int64_t nk = (K + KC - 1) / KC;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = static_cast<int>(kt & 1);
+        if (kt + 1 < nk) load_stage((kt + 1) * KC);
+        const T *sa = &sm.a[cur][(wm * 64 + li) * SA + lk];
+        const T *sb = &sm.b[cur][lk * SB + wn * 64 + li];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            T fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = sa[i * 16 * SA + ks * 4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = sb[ks * 4 * SB + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < mt_cnt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < nt_cnt) acc[i][j] = MF::run(fa[i], fb[j], acc[i][j]);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < nk) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C = alpha * acc + beta * C
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= mt_cnt) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nt_cnt) continue;
+            const int64_t col = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * 64 + i * 16 + MF::row(lane, r);
+                if (row < M && col < N) {
+                    T *dst = C + row * ldc + col;
+                    T v = alpha * acc[i][j][r];
+                    if (beta != T(0)) v += beta * (*dst);
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64_t lda,
+                const void *B, int64_t ldb, double beta, void *C, int64_t ldc, hipStream_t st) {
+    if (M <= 0 || N <= 0) return SSA_OK;
+    const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
+    const size_t smem = sizeof(GemmSmem<T>);
+    const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
+                         ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
+    const dim3 grid(static_cast<unsigned>(ntm * ntn));
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(smem)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(smem)) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    if (aligned) {
+        hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(kGemmThreads), smem, st, M, N, K,
+                           static_cast<T>(alpha), static_cast<const T *>(A), lda,
+                           static_cast<const T *>(B), ldb, static_cast<T>(beta),
+                           static_cast<T *>(C), ldc, ntm, ntn);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<T, false>), grid, dim3(kGemmThreads), smem, st, M, N, K,
+                           static_cast<T>(alpha), static_cast<const T *>(A), lda,
+                           static_cast<const T *>(B), ldb, static_cast<T>(beta),
+                           static_cast<T *>(C), ldc, ntm, ntn);
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+// Used by lu.hip
+int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+             const double *B, int64_t ldb, double beta, double *C, int64_t ldc, hipStream_t st) {
+    return launch_gemm<double>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+             const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st) {
+    return launch_gemm<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+
+}  // namespace ssa
+
+using namespace ssa;
+
+extern "C" int ssa_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A,
+                        int64_t lda, const void *B, int64_t ldb, double beta, void *C,
+                        int64_t ldc, int dtype, void *stream) {
+    if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return SSA_ERR_INVALID_ARGUMENT;
+    if (lda < K || ldb < N || ldc < N) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype == SSA_F64)
+        return launch_gemm<double>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, as_stream(stream));
+    if (dtype == SSA_F32)
+        return launch_gemm<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, as_stream(stream));
+    return SSA_ERR_INVALID_ARGUMENT;
+}

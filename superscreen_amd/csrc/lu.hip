@@ -1,0 +1,628 @@
+// Dense LU factor / solve for gfx950 (replaces scipy.linalg.lu_factor / lu_solve = LAPACK
+// ?getrf / ?getrs at solver/solve_film.py:279 and :530).  Row-major storage, partial (row)
+// pivoting, right-looking, two-level blocking:
+//
+//   outer panel NB = 256 columns  -> trailing update C -= L21 * U12 is an MFMA GEMM with
+//                                    K = 256 (compute-bound: 2K/16 = 32 flop per C byte)
+//   sub-panel   PW = 64 columns   -> factored by ONE cooperative persistent kernel
+//                                    (lu_panel_kernel); the rest of the outer panel is then
+//                                    updated by laswp + trsm + a skinny GEMM (L2 resident)
+//
+// lu_panel_kernel: the (m x 64) sub-panel is cut into row slabs of <= 256 rows, one
+// workgroup per slab, each slab living in LDS (column-major, lane <-> row, odd row stride =>
+// conflict-free).  Per column: local |max| search -> every workgroup publishes its best
+// candidate ROW (write-through 8-byte stores) -> one sharded arrival counter -> every
+// workgroup picks the same global pivot, reads the winner's row and eliminates its own slab.
+// Rows never move inside the kernel: the LAPACK interchange sequence is tracked as a
+// permutation (every row knows its "current position") and applied when slabs are written
+// back, so the result -- including ipiv and tie-breaking on the lowest current position, as
+// i?amax does -- is what ?getf2 would produce.  Inter-workgroup hand-offs follow the CDNA4
+// recipe: sc1 payload stores, per-wave vmcnt(0) drain, relaxed agent-scope counter,
+// relaxed poll, sc1 loads; every spin is bounded.
+#include "common.hpp"
+
+namespace ssa {
+
+int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+             const double *B, int64_t ldb, double beta, double *C, int64_t ldc, hipStream_t st);
+int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+             const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st);
+
+template <typename T>
+int gemm_t(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B,
+           int64_t ldb, double beta, T *C, int64_t ldc, hipStream_t st);
+template <>
+int gemm_t<double>(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
+                   hipStream_t st) {
+    return gemm_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+template <>
+int gemm_t<float>(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                  const float *B, int64_t ldb, double beta, float *C, int64_t ldc,
+                  hipStream_t st) {
+    return gemm_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+
+constexpr int NB = 256;         // outer panel width
+constexpr int PW = 64;          // sub-panel width (one lane per column)
+constexpr int kPanelThreads = 256;
+constexpr int kSlabStride = kPanelThreads + 1;  // odd => conflict-free both ways
+constexpr int kShards = 8;      // arrival-counter shards (128 B apart)
+constexpr int kMaxPanelGroups = 256;
+constexpr unsigned kSpinLimit = 1u << 22;
+
+// ---- agent-scope (sc1) accessors for inter-workgroup traffic --------------------------
+#define SSA_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+                       static_cast<unsigned long long>(__double_as_longlong(v)), SSA_AGENT);
+}
+__device__ __forceinline__ void st_agent(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned int *>(p), __float_as_uint(v), SSA_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+        reinterpret_cast<const unsigned long long *>(p), SSA_AGENT)));
+}
+__device__ __forceinline__ float ld_agent(const float *p) {
+    return __uint_as_float(
+        __hip_atomic_load(reinterpret_cast<const unsigned int *>(p), SSA_AGENT));
+}
+
+struct Cand {  // pivot candidate: larger |value| wins, ties -> smaller current position
+    double absval;
+    int pos;   // current (LAPACK) position of the row, panel-relative
+    int aux;   // local row index (stage 1) or workgroup id (stage 2)
+    int orig;  // original panel-relative row index
+};
+__device__ __forceinline__ bool better(const Cand &a, const Cand &b) {  // a beats b
+    return (a.absval > b.absval) || (a.absval == b.absval && a.pos < b.pos);
+}
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Cand o;
+        o.absval = __shfl_xor(c.absval, off, 64);
+        o.pos = __shfl_xor(c.pos, off, 64);
+        o.aux = __shfl_xor(c.aux, off, 64);
+        o.orig = __shfl_xor(c.orig, off, 64);
+        if (better(o, c)) c = o;
+    }
+    return c;
+}
+
+template <typename T>
+struct PanelArgs {
+    T *A;
+    int64_t lda;
+    int64_t j0;        // first row == first column of the sub-panel
+    int m;             // rows in the sub-panel (n - j0)
+    int jb;            // columns (<= PW)
+    int rpw;           // rows per workgroup (<= kPanelThreads)
+    int32_t *ipiv;     // absolute, LAPACK style
+    int32_t *info;     // device scalar
+    unsigned int *cnt;            // [kShards * 32]
+    unsigned long long *hdr;      // [2][G][2]: {absval bits, pos << 32 | orig}
+    T *rows;                      // [2][G][PW]
+    unsigned int *timeout;        // set when a bounded spin gives up
+};
+
+template <typename T>
+__global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(PanelArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *slab = reinterpret_cast<T *>(smem_raw);                       // [PW][kSlabStride]
+    T *piv = slab + PW * kSlabStride;                                // [PW]
+    double *red_abs = reinterpret_cast<double *>(piv + PW);          // [2][4]
+    int *red_i = reinterpret_cast<int *>(red_abs + 8);               // [2][4][3]
+    int *row_at_top = red_i + 24;                                    // [PW]
+    int *piv_pos = row_at_top + PW;                                  // [PW]  ipiv, relative
+    int *bk = piv_pos + PW;                                          // [4] o, q, rJ, flag
+    int *fpos = bk + 4;                                              // [kPanelThreads]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int row_base = g * a.rpw;
+    const int myrows = max(0, min(a.rpw, a.m - row_base));
+    const int jb = a.jb;
+    T *Ap = a.A + a.j0 * a.lda + a.j0;  // panel origin
+
+    // ---- load the slab: wave <-> row, lane <-> column (coalesced 512 B row segments) ----
+    for (int r = wave; r < myrows; r += kPanelThreads / kWave) {
+        if (lane < jb) slab[lane * kSlabStride + r] = Ap[static_cast<int64_t>(row_base + r) * a.lda + lane];
+    }
+    if (tid < PW) row_at_top[tid] = tid;
+    const int orig = row_base + tid;
+    int curpos = orig;
+    bool done = (tid >= myrows);
+    int finalpos = -1;
+    __syncthreads();
+
+    for (int J = 0; J < jb; ++J) {
+        const int buf = J & 1;
+        // (1) best candidate of this workgroup
+        Cand c;
+        c.absval = done ? -1.0 : fabs(static_cast<double>(slab[J * kSlabStride + tid]));
+        c.pos = curpos;
+        c.aux = tid;
+        c.orig = orig;
+        c = wave_best(c);
+        if (lane == 0) {
+            red_abs[wave] = c.absval;
+            red_i[wave * 3 + 0] = c.pos;
+            red_i[wave * 3 + 1] = c.aux;
+            red_i[wave * 3 + 2] = c.orig;
+        }
+        __syncthreads();  // #1
+        Cand b;
+        b.absval = red_abs[0]; b.pos = red_i[0]; b.aux = red_i[1]; b.orig = red_i[2];
+#pragma unroll
+        for (int v = 1; v < kPanelThreads / kWave; ++v) {
+            Cand o;
+            o.absval = red_abs[v]; o.pos = red_i[v * 3]; o.aux = red_i[v * 3 + 1]; o.orig = red_i[v * 3 + 2];
+            if (better(o, b)) b = o;
+        }
+        // (2) publish candidate row + header, arrive, wait for everybody (wave 0 only)
+        if (wave == 0) {
+            T *slot = a.rows + (static_cast<size_t>(buf) * G + g) * PW;
+            if (lane < jb) {
+                const T v = (b.absval >= 0.0) ? slab[lane * kSlabStride + b.aux] : T(0);
+                st_agent(slot + lane, v);
+            }
+            if (lane == 0) {
+                unsigned long long *h = a.hdr + (static_cast<size_t>(buf) * G + g) * 2;
+                __hip_atomic_store(h, static_cast<unsigned long long>(__double_as_longlong(b.absval)), SSA_AGENT);
+                __hip_atomic_store(h + 1,
+                                   (static_cast<unsigned long long>(static_cast<unsigned int>(b.pos)) << 32) |
+                                       static_cast<unsigned int>(b.orig),
+                                   SSA_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(a.cnt + (g % kShards) * 32, 1u, SSA_AGENT);
+            // shard s receives one arrival per step from every workgroup with id % kShards == s
+            const unsigned per_step = (lane < kShards && lane < G) ? (G - lane + kShards - 1) / kShards : 0u;
+            const unsigned target = per_step * static_cast<unsigned>(J + 1);
+            bool ok = (per_step == 0u);
+            unsigned spins = 0;
+            int gave_up = 0;
+            while (true) {
+                if (!ok) ok = __hip_atomic_load(a.cnt + lane * 32, SSA_AGENT) >= target;
+                if (__all(ok)) break;
+                if (++spins > kSpinLimit) { gave_up = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) {
+                bk[3] = gave_up;
+                if (gave_up) __hip_atomic_store(a.timeout, 1u, SSA_AGENT);
+            }
+        }
+        __syncthreads();  // #2
+        if (bk[3]) {      // a peer never arrived: give up loudly (info = -1), never hang
+            if (g == 0 && tid == 0) *a.info = -1;
+            return;
+        }
+        // (3) global winner: thread t inspects workgroup t's header
+        Cand w;
+        w.absval = -2.0; w.pos = 0x7fffffff; w.aux = 0; w.orig = 0;
+        if (tid < G) {
+            const unsigned long long *h = a.hdr + (static_cast<size_t>(buf) * G + tid) * 2;
+            const unsigned long long v0 = __hip_atomic_load(h, SSA_AGENT);
+            const unsigned long long v1 = __hip_atomic_load(h + 1, SSA_AGENT);
+            w.absval = __longlong_as_double(static_cast<long long>(v0));
+            w.pos = static_cast<int>(v1 >> 32);
+            w.orig = static_cast<int>(v1 & 0xffffffffu);
+            w.aux = tid;
+        }
+        w = wave_best(w);
+        if (lane == 0) {
+            red_abs[4 + wave] = w.absval;
+            red_i[12 + wave * 3 + 0] = w.pos;
+            red_i[12 + wave * 3 + 1] = w.aux;
+            red_i[12 + wave * 3 + 2] = w.orig;
+        }
+        __syncthreads();  // #3
+        Cand p;
+        p.absval = red_abs[4]; p.pos = red_i[12]; p.aux = red_i[13]; p.orig = red_i[14];
+#pragma unroll
+        for (int v = 1; v < kPanelThreads / kWave; ++v) {
+            Cand o;
+            o.absval = red_abs[4 + v]; o.pos = red_i[12 + v * 3]; o.aux = red_i[12 + v * 3 + 1]; o.orig = red_i[12 + v * 3 + 2];
+            if (better(o, p)) p = o;
+        }
+        // (4) fetch the pivot row; replay the LAPACK interchange  row J <-> row p.pos
+        if (wave == 0) {
+            if (lane < jb) piv[lane] = ld_agent(a.rows + (static_cast<size_t>(buf) * G + p.aux) * PW + lane);
+            if (lane == 0) {
+                const int q = p.pos;
+                const int rJ = row_at_top[J];  // the row that currently sits at position J
+                if (q < PW) row_at_top[q] = rJ;
+                row_at_top[J] = p.orig;
+                piv_pos[J] = q;
+                bk[0] = p.orig; bk[1] = q; bk[2] = rJ;
+            }
+        }
+        __syncthreads();  // #4
+        const int o_row = bk[0], q_pos = bk[1], rJ = bk[2];
+        const bool was_active = !done;
+        if (orig == o_row) {
+            done = true;
+            finalpos = J;
+        } else if (orig == rJ) {
+            curpos = q_pos;
+        }
+        // (5) eliminate: l = a/pivot; row -= l * pivot_row   (?getf2: exact zero pivot =>
+        //     record info, skip the scaling; the column below is then all zeros)
+        if (p.absval == 0.0) {
+            if (g == 0 && tid == 0 && *a.info == 0) *a.info = static_cast<int32_t>(a.j0 + J + 1);
+        } else if (was_active && !done) {
+            const T pv = piv[J];
+            const T l = slab[J * kSlabStride + tid] / pv;
+            slab[J * kSlabStride + tid] = l;
+            for (int cidx = J + 1; cidx < jb; ++cidx)
+                slab[cidx * kSlabStride + tid] -= l * piv[cidx];
+        }
+    }
+
+    // ---- write back every row at its final position; workgroup 0 emits ipiv ------------
+    fpos[tid] = done && finalpos >= 0 ? finalpos : curpos;
+    __syncthreads();
+    for (int r = wave; r < myrows; r += kPanelThreads / kWave) {
+        if (lane < jb) Ap[static_cast<int64_t>(fpos[r]) * a.lda + lane] = slab[lane * kSlabStride + r];
+    }
+    if (g == 0 && tid < jb) a.ipiv[a.j0 + tid] = static_cast<int32_t>(a.j0 + piv_pos[tid]);
+}
+
+template <typename T>
+constexpr size_t panel_smem_bytes() {
+    return sizeof(T) * (PW * kSlabStride + PW) + 8 * sizeof(double) +
+           sizeof(int) * (24 + PW + PW + 4 + kPanelThreads) + 64;
+}
+
+// ---- row interchanges on column ranges [c0a,c1a) and [c0b,c1b) -------------------------
+template <typename T>
+__global__ void laswp_kernel(T *__restrict__ A, int64_t lda, int64_t c0a, int64_t c1a,
+                             int64_t c0b, int64_t c1b, const int32_t *__restrict__ ipiv,
+                             int64_t k0, int64_t k1) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t la = c1a - c0a;
+    int64_t c;
+    if (t < la) {
+        c = c0a + t;
+    } else if (t - la < c1b - c0b) {
+        c = c0b + (t - la);
+    } else {
+        return;
+    }
+    for (int64_t k = k0; k < k1; ++k) {
+        const int64_t p = ipiv[k];
+        if (p != k) {
+            const T x = A[k * lda + c], y = A[p * lda + c];
+            A[k * lda + c] = y;
+            A[p * lda + c] = x;
+        }
+    }
+}
+
+// ---- triangular solve with a (kb x kb) block, kb <= 256, in LDS -----------------------
+// LOWER-unit:  L X = B;   UPPER (non-unit): U X = B.   B is kb x N, solved in place in
+// strips of 32 columns (one workgroup each); blockIdx.y batches independent problems.
+// IDENT: B is not read; the right-hand side is the identity (=> X = inverse of the block).
+constexpr int TS = 32;   // strip width
+constexpr int TBLK = 64; // LDS block of the triangular matrix
+
+template <typename T, bool UPPER, bool IDENT>
+__global__ __launch_bounds__(256) void trsm_block_kernel(const T *__restrict__ Tri, int64_t ldt,
+                                                         int64_t tri_batch_stride, T *__restrict__ B,
+                                                         int64_t ldb, int64_t b_batch_stride,
+                                                         int kb, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *Bs = reinterpret_cast<T *>(smem_raw);         // [NB][TS + 1]
+    T *Ls = Bs + NB * (TS + 1);                      // [TBLK][TBLK + 1]
+    constexpr int SBs = TS + 1, SLs = TBLK + 1;
+    const int tid = threadIdx.x;
+    const int c = tid & (TS - 1), rg = tid / TS;     // 8 row groups
+    const int64_t n0 = static_cast<int64_t>(blockIdx.x) * TS;
+    Tri += static_cast<int64_t>(blockIdx.y) * tri_batch_stride;
+    B += static_cast<int64_t>(blockIdx.y) * b_batch_stride;
+    const bool col_ok = (n0 + c < N);
+
+    const int nblk = (kb + TBLK - 1) / TBLK;
+    for (int r = rg; r < nblk * TBLK; r += 8) {  // rows >= kb are zero padding
+        T v = T(0);
+        if (r < kb) {
+            if (IDENT) v = (n0 + c == r) ? T(1) : T(0);
+            else if (col_ok) v = B[static_cast<int64_t>(r) * ldb + n0 + c];
+        }
+        Bs[r * SBs + c] = v;
+    }
+    auto load_tri = [&](int rb, int cb) {  // Ls <- Tri[rb block, cb block], zero padded
+        for (int e = tid; e < TBLK * TBLK; e += 256) {
+            const int i = e / TBLK, k = e % TBLK;
+            const int gi = rb * TBLK + i, gk = cb * TBLK + k;
+            Ls[i * SLs + k] = (gi < kb && gk < kb) ? Tri[static_cast<int64_t>(gi) * ldt + gk] : T(0);
+        }
+    };
+    for (int step = 0; step < nblk; ++step) {
+        const int rb = UPPER ? nblk - 1 - step : step;
+        // off-diagonal blocks already solved: B_rb -= T[rb, cb] * X_cb
+        for (int s2 = 0; s2 < step; ++s2) {
+            const int cb = UPPER ? nblk - 1 - s2 : s2;
+            __syncthreads();
+            load_tri(rb, cb);
+            __syncthreads();
+            T acc[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = T(0);
+            for (int k = 0; k < TBLK; ++k) {
+                const T bv = Bs[min(cb * TBLK + k, NB - 1) * SBs + c];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] += Ls[(rg + 8 * t) * SLs + k] * bv;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int gi = rb * TBLK + rg + 8 * t;
+                if (gi < kb) Bs[gi * SBs + c] -= acc[t];
+            }
+        }
+        __syncthreads();
+        load_tri(rb, rb);
+        __syncthreads();
+        const int rows_here = min(TBLK, kb - rb * TBLK);
+        for (int kk = 0; kk < rows_here; ++kk) {
+            const int k = UPPER ? rows_here - 1 - kk : kk;
+            T xk = Bs[(rb * TBLK + k) * SBs + c];
+            if (UPPER) xk = xk / Ls[k * SLs + k];
+            __syncthreads();
+            if (UPPER && rg == 0) Bs[(rb * TBLK + k) * SBs + c] = xk;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int i = rg + 8 * t;
+                const bool below = UPPER ? (i < k) : (i > k && i < rows_here);
+                if (below) Bs[(rb * TBLK + i) * SBs + c] -= Ls[i * SLs + k] * xk;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int r = rg; r < kb; r += 8) {
+        if (col_ok) B[static_cast<int64_t>(r) * ldb + n0 + c] = Bs[r * SBs + c];
+    }
+}
+
+template <typename T>
+constexpr size_t trsm_smem_bytes() {
+    return sizeof(T) * (NB * (TS + 1) + TBLK * (TBLK + 1));
+}
+
+template <typename T, bool UPPER, bool IDENT>
+int launch_trsm(const T *Tri, int64_t ldt, int64_t tri_bs, T *B, int64_t ldb, int64_t b_bs, int kb,
+                int64_t N, int batch, hipStream_t st) {
+    if (kb <= 0 || N <= 0 || batch <= 0) return SSA_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_block_kernel<T, UPPER, IDENT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(trsm_smem_bytes<T>())) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    const dim3 grid(static_cast<unsigned>(ceil_div(N, TS)), static_cast<unsigned>(batch));
+    hipLaunchKernelGGL((trsm_block_kernel<T, UPPER, IDENT>), grid, dim3(256), trsm_smem_bytes<T>(), st,
+                       Tri, ldt, tri_bs, B, ldb, b_bs, kb, N);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+// ---- workspace layout ------------------------------------------------------------------
+struct PanelScratchBytes {
+    static constexpr size_t cnt = kShards * 32 * sizeof(unsigned int) + 128;  // + timeout word
+    static constexpr size_t hdr = 2 * kMaxPanelGroups * 2 * sizeof(unsigned long long);
+    template <typename T>
+    static constexpr size_t rows() { return 2 * static_cast<size_t>(kMaxPanelGroups) * PW * sizeof(T); }
+};
+
+template <typename T>
+int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, void *workspace,
+          hipStream_t st) {
+    static int num_cus = 0;  // co-residency bound for the cooperative panel kernel
+    if (num_cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return SSA_ERR_HIP;
+        num_cus = v;
+    }
+    const int max_groups = min(num_cus, kMaxPanelGroups);
+    if (ceil_div(n, kPanelThreads) > max_groups) return SSA_ERR_UNSUPPORTED_SIZE;
+
+    Carver cv(workspace);
+    unsigned int *cnt = cv.take<unsigned int>(kShards * 32 + 32);
+    unsigned int *timeout = cnt + kShards * 32;
+    unsigned long long *hdr = cv.take<unsigned long long>(2 * kMaxPanelGroups * 2);
+    T *rows = cv.take<T>(2 * static_cast<size_t>(kMaxPanelGroups) * PW);
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_panel_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(panel_smem_bytes<T>())) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
+
+    int rc;
+    for (int64_t k0 = 0; k0 < n; k0 += NB) {
+        const int64_t kb = (n - k0 < NB) ? n - k0 : NB;
+        for (int64_t j0 = k0; j0 < k0 + kb; j0 += PW) {
+            const int64_t jb = (k0 + kb - j0 < PW) ? k0 + kb - j0 : PW;
+            const int64_t m = n - j0;
+            const int G = static_cast<int>(ceil_div(m, kPanelThreads));
+            const int rpw = static_cast<int>(ceil_div(m, G));
+            if (hipMemsetAsync(cnt, 0, (kShards * 32 + 32) * sizeof(unsigned int), st) != hipSuccess)
+                return SSA_ERR_HIP;
+            PanelArgs<T> pa;
+            pa.A = A; pa.lda = lda; pa.j0 = j0; pa.m = static_cast<int>(m);
+            pa.jb = static_cast<int>(jb); pa.rpw = rpw; pa.ipiv = ipiv; pa.info = info;
+            pa.cnt = cnt; pa.hdr = hdr; pa.rows = rows; pa.timeout = timeout;
+            hipLaunchKernelGGL((lu_panel_kernel<T>), dim3(G), dim3(kPanelThreads),
+                               panel_smem_bytes<T>(), st, pa);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+            // interchanges for the other columns of the outer panel
+            const int64_t wa = j0 - k0, wb = (k0 + kb) - (j0 + jb);
+            if (wa + wb > 0) {
+                hipLaunchKernelGGL((laswp_kernel<T>), dim3(ceil_div(wa + wb, 256)), dim3(256), 0, st, A,
+                                   lda, k0, j0, j0 + jb, k0 + kb, ipiv, j0, j0 + jb);
+                SSA_RETURN_IF_LAUNCH_FAILED();
+            }
+            if (wb > 0) {
+                T *L11 = A + j0 * lda + j0;
+                T *U12 = A + j0 * lda + j0 + jb;
+                rc = launch_trsm<T, false, false>(L11, lda, 0, U12, lda, 0, static_cast<int>(jb), wb, 1, st);
+                if (rc != SSA_OK) return rc;
+                const int64_t mm = n - j0 - jb;
+                if (mm > 0) {
+                    rc = gemm_t<T>(mm, wb, jb, -1.0, A + (j0 + jb) * lda + j0, lda, U12, lda, 1.0,
+                                   A + (j0 + jb) * lda + j0 + jb, lda, st);
+                    if (rc != SSA_OK) return rc;
+                }
+            }
+        }
+        // interchanges left and right of the outer panel
+        const int64_t right = n - k0 - kb;
+        if (k0 + right > 0) {
+            hipLaunchKernelGGL((laswp_kernel<T>), dim3(ceil_div(k0 + right, 256)), dim3(256), 0, st, A, lda,
+                               static_cast<int64_t>(0), k0, k0 + kb, n, ipiv, k0, k0 + kb);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+        }
+        if (right > 0) {
+            T *L11 = A + k0 * lda + k0;
+            T *U12 = A + k0 * lda + k0 + kb;
+            rc = launch_trsm<T, false, false>(L11, lda, 0, U12, lda, 0, static_cast<int>(kb), right, 1, st);
+            if (rc != SSA_OK) return rc;
+            rc = gemm_t<T>(right, right, kb, -1.0, A + (k0 + kb) * lda + k0, lda, U12, lda, 1.0,
+                           A + (k0 + kb) * lda + k0 + kb, lda, st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    // aux = inverses of the diagonal NB x NB blocks of L (unit lower) and U, for ssa_lu_solve
+    const int64_t nblk = ceil_div(n, NB);
+    const int64_t full = n / NB;  // blocks with kb == NB can be batched
+    T *invL = aux, *invU = aux + nblk * NB * NB;
+    if (full > 0) {
+        rc = launch_trsm<T, false, true>(A, lda, NB * (lda + 1), invL, NB, NB * NB, NB, NB,
+                                         static_cast<int>(full), st);
+        if (rc != SSA_OK) return rc;
+        rc = launch_trsm<T, true, true>(A, lda, NB * (lda + 1), invU, NB, NB * NB, NB, NB,
+                                        static_cast<int>(full), st);
+        if (rc != SSA_OK) return rc;
+    }
+    if (full < nblk) {
+        const int kb = static_cast<int>(n - full * NB);
+        const T *D = A + full * NB * (lda + 1);
+        rc = launch_trsm<T, false, true>(D, lda, 0, invL + full * NB * NB, NB, 0, kb, kb, 1, st);
+        if (rc != SSA_OK) return rc;
+        rc = launch_trsm<T, true, true>(D, lda, 0, invU + full * NB * NB, NB, 0, kb, kb, 1, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
+// L U X = B (B already row-permuted).  Block forward / backward substitution where every
+// step is a GEMM: X_k = inv(L_kk) B_k ; B_{>k} -= L_{>k,k} X_k, then the mirror image with U.
+// X (workspace, n x nrhs) and B ping-pong so that no GEMM output aliases its input.
+template <typename T>
+int getrs(const T *LU, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb,
+          T *X, hipStream_t st) {
+    const int64_t nblk = ceil_div(n, NB);
+    const T *invL = aux, *invU = aux + nblk * NB * NB;
+    const int64_t ldx = nrhs;
+    int rc;
+    for (int64_t k = 0; k < nblk; ++k) {
+        const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
+        rc = gemm_t<T>(kb, nrhs, kb, 1.0, invL + k * NB * NB, NB, B + r0 * ldb, ldb, 0.0,
+                       X + r0 * ldx, ldx, st);
+        if (rc != SSA_OK) return rc;
+        const int64_t below = n - r0 - kb;
+        if (below > 0) {
+            rc = gemm_t<T>(below, nrhs, kb, -1.0, LU + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx,
+                           1.0, B + (r0 + kb) * ldb, ldb, st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    for (int64_t k = nblk - 1; k >= 0; --k) {
+        const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
+        rc = gemm_t<T>(kb, nrhs, kb, 1.0, invU + k * NB * NB, NB, X + r0 * ldx, ldx, 0.0,
+                       B + r0 * ldb, ldb, st);
+        if (rc != SSA_OK) return rc;
+        if (r0 > 0) {
+            rc = gemm_t<T>(r0, nrhs, kb, -1.0, LU + r0, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    return SSA_OK;
+}
+
+}  // namespace ssa
+
+using namespace ssa;
+
+extern "C" size_t ssa_lu_factor_workspace_bytes(int64_t n, int dtype) {
+    (void)n;
+    const size_t rows = dtype == SSA_F64 ? PanelScratchBytes::rows<double>() : PanelScratchBytes::rows<float>();
+    return PanelScratchBytes::cnt + PanelScratchBytes::hdr + rows + 4 * 256;
+}
+
+extern "C" size_t ssa_lu_aux_bytes(int64_t n, int dtype) {
+    const size_t es = dtype == SSA_F64 ? 8 : 4;
+    return 2 * static_cast<size_t>(ceil_div(n, NB)) * NB * NB * es;
+}
+
+extern "C" int ssa_lu_factor(void *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info,
+                             void *aux, int dtype, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+    if (!A || !ipiv || !info || !aux || n <= 0 || lda < n) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_lu_factor_workspace_bytes(n, dtype))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    if (dtype == SSA_F64)
+        return getrf<double>(static_cast<double *>(A), n, lda, ipiv, info, static_cast<double *>(aux),
+                             workspace, as_stream(stream));
+    return getrf<float>(static_cast<float *>(A), n, lda, ipiv, info, static_cast<float *>(aux),
+                        workspace, as_stream(stream));
+}
+
+extern "C" int ssa_lu_pivots_to_permutation(const int32_t *ipiv_host, int64_t n,
+                                            int64_t *perm_host) {
+    if (!ipiv_host || !perm_host || n < 0) return SSA_ERR_INVALID_ARGUMENT;
+    for (int64_t i = 0; i < n; ++i) perm_host[i] = i;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t p = ipiv_host[i];
+        if (p < 0 || p >= n) return SSA_ERR_INVALID_ARGUMENT;
+        const int64_t t = perm_host[i];
+        perm_host[i] = perm_host[p];
+        perm_host[p] = t;
+    }
+    return SSA_OK;
+}
+
+extern "C" size_t ssa_lu_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype) {
+    return static_cast<size_t>(n) * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) + 256;
+}
+
+extern "C" int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *B,
+                            int64_t nrhs, int64_t ldb, int dtype, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    if (!LU || !aux || !B || n <= 0 || nrhs <= 0 || lda < n || ldb < nrhs)
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_lu_solve_workspace_bytes(n, nrhs, dtype))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    if (dtype == SSA_F64)
+        return getrs<double>(static_cast<const double *>(LU), n, lda, static_cast<const double *>(aux),
+                             static_cast<double *>(B), nrhs, ldb, static_cast<double *>(workspace),
+                             as_stream(stream));
+    return getrs<float>(static_cast<const float *>(LU), n, lda, static_cast<const float *>(aux),
+                        static_cast<float *>(B), nrhs, ldb, static_cast<float *>(workspace),
+                        as_stream(stream));
+}

@@ -1,0 +1,221 @@
+// All-pairs reductions with no n^2 output: inter-film Biot-Savart coupling
+// (solver/solve.py:28-73) and the matrix-free self-field Q @ (w*g) (solve_film.py:565).
+// FP64-VALU bound: ~20 flops per (target, source) pair, 40 bytes per vertex of input.
+//
+// Decomposition: grid = (target blocks of 256) x (source slices); a workgroup stages 256
+// sources at a time in LDS (x, y and the two pre-multiplied "charges"), every lane owns one
+// target and reads the staged sources as LDS broadcasts.  Slice partial sums go to a
+// workspace [slices, nt] and are combined by a second tiny kernel in a fixed order, so the
+// result is bitwise reproducible (no float atomics).
+#include "common.hpp"
+
+namespace ssa {
+
+constexpr int kPairThreads = 256;
+constexpr int kMaxSlices = 64;
+
+struct alignas(16) Source {
+    double x, y, a, b;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kPairThreads) void biot_savart_partial_kernel(
+    const double *__restrict__ src_xy, const T *__restrict__ src_areas,
+    const double *__restrict__ src_J, int64_t src_begin, int64_t src_end, int64_t slice_len,
+    const double *__restrict__ tgt_xy, int64_t nt, double dz2, double *__restrict__ partial) {
+    __shared__ Source s_src[kPairThreads];
+    const int tid = threadIdx.x;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t j_begin = src_begin + static_cast<int64_t>(blockIdx.y) * slice_len;
+    const int64_t j_end = (j_begin + slice_len < src_end) ? j_begin + slice_len : src_end;
+    const int64_t ic = (i < nt) ? i : nt - 1;
+    const double xi = tgt_xy[2 * ic], yi = tgt_xy[2 * ic + 1];
+    double acc = 0.0;
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        const int64_t j = t0 + tid;
+        Source s;
+        if (j < j_end) {
+            const double a = kOneOver4Pi * static_cast<double>(src_areas[j]);
+            s.x = src_xy[2 * j];
+            s.y = src_xy[2 * j + 1];
+            s.a = a * src_J[2 * j];      // (1/4pi) a_j Jx_j
+            s.b = a * src_J[2 * j + 1];  // (1/4pi) a_j Jy_j
+        } else {
+            s.x = 0.0; s.y = 0.0; s.a = 0.0; s.b = 0.0;
+        }
+        __syncthreads();
+        s_src[tid] = s;
+        __syncthreads();
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const Source q = s_src[k];
+            const double dx = xi - q.x, dy = yi - q.y;
+            const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
+            const double y = rsqrt_f64(r2);
+            const double cross = __builtin_fma(q.a, dy, -(q.b * dx));  // Jx dy - Jy dx
+            acc = __builtin_fma(cross * y, y * y, acc);
+        }
+    }
+    if (i < nt) partial[static_cast<int64_t>(blockIdx.y) * nt + i] = acc;
+}
+
+// out[i] = alpha * ( qdiag_i w_i g_i - sum_{j != i} q_ij w_j g_j )   (partials: the sum only)
+template <typename T>
+__global__ __launch_bounds__(kPairThreads) void self_field_partial_kernel(
+    const double *__restrict__ xy, const double *__restrict__ w, const T *__restrict__ g,
+    int64_t n, int64_t slice_len, double *__restrict__ partial) {
+    __shared__ double s_x[kPairThreads], s_y[kPairThreads], s_c[kPairThreads];
+    const int tid = threadIdx.x;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
+    const int64_t j_end = (j_begin + slice_len < n) ? j_begin + slice_len : n;
+    const int64_t ic = (i < n) ? i : n - 1;
+    const double xi = xy[2 * ic], yi = xy[2 * ic + 1];
+    double acc = 0.0;
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        const int64_t j = t0 + tid;
+        double sx = 0.0, sy = 0.0, sc = 0.0;
+        if (j < j_end) {
+            sx = xy[2 * j];
+            sy = xy[2 * j + 1];
+            sc = kOneOver4Pi * (w[j] * static_cast<double>(g[j]));
+        }
+        __syncthreads();
+        s_x[tid] = sx; s_y[tid] = sy; s_c[tid] = sc;
+        __syncthreads();
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const double dx = xi - s_x[k], dy = yi - s_y[k];
+            const double r2 = __builtin_fma(dx, dx, dy * dy);
+            const double y = rsqrt_f64(r2);
+            const double t = (t0 + k == i) ? 0.0 : (s_c[k] * y) * (y * y);
+            acc += t;
+        }
+    }
+    if (i < n) partial[static_cast<int64_t>(blockIdx.y) * n + i] = acc;
+}
+
+template <typename T>
+__global__ void combine_partials_kernel(const double *__restrict__ partial, int slices,
+                                        int64_t nt, T *__restrict__ out, int accumulate) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    double s = 0.0;
+    for (int k = 0; k < slices; ++k) s += partial[static_cast<int64_t>(k) * nt + i];
+    if (accumulate) s += static_cast<double>(out[i]);  // solver/solve.py:508 (f64 add, one cast)
+    out[i] = static_cast<T>(s);
+}
+
+template <typename T>
+__global__ void self_field_combine_kernel(const double *__restrict__ partial, int slices,
+                                          int64_t n, const double *__restrict__ w,
+                                          const double *__restrict__ qdiag,
+                                          const T *__restrict__ g, double alpha,
+                                          T *__restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < slices; ++k) s += partial[static_cast<int64_t>(k) * n + i];
+    const double d = qdiag[i] * (w[i] * static_cast<double>(g[i]));
+    out[i] = static_cast<T>(alpha * (d - s));
+}
+
+inline int pick_slices(int64_t nt, int64_t ns) {
+    const int64_t tb = ceil_div(nt, kPairThreads);
+    int64_t s = ceil_div(2048, tb);
+    const int64_t max_by_len = ceil_div(ns, kPairThreads);  // at least one tile per slice
+    if (s > max_by_len) s = max_by_len;
+    if (s > kMaxSlices) s = kMaxSlices;
+    if (s < 1) s = 1;
+    return static_cast<int>(s);
+}
+
+}  // namespace ssa
+
+using namespace ssa;
+
+extern "C" size_t ssa_biot_savart_workspace_bytes(int64_t nt) {
+    return static_cast<size_t>(kMaxSlices) * static_cast<size_t>(nt) * sizeof(double) + 256;
+}
+
+extern "C" int ssa_biot_savart(const double *src_xy, const void *src_areas, const double *src_J,
+                               int64_t ns, int64_t src_begin, int64_t src_end,
+                               const double *tgt_xy, int64_t nt, double dz, void *out,
+                               int accumulate, int dtype, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    if (!src_xy || !src_areas || !src_J || !tgt_xy || !out || ns <= 0 || nt <= 0)
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (src_begin < 0 || src_end > ns || src_begin > src_end) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_biot_savart_workspace_bytes(nt))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = as_stream(stream);
+    double *partial = static_cast<double *>(workspace);
+    const int64_t len = src_end - src_begin;
+    int slices = 1;
+    if (len > 0) {
+        slices = pick_slices(nt, len);
+        const int64_t slice_len = ceil_div(ceil_div(len, slices), kPairThreads) * kPairThreads;
+        slices = static_cast<int>(ceil_div(len, slice_len));
+        const dim3 grid(static_cast<unsigned>(ceil_div(nt, kPairThreads)), slices);
+        if (dtype == SSA_F64) {
+            hipLaunchKernelGGL((biot_savart_partial_kernel<double>), grid, dim3(kPairThreads), 0,
+                               st, src_xy, static_cast<const double *>(src_areas), src_J,
+                               src_begin, src_end, slice_len, tgt_xy, nt, dz * dz, partial);
+        } else {
+            hipLaunchKernelGGL((biot_savart_partial_kernel<float>), grid, dim3(kPairThreads), 0,
+                               st, src_xy, static_cast<const float *>(src_areas), src_J,
+                               src_begin, src_end, slice_len, tgt_xy, nt, dz * dz, partial);
+        }
+        SSA_RETURN_IF_LAUNCH_FAILED();
+    } else {
+        slices = 0;
+    }
+    const dim3 cgrid(static_cast<unsigned>(ceil_div(nt, 256)));
+    if (dtype == SSA_F64) {
+        hipLaunchKernelGGL((combine_partials_kernel<double>), cgrid, dim3(256), 0, st, partial,
+                           slices, nt, static_cast<double *>(out), accumulate);
+    } else {
+        hipLaunchKernelGGL((combine_partials_kernel<float>), cgrid, dim3(256), 0, st, partial,
+                           slices, nt, static_cast<float *>(out), accumulate);
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" size_t ssa_self_field_workspace_bytes(int64_t n) {
+    return static_cast<size_t>(kMaxSlices) * static_cast<size_t>(n) * sizeof(double) + 256;
+}
+
+extern "C" int ssa_self_field(const double *xy, const double *w, const double *qdiag,
+                              const void *g, int64_t n, void *out, double alpha, int dtype,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    if (!xy || !w || !qdiag || !g || !out || n <= 0) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_self_field_workspace_bytes(n))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = as_stream(stream);
+    double *partial = static_cast<double *>(workspace);
+    int slices = pick_slices(n, n);
+    const int64_t slice_len = ceil_div(ceil_div(n, slices), kPairThreads) * kPairThreads;
+    slices = static_cast<int>(ceil_div(n, slice_len));
+    const dim3 grid(static_cast<unsigned>(ceil_div(n, kPairThreads)), slices);
+    const dim3 cgrid(static_cast<unsigned>(ceil_div(n, 256)));
+    if (dtype == SSA_F64) {
+        hipLaunchKernelGGL((self_field_partial_kernel<double>), grid, dim3(kPairThreads), 0, st,
+                           xy, w, static_cast<const double *>(g), n, slice_len, partial);
+        hipLaunchKernelGGL((self_field_combine_kernel<double>), cgrid, dim3(256), 0, st, partial,
+                           slices, n, w, qdiag, static_cast<const double *>(g), alpha,
+                           static_cast<double *>(out));
+    } else {
+        hipLaunchKernelGGL((self_field_partial_kernel<float>), grid, dim3(kPairThreads), 0, st, xy,
+                           w, static_cast<const float *>(g), n, slice_len, partial);
+        hipLaunchKernelGGL((self_field_combine_kernel<float>), cgrid, dim3(256), 0, st, partial,
+                           slices, n, w, qdiag, static_cast<const float *>(g), alpha,
+                           static_cast<float *>(out));
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}

@@ -1,0 +1,253 @@
+"""Thin, typed wrappers around the C ABI (``include/superscreen_hip.h``) operating on torch
+CUDA tensors.  One function per entry point; the docstrings name the reference call site
+each one replaces (paths relative to ``/root/reference/superscreen/``).
+
+PyTorch provides device buffers and the stream; all arithmetic happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import check, current_stream, dtype_code, load_library, ptr
+
+
+def _tdtype(dtype) -> torch.dtype:
+    return torch.float64 if dtype_code(dtype) == _hip.SSA_F64 else torch.float32
+
+
+def padded_ld(n: int, dtype) -> int:
+    """Leading dimension that keeps every row 128-byte aligned (full cache lines)."""
+    per_line = 128 // (8 if dtype_code(dtype) == _hip.SSA_F64 else 4)
+    return (n + per_line - 1) // per_line * per_line
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def device_info() -> Tuple[int, int, str]:
+    lib = load_library()
+    cus = ctypes.c_int(0)
+    mem = ctypes.c_size_t(0)
+    name = ctypes.create_string_buffer(64)
+    check(lib.ssa_device_info(ctypes.byref(cus), ctypes.byref(mem), name, 64), "ssa_device_info")
+    return cus.value, mem.value, name.value.decode()
+
+
+# ---------------------------------------------------------------------------------------
+def q_assemble(xy: torch.Tensor, w: torch.Tensor, C: torch.Tensor, dtype, *,
+               want_Q: bool = True, ld: Optional[int] = None,
+               out: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """``MeshOperators.Q_matrix`` (device/mesh.py:435-458) incl. ``q_matrix``
+    (distance.py:87-115).  Returns ``(Q [n, ld] or None, qdiag [n] float64)``."""
+    lib = load_library()
+    n = xy.shape[0]
+    qdiag = torch.empty(n, dtype=torch.float64, device=xy.device)
+    Q = None
+    ldq = 0
+    if want_Q:
+        ldq = ld or padded_ld(n, dtype)
+        Q = out if out is not None else torch.empty((n, ldq), dtype=_tdtype(dtype), device=xy.device)
+    check(lib.ssa_q_assemble(ptr(xy), ptr(w), ptr(C), n, ptr(Q), ldq, dtype_code(dtype),
+                             ptr(qdiag), current_stream()), "ssa_q_assemble")
+    return Q, qdiag
+
+
+def system_assemble(xy, w, qdiag, Lambda, lap_indptr, lap_indices, lap_data, rows, cols, *,
+                    sign: float, dtype, ld: Optional[int] = None) -> torch.Tensor:
+    """``_build_system_2d`` / ``_build_system_1d`` (solver/solve_film.py:285-305):
+    ``sign * (Q[rows, cols] * w[cols] - Lambda[cols] * Del2[rows, cols])`` as ``[nr, ld]``."""
+    lib = load_library()
+    n = xy.shape[0]
+    nr = n if rows is None else rows.shape[0]
+    nc = cols.shape[0]
+    ldo = ld or (padded_ld(nc, dtype) if nc > 1 else 1)
+    out = torch.empty((nr, ldo), dtype=_tdtype(dtype), device=xy.device)
+    nbytes = lib.ssa_system_assemble_workspace_bytes(n, nr, nc)
+    ws = _ws(nbytes, xy.device)
+    check(lib.ssa_system_assemble(ptr(xy), ptr(w), ptr(qdiag), ptr(Lambda), n, ptr(lap_indptr),
+                                  ptr(lap_indices), ptr(lap_data), ptr(rows), nr, ptr(cols), nc,
+                                  float(sign), ptr(out), ldo, dtype_code(dtype), ptr(ws), nbytes,
+                                  current_stream()), "ssa_system_assemble")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+@dataclass
+class LUFactors:
+    """Device-resident result of :func:`lu_factor` (the ``lu_piv`` of the reference)."""
+
+    lu: torch.Tensor        # [n, lda] L\\U, row-major
+    n: int
+    ipiv: torch.Tensor      # [n] int32, LAPACK row interchanges (0-based)
+    perm: torch.Tensor      # [n] int64 gather permutation: LU == A[perm]
+    aux: torch.Tensor       # inverses of the diagonal blocks (solve phase)
+    info: int               # LAPACK info
+    dtype: torch.dtype
+
+    @property
+    def lda(self) -> int:
+        return self.lu.shape[1]
+
+
+def lu_factor(A: torch.Tensor, n: int) -> LUFactors:
+    """``scipy.linalg.lu_factor`` (solver/solve_film.py:279): in-place on ``A [n, lda]``."""
+    lib = load_library()
+    dt = dtype_code(A.dtype)
+    lda = A.shape[1]
+    dev = A.device
+    ipiv = torch.empty(n, dtype=torch.int32, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    aux = torch.empty(lib.ssa_lu_aux_bytes(n, dt) // A.element_size(), dtype=A.dtype, device=dev)
+    nbytes = lib.ssa_lu_factor_workspace_bytes(n, dt)
+    ws = _ws(nbytes, dev)
+    check(lib.ssa_lu_factor(ptr(A), n, lda, ptr(ipiv), ptr(info), ptr(aux), dt, ptr(ws), nbytes,
+                            current_stream()), "ssa_lu_factor")
+    ipiv_h = np.ascontiguousarray(ipiv.cpu().numpy())  # synchronises the stream
+    info_h = int(info.item())
+    if info_h < 0:
+        raise _hip.HipLibraryError(
+            "ssa_lu_factor: the cooperative panel kernel timed out waiting for a peer workgroup."
+        )
+    perm_h = np.empty(n, dtype=np.int64)
+    check(lib.ssa_lu_pivots_to_permutation(ipiv_h.ctypes.data, n, perm_h.ctypes.data),
+          "ssa_lu_pivots_to_permutation")
+    perm = torch.from_numpy(perm_h).to(dev)
+    return LUFactors(lu=A, n=n, ipiv=ipiv, perm=perm, aux=aux, info=info_h, dtype=A.dtype)
+
+
+def lu_solve_permuted(f: LUFactors, B: torch.Tensor) -> torch.Tensor:
+    """``scipy.linalg.lu_solve`` (solver/solve_film.py:530) on an already row-permuted rhs
+    ``B [n] or [n, nrhs]`` (``B = h[perm]``); solved in place and returned."""
+    lib = load_library()
+    dt = dtype_code(f.dtype)
+    nrhs = 1 if B.dim() == 1 else B.shape[1]
+    nbytes = lib.ssa_lu_solve_workspace_bytes(f.n, nrhs, dt)
+    ws = _ws(nbytes, B.device)
+    check(lib.ssa_lu_solve(ptr(f.lu), f.n, f.lda, ptr(f.aux), ptr(B), nrhs, nrhs, dt, ptr(ws), nbytes,
+                           current_stream()), "ssa_lu_solve")
+    return B
+
+
+def lu_solve(f: LUFactors, b: torch.Tensor) -> torch.Tensor:
+    """Convenience: permutes ``b`` with torch indexing, then :func:`lu_solve_permuted`."""
+    return lu_solve_permuted(f, b[f.perm].contiguous())
+
+
+# ---------------------------------------------------------------------------------------
+def gemv(M: torch.Tensor, nr: int, nc: int, x: torch.Tensor, *, xscale=None, xidx=None,
+         y: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+    """BLAS gemv at solver/solve_film.py:503 and :565."""
+    lib = load_library()
+    if y is None:
+        y = torch.empty(nr, dtype=M.dtype, device=M.device)
+        beta = 0.0
+    ldm = M.shape[1] if M.dim() == 2 else nc
+    check(lib.ssa_gemv(ptr(M), nr, nc, ldm, ptr(x), ptr(xscale), ptr(xidx), ptr(y), float(alpha),
+                       float(beta), dtype_code(M.dtype), current_stream()), "ssa_gemv")
+    return y
+
+
+def row_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    y = torch.empty_like(x)
+    nvec = 1 if x.dim() == 1 else x.shape[1]
+    check(lib.ssa_row_scale(ptr(x), ptr(s), ptr(y), x.shape[0], nvec, dtype_code(x.dtype),
+                            current_stream()), "ssa_row_scale")
+    return y
+
+
+def self_field(xy, w, qdiag, g: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """Matrix-free ``Q @ (w * g)`` (solver/solve_film.py:565)."""
+    lib = load_library()
+    n = xy.shape[0]
+    out = torch.empty_like(g)
+    nbytes = lib.ssa_self_field_workspace_bytes(n)
+    ws = _ws(nbytes, g.device)
+    check(lib.ssa_self_field(ptr(xy), ptr(w), ptr(qdiag), ptr(g), n, ptr(out), float(alpha),
+                             dtype_code(g.dtype), ptr(ws), nbytes, current_stream()), "ssa_self_field")
+    return out
+
+
+def film_rhs(applied, other, ha_eff, idx, nvec: int = 1) -> torch.Tensor:
+    """``h = Hz[indices] - Ha_eff[indices]`` (solver/solve_film.py:486-488, 526-529)."""
+    lib = load_library()
+    ni = idx.shape[0]
+    shape = (ni,) if nvec == 1 and applied.dim() == 1 else (ni, nvec)
+    h = torch.empty(shape, dtype=applied.dtype, device=applied.device)
+    check(lib.ssa_film_rhs(ptr(applied), ptr(other), ptr(ha_eff), ptr(idx), ni, nvec, ptr(h),
+                           dtype_code(applied.dtype), current_stream()), "ssa_film_rhs")
+    return h
+
+
+def scatter_add(g, idx, gf, nvec: int = 1) -> None:
+    """``g[indices] += gf`` (solver/solve_film.py:531)."""
+    lib = load_library()
+    check(lib.ssa_scatter_add(ptr(g), ptr(idx), ptr(gf), idx.shape[0], nvec, dtype_code(g.dtype),
+                              current_stream()), "ssa_scatter_add")
+
+
+def index_add_scalar(g, idx, values) -> None:
+    """``g[hole_indices] += I_circ`` (solver/solve_film.py:498-502)."""
+    lib = load_library()
+    vals = np.atleast_1d(np.asarray(values, dtype=np.float64))
+    check(lib.ssa_index_add_scalar(ptr(g), ptr(idx), idx.shape[0], vals.ctypes.data, len(vals),
+                                   dtype_code(g.dtype), current_stream()), "ssa_index_add_scalar")
+
+
+def current_density(indptr, indices, gx_data, gy_data, g, nvec: int = 1) -> torch.Tensor:
+    """``J = [grad_y @ g, -(grad_x @ g)].T`` (solver/solve_film.py:556); float64 output."""
+    lib = load_library()
+    n = indptr.shape[0] - 1
+    shape = (n, 2) if nvec == 1 and g.dim() == 1 else (n, nvec, 2)
+    J = torch.empty(shape, dtype=torch.float64, device=g.device)
+    check(lib.ssa_current_density(ptr(indptr), ptr(indices), ptr(gx_data), ptr(gy_data), ptr(g), n,
+                                  nvec, ptr(J), dtype_code(g.dtype), current_stream()),
+          "ssa_current_density")
+    return J
+
+
+def scale(x: torch.Tensor, alpha: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load_library()
+    y = torch.empty_like(x) if out is None else out
+    check(lib.ssa_scale(ptr(x), ptr(y), float(alpha), x.numel(), dtype_code(x.dtype),
+                        current_stream()), "ssa_scale")
+    return y
+
+
+def biot_savart(src_xy, src_areas, src_J, tgt_xy, dz: float, out: torch.Tensor, *,
+                accumulate: bool, src_begin: int = 0, src_end: Optional[int] = None) -> torch.Tensor:
+    """``biot_savart_film_to_film`` + ``other[film] += ...`` (solver/solve.py:28-73, :508)."""
+    lib = load_library()
+    ns, nt = src_xy.shape[0], tgt_xy.shape[0]
+    src_end = ns if src_end is None else src_end
+    nbytes = lib.ssa_biot_savart_workspace_bytes(nt)
+    ws = _ws(nbytes, out.device)
+    check(lib.ssa_biot_savart(ptr(src_xy), ptr(src_areas), ptr(src_J), ns, src_begin, src_end,
+                              ptr(tgt_xy), nt, float(dz), ptr(out), int(bool(accumulate)),
+                              dtype_code(out.dtype), ptr(ws), nbytes, current_stream()),
+          "ssa_biot_savart")
+    return out
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int,
+         alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+    lib = load_library()
+    lda = A.stride(0) if A.dim() == 2 else 1
+    ldb = B.stride(0) if B.dim() == 2 else 1
+    ldc = C.stride(0) if C.dim() == 2 else 1
+    check(lib.ssa_gemm(M, N, K, float(alpha), A.data_ptr(), lda, B.data_ptr(), ldb, float(beta),
+                       C.data_ptr(), ldc, dtype_code(C.dtype), current_stream()), "ssa_gemm")
+    return C
+
+
+def fill_probe(buf: torch.Tensor) -> None:
+    lib = load_library()
+    check(lib.ssa_fill_probe(ptr(buf), buf.numel() * buf.element_size(), current_stream()),
+          "ssa_fill_probe")

@@ -1,0 +1,223 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle
+and numpy/scipy.  Run with ``pytest -m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+import scipy.linalg as la
+import scipy.sparse as sp
+
+import superscreen_oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from superscreen_amd import kernels
+
+    return kernels
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def disk():
+    from superscreen_amd import synthetic
+
+    sites, elements, dr = synthetic.ring_disk_mesh(14)  # n = 631 (odd, not a tile multiple)
+    mesh = orc.make_mesh(sites, elements)
+    return sites, elements, mesh
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 2e-14), ("float32", 1e-6)])
+def test_q_assemble(K, disk, dtype, tol):
+    sites, elements, mesh = disk
+    n = len(sites)
+    C = orc.C_vector(sites)
+    Q, qd = K.q_assemble(dev(sites), dev(mesh.weights), dev(C), dtype)
+    Qh = Q.cpu().numpy()[:, :n]
+    assert relerr(qd.cpu().numpy(), np.diag(mesh.Q)) < 2e-14
+    # off-diagonal entries are tiny next to the diagonal: compare them on their own scale
+    off = ~np.eye(n, dtype=bool)
+    assert np.max(np.abs(Qh[off] - mesh.Q[off]) / np.abs(mesh.Q[off])) < tol
+    assert relerr(np.diag(Qh), np.diag(mesh.Q)) < tol
+
+
+def test_q_assemble_golden(K, golden):
+    d = golden("disk_K10.npz")
+    Q, qd = K.q_assemble(dev(d["sites"]), dev(d["weights"]), dev(d["C"]), "float64")
+    n = len(d["sites"])
+    assert relerr(Q.cpu().numpy()[:, :n], d["Q"]) < 1e-13
+    assert relerr(qd.cpu().numpy(), d["Q_diag"]) < 1e-13
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 2e-6)])
+def test_system_assemble(K, disk, dtype, tol):
+    sites, elements, mesh = disk
+    n = len(sites)
+    rng = np.random.default_rng(1)
+    Lam = rng.uniform(0.05, 0.2, n)
+    ix = np.sort(rng.choice(n, size=401, replace=False)).astype(np.int64)
+    hole = np.arange(5, 42, dtype=np.int64)
+    lap = mesh.laplacian.tocsr()
+    lap.sort_indices()
+    _, qd = K.q_assemble(dev(sites), dev(mesh.weights), dev(orc.C_vector(sites)), "float64", want_Q=False)
+    args = (dev(sites), dev(mesh.weights), qd, dev(Lam), dev(lap.indptr.astype(np.int64)),
+            dev(lap.indices.astype(np.int64)), dev(lap.data))
+    npdt = np.dtype(dtype)
+    Qc, wc, Lc, lapc = mesh.Q.astype(npdt), mesh.weights.astype(npdt), Lam.astype(npdt), lap.astype(npdt)
+    A_ref = orc.build_system_2d(Qc, wc, Lc, lapc, ix)
+    A = K.system_assemble(*args, dev(ix), dev(ix), sign=-1.0, dtype=dtype)
+    assert relerr(A.cpu().numpy()[:, :len(ix)], -A_ref) < tol
+    Ah_ref = orc.build_system_1d(Qc, wc, Lc, lapc, hole)
+    Ah = K.system_assemble(*args, None, dev(hole), sign=1.0, dtype=dtype)
+    assert relerr(Ah.cpu().numpy()[:, :len(hole)], Ah_ref) < tol
+    # single column (ld = 1)
+    one = np.array([77], dtype=np.int64)
+    A1 = K.system_assemble(*args, None, dev(one), sign=1.0, dtype=dtype)
+    assert relerr(A1.cpu().numpy()[:, 0], orc.build_system_1d(Qc, wc, Lc, lapc, one)[:, 0]) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 1e-5)])
+@pytest.mark.parametrize("shape", [(300, 200, 64), (129, 257, 203), (1000, 1, 256), (77, 130, 5), (512, 384, 256)])
+def test_gemm(K, dtype, tol, shape):
+    M, N, Kd = shape
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((M, Kd)).astype(dtype)
+    B = rng.standard_normal((Kd, N)).astype(dtype)
+    C = rng.standard_normal((M, N)).astype(dtype)
+    Cd = dev(C)
+    K.gemm(dev(A), dev(B), Cd, M, N, Kd, alpha=-1.0, beta=1.0)
+    ref = C.astype(np.float64) - A.astype(np.float64) @ B.astype(np.float64)
+    assert relerr(Cd.cpu().numpy(), ref) < tol
+    Cd2 = torch.full((M, N), float("nan"), dtype=Cd.dtype, device="cuda")
+    K.gemm(dev(A), dev(B), Cd2, M, N, Kd, alpha=2.0, beta=0.0)
+    assert relerr(Cd2.cpu().numpy(), 2.0 * (A.astype(np.float64) @ B.astype(np.float64))) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-3)])
+@pytest.mark.parametrize("n", [50, 64, 257, 300, 777, 1500])
+def test_lu_factor_solve_random(K, dtype, tol, n):
+    """General (not diagonally dominant) matrices: pivoting must match LAPACK's choices."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)).astype(dtype)
+    ld = K.padded_ld(n, dtype)
+    Ad = torch.zeros((n, ld), dtype=getattr(torch, dtype), device="cuda")
+    Ad[:, :n] = dev(A)
+    f = K.lu_factor(Ad, n)
+    assert f.info == 0
+    lu_ref, piv_ref = la.lu_factor(A)
+    if dtype == "float64":
+        assert np.array_equal(f.ipiv.cpu().numpy(), piv_ref)
+        assert relerr(f.lu.cpu().numpy()[:, :n], lu_ref) < 1e-9
+    for nrhs in (1, 3):
+        b = rng.standard_normal((n, nrhs)).astype(dtype)
+        bd = dev(b[:, 0]) if nrhs == 1 else dev(b)
+        x = K.lu_solve(f, bd).cpu().numpy().reshape(n, nrhs)
+        ref = np.linalg.solve(A.astype(np.float64), b.astype(np.float64))
+        assert relerr(x, ref) < tol * max(1.0, np.linalg.cond(A.astype(np.float64)) / 1e3)
+
+
+def test_lu_singular_info(K):
+    n = 100
+    A = np.random.default_rng(0).standard_normal((n, n))
+    A[:, 40] = 0.0
+    ld = K.padded_ld(n, "float64")
+    Ad = torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+    Ad[:, :n] = dev(A)
+    f = K.lu_factor(Ad, n)
+    assert f.info == 41  # LAPACK: U[40, 40] is exactly zero
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 1e-5)])
+def test_gemv_and_vector_kernels(K, dtype, tol):
+    rng = np.random.default_rng(3)
+    nr, nc = 517, 1031
+    npdt = np.dtype(dtype)
+    M = rng.standard_normal((nr, nc)).astype(npdt)
+    ld = K.padded_ld(nc, dtype)
+    Md = torch.zeros((nr, ld), dtype=getattr(torch, dtype), device="cuda")
+    Md[:, :nc] = dev(M)
+    x = rng.standard_normal(nc).astype(npdt)
+    s = rng.uniform(0.5, 2, nc).astype(npdt)
+    y = K.gemv(Md, nr, nc, dev(x), xscale=dev(s))
+    assert relerr(y.cpu().numpy(), M.astype(float) @ (s.astype(float) * x)) < tol
+    # unaligned ld + gathered x + accumulate
+    big = rng.standard_normal(4000).astype(npdt)
+    idx = np.sort(rng.choice(4000, nc, replace=False)).astype(np.int64)
+    y0 = rng.standard_normal(nr).astype(npdt)
+    yd = dev(y0)
+    K.gemv(dev(M), nr, nc, dev(big), xidx=dev(idx), y=yd, alpha=-1.0, beta=1.0)
+    assert relerr(yd.cpu().numpy(), y0 - M.astype(float) @ big[idx].astype(float)) < tol
+    # rhs gather / scatter / index add / scale
+    n = 900
+    applied, other, ha = (rng.standard_normal(n).astype(npdt) for _ in range(3))
+    ix = np.sort(rng.choice(n, 400, replace=False)).astype(np.int64)
+    h = K.film_rhs(dev(applied), dev(other), dev(ha), dev(ix))
+    assert np.array_equal(h.cpu().numpy(), (applied + other)[ix] - ha[ix])
+    h2 = K.film_rhs(dev(applied), None, dev(ha), dev(ix))
+    assert np.array_equal(h2.cpu().numpy(), applied[ix] - ha[ix])
+    g = dev(applied.copy())
+    K.scatter_add(g, dev(ix), h)
+    ref = applied.copy(); ref[ix] += (applied + other)[ix] - ha[ix]
+    assert np.array_equal(g.cpu().numpy(), ref)
+    K.index_add_scalar(g, dev(ix[:10]), 2.5)
+    ref[ix[:10]] += npdt.type(2.5)
+    assert np.array_equal(g.cpu().numpy(), ref)
+    assert np.array_equal(K.scale(g, 0.5).cpu().numpy(), (ref * npdt.type(0.5)))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_current_density_and_self_field(K, disk, dtype):
+    sites, elements, mesh = disk
+    n = len(sites)
+    rng = np.random.default_rng(4)
+    g = rng.standard_normal(n).astype(dtype)
+    gx, gy = mesh.gradient_x.tocsr(), mesh.gradient_y.tocsr()
+    pattern = (abs(gx) + abs(gy)).tocsr()
+    pattern.sort_indices()
+    rows = np.repeat(np.arange(n), np.diff(pattern.indptr))
+    vx = np.asarray(gx[rows, pattern.indices]).ravel()
+    vy = np.asarray(gy[rows, pattern.indices]).ravel()
+    J = K.current_density(dev(pattern.indptr.astype(np.int64)), dev(pattern.indices.astype(np.int64)),
+                          dev(vx), dev(vy), dev(g))
+    gd = g.astype(np.float64)
+    ref = np.array([gy @ gd, -(gx @ gd)]).T
+    assert relerr(J.cpu().numpy(), ref) < 1e-13
+    _, qd = K.q_assemble(dev(sites), dev(mesh.weights), dev(orc.C_vector(sites)), "float64", want_Q=False)
+    sf = K.self_field(dev(sites), dev(mesh.weights), qd, dev(g), alpha=0.25)
+    ref_sf = 0.25 * (mesh.Q @ (mesh.weights * gd))
+    assert relerr(sf.cpu().numpy(), ref_sf) < (1e-12 if dtype == "float64" else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_biot_savart_golden(K, golden, dtype):
+    d = golden("biot_savart.npz")
+    areas = d["areas"].astype(dtype)
+    for tag in ("dz05", "dz0_disjoint", "dzneg"):
+        za, zb, shift = d[f"args_{tag}"]
+        tgt = d["sites2"] + np.array([shift, 0.0])
+        out = torch.zeros(len(tgt), dtype=getattr(torch, dtype), device="cuda")
+        K.biot_savart(dev(d["sites1"]), dev(areas), dev(d["J"]), dev(tgt), zb - za, out, accumulate=False)
+        ref = orc.biot_savart_film_to_film(film1_sites=d["sites1"], film1_z0=za, film1_areas=areas.astype(float),
+                                           film1_J=d["J"], film2_sites=tgt, film2_z0=zb)
+        tol = 1e-12 if dtype == "float64" else 1e-6
+        assert relerr(out.cpu().numpy(), ref) < tol
+        if dtype == "float64":
+            assert relerr(out.cpu().numpy(), d[f"H_{tag}"]) < 1e-12
+        # source slices + accumulate == full sum
+        ns = len(d["sites1"])
+        acc = torch.zeros_like(out)
+        for b, e in ((0, 100), (100, 101), (101, ns)):
+            K.biot_savart(dev(d["sites1"]), dev(areas), dev(d["J"]), dev(tgt), zb - za, acc,
+                          accumulate=True, src_begin=b, src_end=e)
+        assert relerr(acc.cpu().numpy(), ref) < tol
