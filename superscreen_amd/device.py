@@ -1,0 +1,318 @@
+"""``Layer``, ``Polygon`` and ``Device``: the model objects the solver path consumes.
+
+API surface kept from the reference: ``Layer(name, Lambda=None,
+london_lambda=None, thickness=None, z0=0)`` (``device/layer.py:32-64``), ``Polygon(name=None,
+*, layer=None, points)`` with CCW orientation and ``contains_points`` via
+``matplotlib.path.Path`` (``device/polygon.py:40-80,138-162``), ``Device(name, *, layers,
+films, holes=None, terminals=None, abstract_regions=None, length_units="um",
+solve_dtype="float32")`` with ``films / holes / layers / meshes / terminals``,
+``solve_dtype``, ``length_units``, ``holes_by_film``, ``polygons_by_layer``, ``copy``
+(``device/device.py:47-246``).
+
+Out of scope: geometry authoring (boolean ops, buffering, resampling --
+needs shapely), meshing with meshpy/Triangle (``Device.make_mesh`` here meshes only what the
+synthetic mesher supports, or takes explicit triangulations), plotting, HDF5, transforms,
+``mutual_inductance_matrix`` (listed as "next" in section 8f).
+"""
+from __future__ import annotations
+
+import numbers
+from copy import deepcopy
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .geometry import close_curve
+from .parameter import Parameter
+
+
+class Layer:
+    """A single layer of a superconducting device (``device/layer.py:11-64``)."""
+
+    __slots__ = ("name", "thickness", "london_lambda", "z0", "_Lambda")
+
+    def __init__(self, name: str, Lambda: Union[float, Parameter, None] = None,
+                 london_lambda: Union[float, Parameter, None] = None,
+                 thickness: Optional[float] = None, z0: float = 0):
+        self.name = name
+        self.thickness = thickness
+        self.london_lambda = london_lambda
+        self.z0 = z0
+        if Lambda is None:
+            if london_lambda is None or thickness is None:
+                raise ValueError(
+                    "You must provide either an effective penetration depth Lambda "
+                    "or both a london_lambda and a thickness."
+                )
+            self._Lambda = None
+        else:
+            if london_lambda is not None or thickness is not None:
+                raise ValueError(
+                    "You must provide either an effective penetration depth Lambda "
+                    "or both a london_lambda and a thickness (but not all three)."
+                )
+            self._Lambda = Lambda
+
+    @property
+    def Lambda(self) -> Union[float, Parameter]:
+        """Effective penetration depth ``lambda^2 / d`` (``device/layer.py:60-64``)."""
+        if self._Lambda is not None:
+            return self._Lambda
+        return self.london_lambda ** 2 / self.thickness
+
+    @Lambda.setter
+    def Lambda(self, value) -> None:
+        if self._Lambda is None:
+            raise AttributeError("Can't set Lambda directly. Set london_lambda and/or thickness instead.")
+        self._Lambda = value
+
+    def copy(self) -> "Layer":
+        return deepcopy(self)
+
+    def __eq__(self, other) -> bool:
+        if other is self:
+            return True
+        if not isinstance(other, Layer):
+            return False
+        return (self.name == other.name and self.thickness == other.thickness
+                and self.london_lambda == other.london_lambda and self.Lambda == other.Lambda
+                and self.z0 == other.z0)
+
+    def __repr__(self) -> str:
+        return (f"Layer({self.name!r}, Lambda={self.Lambda!r}, thickness={self.thickness!r}, "
+                f"london_lambda={self.london_lambda!r}, z0={self.z0!r})")
+
+
+def _signed_area(points: np.ndarray) -> float:
+    x, y = points[:, 0], points[:, 1]
+    return 0.5 * float(np.sum(x[:-1] * y[1:] - x[1:] * y[:-1]))
+
+
+class Polygon:
+    """A simply-connected polygon located in a Layer (``device/polygon.py:28-162``).
+
+    ``points`` are stored closed and counter-clockwise, as the reference does through
+    ``shapely.geometry.polygon.orient`` (``device/polygon.py:56-80``).
+    """
+
+    __slots__ = ("name", "layer", "_points")
+
+    def __init__(self, name: Optional[str] = None, *, layer: Optional[str] = None, points):
+        self.name = name
+        self.layer = layer
+        self.points = points
+
+    @property
+    def points(self) -> np.ndarray:
+        return self._points
+
+    @points.setter
+    def points(self, points) -> None:
+        if isinstance(points, Polygon):
+            points = points.points
+        points = np.asarray(points, dtype=float)
+        if points.ndim != 2 or points.shape[-1] != 2:
+            raise ValueError(f"Expected shape (n, 2), but got {points.shape}.")
+        points = close_curve(points)
+        if len(points) < 4:
+            raise ValueError("The given points do not define a valid polygon (fewer than 3 vertices).")
+        area = _signed_area(points)
+        if area == 0:
+            raise ValueError("The given points do not define a valid polygon (zero area).")
+        if area < 0:
+            points = points[::-1].copy()
+        self._points = points
+
+    @property
+    def is_valid(self) -> bool:
+        return self.name is not None and self.layer is not None and abs(self.area) > 0
+
+    @property
+    def area(self) -> float:
+        return abs(_signed_area(self._points))
+
+    @property
+    def extents(self) -> Tuple[float, float]:
+        return tuple(np.ptp(self._points, axis=0))
+
+    @property
+    def path(self):
+        """A ``matplotlib.path.Path`` of the boundary (``device/polygon.py:108-111``)."""
+        from matplotlib.path import Path
+
+        return Path(self._points, closed=True)
+
+    def set_name(self, name) -> "Polygon":
+        self.name = name
+        return self
+
+    def set_layer(self, layer) -> "Polygon":
+        self.layer = layer
+        return self
+
+    def contains_points(self, points: np.ndarray, index: bool = False, radius: float = 0):
+        """``device/polygon.py:138-162`` -- point-in-polygon via ``Path.contains_points``."""
+        mask = self.path.contains_points(np.atleast_2d(points), radius=radius)
+        if index:
+            return np.where(mask)[0]
+        return mask
+
+    def copy(self) -> "Polygon":
+        return Polygon(self.name, layer=self.layer, points=self._points.copy())
+
+    def __eq__(self, other) -> bool:
+        if other is self:
+            return True
+        if not isinstance(other, Polygon):
+            return False
+        return (self.name == other.name and self.layer == other.layer
+                and np.allclose(self.points, other.points))
+
+    def __repr__(self) -> str:
+        return f"Polygon({self.name!r}, layer={self.layer!r}, points=<ndarray: shape={self._points.shape}>)"
+
+
+class Device:
+    """A device composed of one or more layers of thin-film superconductor
+    (``device/device.py:29-109``)."""
+
+    def __init__(self, name: str, *, layers, films, holes=None, terminals=None,
+                 abstract_regions=None, length_units: str = "um",
+                 solve_dtype: Union[str, np.dtype] = "float32"):
+        self.name = name
+        if isinstance(layers, dict):
+            layers = list(layers.values())
+        self.layers: Dict[str, Layer] = {layer.name: layer for layer in layers}
+        if isinstance(films, dict):
+            films = list(films.values())
+        self.films: Dict[str, Polygon] = {film.name: film for film in films}
+        if holes is None:
+            holes = []
+        if isinstance(holes, dict):
+            holes = list(holes.values())
+        self.holes: Dict[str, Polygon] = {hole.name: hole for hole in holes}
+        self.terminals: Dict[str, List[Polygon]] = terminals or {}
+        if not set(self.terminals).issubset(self.films):
+            raise ValueError(
+                f"terminals.keys() must be a subset of films.keys() ({list(self.films)!r})."
+            )
+        if abstract_regions is None:
+            abstract_regions = []
+        if isinstance(abstract_regions, dict):
+            abstract_regions = list(abstract_regions.values())
+        self.abstract_regions = {region.name: region for region in abstract_regions}
+        for polygons, label in [(self.films.values(), "film"), (self.holes.values(), "hole")]:
+            for polygon in polygons:
+                if not polygon.is_valid:
+                    raise ValueError(f"The following {label} is not valid: {polygon}.")
+                if polygon.layer not in self.layers:
+                    raise ValueError(
+                        f"The following {label} is assigned to a layer that doesn not "
+                        f"exist in the device: {polygon}."
+                    )
+        self._length_units = length_units
+        self.solve_dtype = solve_dtype
+        self.meshes = None
+
+    @property
+    def length_units(self) -> str:
+        return self._length_units
+
+    @property
+    def solve_dtype(self) -> np.dtype:
+        """Numpy dtype used for the solve (``device/device.py:116-127``)."""
+        return self._solve_dtype
+
+    @solve_dtype.setter
+    def solve_dtype(self, dtype) -> None:
+        try:
+            np.finfo(dtype)
+        except ValueError as e:
+            raise ValueError(f"Invalid float dtype: {dtype}") from e
+        self._solve_dtype = np.dtype(dtype)
+
+    def get_polygons(self, include_terminals: bool = True) -> List[Polygon]:
+        polygons = []
+        for attr in ("films", "holes", "abstract_regions"):
+            polygons.extend(getattr(self, attr).values())
+        if include_terminals:
+            for terms in self.terminals.values():
+                polygons.extend(terms)
+        return polygons
+
+    def polygons_by_layer(self, polygon_type: Optional[str] = None) -> Dict[str, List[Polygon]]:
+        """``device/device.py:155-196``."""
+        valid = ("film", "hole", "abstract", "terminal", "all")
+        polygon_type = (polygon_type or "all").lower()
+        if polygon_type not in valid:
+            raise ValueError(f"Invalid polygon type ({polygon_type}). Expected one of {valid!r}.")
+        if polygon_type == "film":
+            polys = list(self.films.values())
+        elif polygon_type == "hole":
+            polys = list(self.holes.values())
+        elif polygon_type == "abstract":
+            polys = list(self.abstract_regions.values())
+        elif polygon_type == "terminal":
+            polys = [t for terms in self.terminals.values() for t in terms]
+        else:
+            polys = self.get_polygons()
+        return {layer: [p for p in polys if p.layer == layer] for layer in self.layers}
+
+    def holes_by_film(self) -> Dict[str, List[Polygon]]:
+        """``device/device.py:198-211``: holes of the film's layer whose points all lie in it."""
+        by_layer = self.polygons_by_layer("hole")
+        out = {}
+        for film in self.films.values():
+            out[film.name] = [h for h in by_layer[film.layer] if film.contains_points(h.points).all()]
+        return out
+
+    def copy(self, with_mesh: bool = True, copy_mesh: bool = False) -> "Device":
+        """``device/device.py:213-246``.  Quirk kept: the copy does NOT carry ``solve_dtype``
+        (it falls back to the default float32), exactly like the reference (:232-240)."""
+        device = Device(
+            self.name,
+            layers=[layer.copy() for layer in self.layers.values()],
+            films=[film.copy() for film in self.films.values()],
+            holes=[hole.copy() for hole in self.holes.values()],
+            terminals={f: [t.copy() for t in ts] for f, ts in self.terminals.items()},
+            abstract_regions=[r.copy() for r in self.abstract_regions.values()],
+            length_units=self.length_units,
+        )
+        if with_mesh and self.meshes is not None:
+            meshes = self.meshes
+            if copy_mesh:
+                meshes = {name: mesh.copy() for name, mesh in meshes.items()}
+            device.meshes = meshes
+        return device
+
+    def __copy__(self):
+        return self.copy(with_mesh=True, copy_mesh=False)
+
+    def __deepcopy__(self, memo):
+        return self.copy(with_mesh=True, copy_mesh=True)
+
+    def make_mesh(self, triangulations: Optional[Dict[str, Tuple[np.ndarray, np.ndarray]]] = None,
+                  **unsupported) -> None:
+        """Attaches a mesh to every film.
+
+        The reference meshes with meshpy/Triangle (``device/device.py:383-471``), which is out
+        of scope; here the caller supplies ``{film_name: (sites, elements)}`` (e.g. from
+        :mod:`superscreen_amd.synthetic` or any external mesher).
+        """
+        from .mesh import Mesh
+
+        if triangulations is None:
+            raise NotImplementedError(
+                "superscreen_amd does not ship a mesher (meshpy/Triangle is out of scope): pass "
+                "triangulations={film: (sites, elements)} or use superscreen_amd.synthetic."
+            )
+        if unsupported:
+            raise TypeError(f"Unsupported make_mesh arguments: {sorted(unsupported)}")
+        missing = set(self.films) - set(triangulations)
+        if missing:
+            raise ValueError(f"No triangulation given for films {sorted(missing)!r}.")
+        self.meshes = {name: Mesh.from_triangulation(*triangulations[name]) for name in self.films}
+
+    def __repr__(self) -> str:
+        return (f"Device({self.name!r}, layers={list(self.layers)!r}, films={list(self.films)!r}, "
+                f"holes={list(self.holes)!r}, length_units={self.length_units!r})")

@@ -1,0 +1,205 @@
+"""Result containers and the fluxoid post-processing that parity is judged on.
+
+Kept from the reference (``solution.py``): ``Fluxoid`` (:39-59), ``Vortex`` (:62-92),
+``FilmSolution`` (:95-198), ``Solution.__init__`` (:219-244), ``interp_current_density``
+(:278-319), ``polygon_fluxoid`` (:484-563), ``hole_fluxoid`` (:565-609).  All of it is O(n)
+host work on the vectors the GPU returns.  Field maps at arbitrary positions, vector
+potential, HDF5 and plotting are out of scope.
+"""
+from __future__ import annotations
+
+import datetime as dt
+from dataclasses import dataclass
+from typing import Callable, Dict, List, NamedTuple, Optional, Union
+
+import numpy as np
+
+from .device import Device, Polygon
+from .parameter import Constant
+from .units import MU_0, Quantity, convert_field, parse_units
+from .version import __version__
+
+
+class Fluxoid(NamedTuple):
+    """Flux part and supercurrent part of the fluxoid of a closed region (``solution.py:39-59``)."""
+
+    flux_part: Union[float, Quantity]
+    supercurrent_part: Union[float, Quantity]
+
+
+@dataclass
+class Vortex:
+    """A vortex pinned at ``(x, y)`` in ``film`` carrying ``nPhi0`` flux quanta
+    (``solution.py:62-92``).  Accepted by the API; the vortex branch of ``solve_film`` is not
+    on the BASELINE path yet."""
+
+    x: float
+    y: float
+    film: str
+    nPhi0: float = 1
+
+
+class FilmSolution:
+    """Raw solution data for a single film (``solution.py:95-130``)."""
+
+    def __init__(self, stream, current_density, applied_field, self_field,
+                 field_from_other_films=None):
+        self.stream = np.asarray(stream)
+        self.current_density = np.asarray(current_density)
+        self.applied_field = np.asarray(applied_field)
+        self.self_field = np.asarray(self_field)
+        if field_from_other_films is not None:
+            field_from_other_films = np.asarray(field_from_other_films)
+        self.field_from_other_films = field_from_other_films
+        self._total_field = None
+
+    @property
+    def total_field(self) -> np.ndarray:
+        """``applied + self (+ other)`` (``solution.py:123-130``)."""
+        if self._total_field is None:
+            total = self.applied_field + self.self_field
+            if self.field_from_other_films is not None:
+                total = total + self.field_from_other_films
+            self._total_field = total
+        return self._total_field
+
+    def is_close(self, other: "FilmSolution", rtol: float = 1e-4, atol: float = 1e-7) -> bool:
+        """``solution.py:166-185``."""
+        kw = dict(rtol=rtol, atol=atol)
+        return (np.allclose(self.stream, other.stream, **kw)
+                and np.allclose(self.applied_field, other.applied_field, **kw)
+                and np.allclose(self.self_field, other.self_field, **kw)
+                and np.allclose(self.total_field, other.total_field, **kw))
+
+    def __eq__(self, other) -> bool:
+        if other is self:
+            return True
+        if not isinstance(other, FilmSolution):
+            return False
+        if (self.field_from_other_films is None) != (other.field_from_other_films is None):
+            return False
+        return self.is_close(other)
+
+
+class Solution:
+    """Stream functions and fields of all films of a solved ``Device`` (``solution.py:201-244``)."""
+
+    def __init__(self, *, device: Device, film_solutions: Dict[str, FilmSolution],
+                 applied_field_func: Callable, field_units: str, current_units: str,
+                 circulating_currents: Optional[Dict[str, float]] = None,
+                 terminal_currents: Optional[Dict[str, float]] = None,
+                 vortices: Optional[List[Vortex]] = None, solver: str = "superscreen_amd.solve"):
+        self.device = device.copy(with_mesh=True, copy_mesh=False)  # solution.py:232
+        self.film_solutions = film_solutions
+        self.applied_field_func = applied_field_func
+        self.circulating_currents = circulating_currents or {}
+        self.terminal_currents = terminal_currents or {}
+        self.vortices = vortices or []
+        self._field_units = field_units
+        self._current_units = current_units
+        self._solver = solver
+        self._time_created = dt.datetime.now()
+        self._version_info = {"superscreen_amd": __version__}
+
+    @property
+    def field_units(self) -> str:
+        return self._field_units
+
+    @property
+    def current_units(self) -> str:
+        return self._current_units
+
+    @property
+    def solver(self) -> str:
+        return self._solver
+
+    @property
+    def time_created(self) -> dt.datetime:
+        return self._time_created
+
+    @property
+    def version_info(self) -> Dict[str, str]:
+        return self._version_info
+
+    # ------------------------------------------------------------------------------------
+    def interp_current_density(self, positions: np.ndarray, *, film: str, method: str = "linear",
+                               units: Optional[str] = None, with_units: bool = False):
+        """Interpolates ``J = [dg/dy, -dg/dx]`` inside a film (``solution.py:278-319``);
+        positions outside the film or with non-finite interpolants give 0 (:313-315)."""
+        import matplotlib.tri as mtri
+
+        device = self.device
+        default_units = f"{self.current_units} / {device.length_units}"
+        units = units or default_units
+        positions = np.atleast_2d(positions)
+        xv, yv = positions.T
+        interp = {"linear": mtri.LinearTriInterpolator, "cubic": mtri.CubicTriInterpolator}[method]
+        mesh = device.meshes[film]
+        J = self.film_solutions[film].current_density
+        J = np.array([interp(mesh.triangulation, J[:, 0])(xv, yv).data,
+                      interp(mesh.triangulation, J[:, 1])(xv, yv).data]).T
+        J[~device.films[film].contains_points(positions)] = 0
+        J[~np.isfinite(J).all(axis=1)] = 0
+        q = Quantity(J, default_units).to(units)
+        return q if with_units else q.magnitude
+
+    def polygon_fluxoid(self, polygon_coords, *, film: str, interp_method: str = "linear",
+                        units: Optional[str] = "Phi_0", with_units: bool = True) -> Fluxoid:
+        """Fluxoid of a polygonal region (``solution.py:484-563``):
+        flux part ``sum_{i in polygon} total_field_i w_i`` (:535-538) and supercurrent part
+        ``mu_0 trapezoid(Lambda_k (J_k . dl_k))`` over the polygon vertices (:542-559)."""
+        device = self.device
+        if units is None:
+            units = f"{self.field_units} * {device.length_units} ** 2"
+        polygon = Polygon(points=polygon_coords)
+        points = polygon.points
+        if not device.films[film].contains_points(points).all():
+            raise ValueError(f"The polygon is not contained within the film ({film!r}).")
+        mesh = device.meshes[film]
+        ix = polygon.contains_points(mesh.sites)
+        fields = self.film_solutions[film].total_field
+        flux_raw = float(np.einsum("i, i ->", fields[ix], mesh.vertex_areas[ix]))
+        # field_units may be H-like or B-like; express as B = mu_0 H, like pint's .to() chain
+        flux_T_m2 = convert_field(flux_raw, "T", old_units=self.field_units, with_units=False) \
+            * parse_units(device.length_units).scale ** 2
+        flux_part = Quantity(flux_T_m2, "Wb").to(units)
+
+        J_units = f"{self.current_units} / {device.length_units}"
+        J_poly = self.interp_current_density(points, film=film, method=interp_method,
+                                             units=J_units, with_units=False)
+        Lambda = device.layers[device.films[film].layer].Lambda
+        if not callable(Lambda):
+            Lambda = Constant(Lambda)
+        Lambda_poly = Lambda(points[:, 0], points[:, 1]) * np.ones(len(points))
+        dl = np.diff(points, axis=0)
+        int_J = float(np.trapezoid(Lambda_poly[:-1] * np.sum(J_poly[:-1] * dl, axis=1)))
+        # [J_units * length^2] = current * length ; mu_0 * that is a flux
+        int_J_SI = int_J * parse_units(self.current_units).scale * parse_units(device.length_units).scale
+        supercurrent_part = Quantity(MU_0 * int_J_SI, "Wb").to(units)
+        if not with_units:
+            return Fluxoid(float(flux_part.magnitude), float(supercurrent_part.magnitude))
+        return Fluxoid(flux_part, supercurrent_part)
+
+    def hole_fluxoid(self, hole_name: str, points: Optional[np.ndarray] = None,
+                     interp_method: str = "linear", units: Optional[str] = "Phi_0",
+                     with_units: bool = True) -> Fluxoid:
+        """Fluxoid of a polygon enclosing a hole (``solution.py:565-609``).  Without ``points`` the
+        reference buffers the hole with shapely (``fluxoid.py:13-52``); that is out of scope, so
+        ``points`` is required here."""
+        if points is None:
+            raise NotImplementedError(
+                "make_fluxoid_polygons needs shapely (out of scope): pass the enclosing polygon."
+            )
+        device = self.device
+        hole = device.holes[hole_name]
+        if not Polygon(points=points).contains_points(hole.points).all():
+            raise ValueError(f"Hole {hole.name} is not completely enclosed by the given polygon.")
+        film_name = None
+        for name, holes in device.holes_by_film().items():
+            if hole.name in [h.name for h in holes]:
+                film_name = name
+                break
+        if film_name is None:
+            raise ValueError(f"Hole {hole_name!r} is not contained in any film.")
+        return self.polygon_fluxoid(points, film=film_name, interp_method=interp_method,
+                                    units=units, with_units=with_units)

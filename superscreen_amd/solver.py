@@ -1,0 +1,522 @@
+"""The solver hot path: ``factorize_model`` and ``solve`` on an MI355X.
+
+Host orchestration mirrors the reference line by line where behaviour is observable
+(``solver/solve.py:223-549``, ``solver/solve_film.py:151-282, 440-574``,
+``solver/utils.py:19-132, 234-324``); every numerical step runs in the HIP library
+(``include/superscreen_hip.h``) on device-resident data:
+
+  make_film_info            host index logic (point-in-polygon, setdiff1d)      utils.py:271-304
+  factorize_linear_systems  ssa_q_assemble (diagonal) -> ssa_system_assemble    solve_film.py:209-218, 275
+                            (-A generated straight into the LU buffer)
+                            -> ssa_lu_factor                                     solve_film.py:279
+  solve_film                ssa_index_add_scalar / ssa_gemv (holes)             solve_film.py:498-503
+                            ssa_film_rhs -> ssa_lu_solve -> ssa_scatter_add      :526-531
+                            ssa_current_density                                  :556
+                            ssa_self_field (matrix-free) or ssa_gemv on a stored Q  :565
+  solve                     ssa_biot_savart per ordered film pair, Jacobi loop   solve.py:491-536
+
+Memory (per film, n vertices, n_i unknowns, s = sizeof(solve dtype)): LU n_i^2 s (13.7 GB at
+n = 50k in f64), hole systems n * k_h * s, optional stored Q n^2 s; the reference additionally
+keeps A, a float64 Q and a DENSE Laplacian (solver/utils.py:290-292), about 5 n^2 words.
+
+Not implemented (raise NotImplementedError): terminal currents,
+vortices, the grad(Lambda) term of inhomogeneous films, HDF5 persistence.
+"""
+from __future__ import annotations
+
+import copy as _copy
+import itertools
+import logging
+import numbers
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import fem
+from .device import Device
+from .parameter import Constant
+from .solution import FilmSolution, Solution, Vortex
+from .sources import ConstantField
+from .units import current_to_float, field_conversion_factor, vortex_flux
+
+logger = logging.getLogger("solve")
+
+
+# ---------------------------------------------------------------------------------------
+# Film bookkeeping (host)
+# ---------------------------------------------------------------------------------------
+class LambdaInfo:
+    """Effective penetration depth of a film on its mesh (``solver/utils.py:19-58``)."""
+
+    def __init__(self, *, film: str, Lambda: np.ndarray, london_lambda: Optional[np.ndarray] = None,
+                 thickness: Optional[float] = None):
+        self.film = film
+        self.Lambda = Lambda
+        self.london_lambda = london_lambda
+        self.thickness = thickness
+        self.inhomogeneous = bool(
+            np.ptp(self.Lambda) / max(np.min(np.abs(self.Lambda)), np.finfo(float).eps) > 1e-6
+        )
+        if self.inhomogeneous:
+            logger.info(f"Inhomogeneous Lambda in film {self.film!r}, which violates the "
+                        "assumptions of the London model. Results may not be reliable.")
+        if self.london_lambda is not None:
+            assert self.thickness is not None
+            assert np.allclose(self.Lambda, self.london_lambda ** 2 / self.thickness)
+        if np.any(self.Lambda < 0):
+            raise ValueError(f"Negative Lambda in film {film!r}.")
+
+
+@dataclass
+class FilmInfo:
+    """Per-film data required by the solver (``solver/utils.py:96-132``).  ``kernel`` is not
+    stored: the dense Q lives (optionally) on the GPU, see ``FilmDeviceData``."""
+
+    name: str
+    layer: str
+    lambda_info: LambdaInfo
+    vortices: Tuple[Vortex, ...]
+    interior_indices: np.ndarray
+    boundary_indices: np.ndarray
+    hole_indices: Dict[str, np.ndarray]
+    in_hole: np.ndarray
+    circulating_currents: Dict[str, float]
+    weights: np.ndarray
+    laplacian: sp.csr_array
+    gradient: Optional[np.ndarray] = None
+    terminal_currents: Optional[Dict[str, float]] = None
+    z0: float = 0.0
+
+
+def get_holes_and_vortices_by_film(device: Device, vortices: Sequence[Vortex]):
+    """``solver/utils.py:212-231`` (incl. its error conventions)."""
+    vortices_by_film = {name: [] for name in device.films}
+    holes_by_film = device.holes_by_film()
+    for vortex in vortices:
+        if not isinstance(vortex, Vortex):
+            raise TypeError(f"Expected a Vortex, but got {type(vortex)}.")
+        if not device.films[vortex.film].contains_points((vortex.x, vortex.y)).all():
+            raise ValueError(f"Vortex {vortex!r} is not located in film {vortex.film!r}.")
+        for hole in holes_by_film[vortex.film]:
+            if hole.contains_points((vortex.x, vortex.y)).all():
+                raise ValueError(f"Vortex {vortex} is located in hole {hole.name!r}.")
+        vortices_by_film[vortex.film].append(vortex)
+    return holes_by_film, vortices_by_film
+
+
+def make_film_info(*, device: Device, vortices: Sequence[Vortex],
+                   circulating_currents: Dict[str, float],
+                   terminal_currents: Dict[str, Dict[str, float]]) -> Dict[str, FilmInfo]:
+    """``make_film_info`` (``solver/utils.py:234-324``)."""
+    dtype = device.solve_dtype
+    holes_by_film, vortices_by_film = get_holes_and_vortices_by_film(device, vortices)
+    film_info = {}
+    for name, film in device.films.items():
+        mesh = device.meshes[name]
+        layer = device.layers[film.layer]
+        london_lambda, d, Lambda = layer.london_lambda, layer.thickness, layer.Lambda
+        if isinstance(london_lambda, numbers.Real) and london_lambda <= d:
+            logger.info(f"Layer {name!r}: film thickness d = {d:.4f} >= london_lambda = "
+                        f"{london_lambda:.4f}; the thin-film assumption may not be valid.")
+        if isinstance(Lambda, numbers.Real):
+            Lambda = Constant(Lambda)
+        Lambda = np.asarray(Lambda(mesh.sites[:, 0], mesh.sites[:, 1]) * np.ones(len(mesh.sites)))
+        Lambda = Lambda.astype(dtype, copy=False)[:, np.newaxis]
+        if london_lambda is not None:
+            if isinstance(london_lambda, numbers.Real):
+                london_lambda = Constant(london_lambda)
+            london_lambda = np.asarray(
+                london_lambda(mesh.sites[:, 0], mesh.sites[:, 1]) * np.ones(len(mesh.sites))
+            ).astype(dtype, copy=False)[:, np.newaxis]
+        hole_indices = {hole.name: hole.contains_points(mesh.sites, index=True)
+                        for hole in holes_by_film[name]}
+        in_hole = np.zeros(len(mesh.sites), dtype=bool)
+        if hole_indices:
+            in_hole[np.concatenate(list(hole_indices.values()))] = True
+        circ = {h: c for h, c in circulating_currents.items() if h in hole_indices}
+        lambda_info = LambdaInfo(film=name, Lambda=Lambda, london_lambda=london_lambda,
+                                 thickness=layer.thickness)
+        if name in device.terminals:
+            raise NotImplementedError("Terminal currents are not on the accelerated path yet.")
+        boundary = mesh.boundary_indices
+        interior = np.setdiff1d(film.contains_points(mesh.sites, index=True), boundary)
+        film_info[name] = FilmInfo(
+            name=name, layer=layer.name, lambda_info=lambda_info,
+            vortices=tuple(vortices_by_film[name]), interior_indices=interior,
+            boundary_indices=boundary, hole_indices=hole_indices, in_hole=in_hole,
+            circulating_currents=circ, terminal_currents=terminal_currents.get(name),
+            weights=mesh.operators.weights.astype(dtype, copy=False),
+            laplacian=mesh.operators.laplacian.astype(dtype), z0=float(layer.z0),
+        )
+    return film_info
+
+
+# ---------------------------------------------------------------------------------------
+# Device-resident state
+# ---------------------------------------------------------------------------------------
+class FilmDeviceData:
+    """Everything of one film that lives in HBM (torch tensors are plumbing only)."""
+
+    def __init__(self, info: FilmInfo, mesh, dtype: np.dtype, store_Q: bool):
+        import torch
+
+        from . import kernels
+
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ops = mesh.operators
+
+        def put(a, dt=None):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            return t if dt is None else t.to(dt)
+
+        self.n = len(mesh.sites)
+        self.dtype, self.tdtype, self.device = dtype, tdt, dev
+        self.xy = put(mesh.sites)
+        self.w = put(ops.weights)                      # float64 geometry
+        self.w_t = self.w.to(tdt)                      # film_info.weights (solve dtype)
+        self.Lambda = put(info.lambda_info.Lambda[:, 0].astype(np.float64))
+        lap = ops.laplacian.tocsr()
+        lap.sort_indices()
+        self.lap = (put(lap.indptr.astype(np.int64)), put(lap.indices.astype(np.int64)), put(lap.data))
+        ptr_, idx_, vx, vy = fem.shared_pattern(ops.gradient_x, ops.gradient_y)
+        self.grad = (put(ptr_), put(idx_), put(vx), put(vy))
+        C = put(ops.C)
+        # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
+        # unless the dense Q is wanted for the self-field GEMV.
+        self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, C, dtype, want_Q=store_Q)
+
+
+@dataclass
+class LinearSystem:
+    """The linear system of a film or hole (``solver/solve_film.py:19-35``).
+
+    ``A`` and ``lu_piv`` are host views produced on demand from the device-resident data;
+    ``lu_piv = (lu, piv)`` follows ``scipy.linalg.lu_factor`` conventions."""
+
+    indices: np.ndarray
+    grad_Lambda_term: Union[float, np.ndarray] = 0.0
+    _assemble: Optional[Callable[[], "np.ndarray"]] = None   # -> host A
+    factors: Optional[object] = None                         # kernels.LUFactors
+    A_device: Optional[object] = None                        # hole systems: [n, ld] tensor
+    indices_device: Optional[object] = None
+    rhs_indices_device: Optional[object] = None              # indices[perm] (LU row order)
+    _A_host: Optional[np.ndarray] = None
+
+    @property
+    def A(self) -> np.ndarray:
+        if self._A_host is None:
+            self._A_host = self._assemble()
+        return self._A_host
+
+    @property
+    def lu_piv(self) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        if self.factors is None:
+            return None
+        f = self.factors
+        return f.lu[:, :f.n].cpu().numpy(), f.ipiv.cpu().numpy()
+
+
+def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo], *,
+                             store_Q: bool = False):
+    """``factorize_linear_systems`` (``solver/solve_film.py:151-282``) on the GPU.
+    Returns ``(film_systems, hole_systems, terminal_systems, film_data)``."""
+    import torch
+
+    from . import _hip, kernels
+
+    _hip.require_gpu()
+    dtype = device.solve_dtype
+    film_systems, hole_systems, film_data = {}, {}, {}
+    for name, info in film_info_dict.items():
+        if info.lambda_info.inhomogeneous:
+            raise NotImplementedError(
+                "Inhomogeneous Lambda (grad(Lambda) term, solve_film.py:181-185) is not on the "
+                "accelerated path yet."
+            )
+        mesh = device.meshes[name]
+        fd = FilmDeviceData(info, mesh, dtype, store_Q)
+        film_data[name] = fd
+        dev = fd.device
+
+        def assemble(rows, cols, sign, fd=fd):
+            return kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, rows, cols,
+                                           sign=sign, dtype=dtype)
+
+        hole_systems[name] = {}
+        for hole_name, indices in info.hole_indices.items():
+            ix_d = torch.from_numpy(indices.astype(np.int64)).to(dev)
+            A_h = assemble(None, ix_d, 1.0)  # [n, ld]
+            hole_systems[name][hole_name] = LinearSystem(
+                indices=indices, A_device=A_h, indices_device=ix_d,
+                _assemble=lambda A_h=A_h, k=len(indices): A_h[:, :k].cpu().numpy(),
+            )
+        interior = info.interior_indices
+        if info.hole_indices:  # solve_film.py:269-272
+            interior = np.setdiff1d(interior, np.concatenate(list(info.hole_indices.values())))
+        ix_d = torch.from_numpy(interior.astype(np.int64)).to(dev)
+        ni = len(interior)
+        minusA = assemble(ix_d, ix_d, -1.0)          # -A, written once, factored in place
+        factors = kernels.lu_factor(minusA, ni)      # solve_film.py:279
+        if factors.info > 0:
+            logger.warning(f"LU of film {name!r}: exactly singular U[{factors.info - 1}, "
+                           f"{factors.info - 1}] (LAPACK info = {factors.info}).")
+        film_systems[name] = LinearSystem(
+            indices=interior, factors=factors, indices_device=ix_d,
+            rhs_indices_device=ix_d[factors.perm].contiguous(),
+            _assemble=lambda ix_d=ix_d, ni=ni, assemble=assemble: assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy(),
+        )
+    return film_systems, hole_systems, {}, film_data
+
+
+@dataclass
+class FactorizedModel:
+    """A pre-factorized model (``solver/solve.py:76-100``), reusable for any number of
+    ``solve(model=...)`` calls; ``solve`` never mutates it."""
+
+    device: Device
+    film_info: Dict[str, FilmInfo]
+    film_systems: Dict[str, LinearSystem]
+    hole_systems: Dict[str, Dict[str, LinearSystem]]
+    terminal_systems: Dict[str, object]
+    terminal_currents: Dict[str, Dict[str, float]]
+    circulating_currents: Dict[str, float]
+    vortices: Sequence[Vortex]
+    current_units: str
+    film_data: Dict[str, FilmDeviceData] = field(default_factory=dict, repr=False)
+    self_field_mode: str = "matrix_free"
+
+    def set_circulating_currents(self, circulating_currents: Dict[str, Union[float, str]]) -> None:
+        """``solver/solve.py:182-202``: no re-factorization needed."""
+        currents = {k: current_to_float(v, self.current_units) for k, v in circulating_currents.items()}
+        holes = self.device.holes
+        for hole_name in currents:
+            if hole_name not in holes:
+                raise KeyError(f"Unknown hole {hole_name!r}.")
+        self.circulating_currents = currents
+        for info in self.film_info.values():
+            info.circulating_currents = {h: c for h, c in currents.items() if h in info.hole_indices}
+
+    def set_vortices(self, vortices: Sequence[Vortex]) -> None:
+        if vortices:
+            raise NotImplementedError("Vortices are not on the accelerated path yet.")
+        self.vortices = []
+
+    def copy(self) -> "FactorizedModel":
+        """Shallow copy (``solver/solve.py:219-220``)."""
+        return _copy.copy(self)
+
+
+def factorize_model(*, device: Device, current_units: str,
+                    terminal_currents: Optional[Dict[str, Dict[str, Union[float, str]]]] = None,
+                    circulating_currents: Optional[Dict[str, Union[float, str]]] = None,
+                    vortices: Optional[Sequence[Vortex]] = None,
+                    self_field: str = "matrix_free") -> FactorizedModel:
+    """``factorize_model`` (``solver/solve.py:223-287``).
+
+    ``self_field`` (extension): ``"matrix_free"`` regenerates q_ij on the fly for
+    ``Q @ (w * g)`` (2.2x faster than streaming a stored Q at n = 50k, and n^2 words less HBM);
+    ``"dense"`` stores Q in the solve dtype like the reference and uses a GEMV.
+    """
+    if self_field not in ("matrix_free", "dense"):
+        raise ValueError(f"Unknown self_field mode {self_field!r}.")
+    circulating_currents = {k: current_to_float(v, current_units)
+                            for k, v in (circulating_currents or {}).items()}
+    terminal_currents = {film: {k: current_to_float(v, current_units) for k, v in cur.items()}
+                         for film, cur in (terminal_currents or {}).items()}
+    for film_name, currents in terminal_currents.items():
+        if sum(currents.values()):
+            raise ValueError(f"Terminal currents in film {film_name!r} are not conserved.")
+    if any(terminal_currents.values()):
+        raise NotImplementedError("Terminal currents are not on the accelerated path yet.")
+    vortices = list(vortices or [])
+    if not device.meshes:
+        raise ValueError("The device does not have a mesh. Call device.make_mesh() to generate it.")
+    film_info = make_film_info(device=device, vortices=vortices,
+                               circulating_currents=circulating_currents,
+                               terminal_currents=terminal_currents)
+    if vortices:
+        raise NotImplementedError("Vortices are not on the accelerated path yet.")
+    film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
+        device, film_info, store_Q=(self_field == "dense"))
+    return FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
+                           terminal_currents, circulating_currents, vortices, current_units,
+                           film_data=film_data, self_field_mode=self_field)
+
+
+# ---------------------------------------------------------------------------------------
+# solve_film / solve
+# ---------------------------------------------------------------------------------------
+@dataclass
+class _DeviceFilmResult:
+    g: object          # [n] solve dtype
+    J: object          # [n, 2] float64
+    self_field: object  # [n] solve dtype, raw (not yet divided by field_conversion)
+
+
+def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
+                       check_inversion: bool) -> _DeviceFilmResult:
+    """Device part of ``solve_film`` (``solver/solve_film.py:486-565``)."""
+    import torch
+
+    from . import kernels
+
+    fd = model.film_data[name]
+    info = model.film_info[name]
+    system = model.film_systems[name]
+    g = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+    ha_eff = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+    for hole_name, hs in model.hole_systems[name].items():
+        current = info.circulating_currents.get(hole_name, 0)
+        kernels.index_add_scalar(g, hs.indices_device, current)        # g[hole] += I_circ
+        kernels.gemv(hs.A_device, fd.n, len(hs.indices), g, xidx=hs.indices_device,
+                     y=ha_eff, alpha=-1.0, beta=1.0)                      # Ha_eff += -(A @ g[ix])
+    h = kernels.film_rhs(applied_d, other_d, ha_eff, system.rhs_indices_device)
+    if check_inversion:
+        h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
+    gf = kernels.lu_solve_permuted(system.factors, h)                    # = lu_solve(lu_piv, h)
+    if check_inversion:  # solve_film.py:533-540: warn, never raise
+        A = torch.from_numpy(system.A).to(fd.device)
+        hsim = -(kernels.gemv(A, len(system.indices), len(system.indices), gf))
+        if not np.allclose(hsim.cpu().numpy(), h_nat.cpu().numpy()):
+            err = (hsim - h_nat).abs().max().item()
+            logger.warning(f"Unable to solve for stream function in {name!r}), maximum error {err:.3e}.")
+    kernels.scatter_add(g, system.indices_device, gf)
+    J = kernels.current_density(*fd.grad, g)
+    if model.self_field_mode == "dense":
+        sf = kernels.gemv(fd.Q, fd.n, fd.n, g, xscale=fd.w_t)
+    else:
+        sf = kernels.self_field(fd.xy, fd.w, fd.qdiag, g)
+    return _DeviceFilmResult(g=g, J=J, self_field=sf)
+
+
+def _film_solution(res: _DeviceFilmResult, applied_h: np.ndarray, other_d, conv: float) -> FilmSolution:
+    """Host epilogue of ``solve_film`` (``solver/solve_film.py:566-574``)."""
+    other = None
+    if other_d is not None:
+        other = other_d.cpu().numpy() / conv
+    return FilmSolution(
+        stream=res.g.cpu().numpy(),
+        current_density=res.J.cpu().numpy(),
+        applied_field=applied_h / conv,
+        self_field=res.self_field.cpu().numpy() / conv,
+        field_from_other_films=other,
+    )
+
+
+def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] = None,
+          applied_field: Optional[Callable] = None,
+          terminal_currents: Optional[Dict[str, Dict[str, Union[float, str]]]] = None,
+          circulating_currents: Optional[Dict[str, Union[float, str]]] = None,
+          vortices: Optional[Sequence[Vortex]] = None, field_units: str = "mT",
+          current_units: str = "uA", check_inversion: bool = False, iterations: int = 0,
+          return_solutions: bool = True, save_path=None, log_level: Optional[int] = None,
+          progress_bar: bool = True, tolerance: Optional[float] = None,
+          coupling: Optional[object] = None,
+          _solver: str = "superscreen_amd.solve") -> Optional[List[Solution]]:
+    """``solve`` (``solver/solve.py:290-549``): same arguments, same Jacobi scheme, same list of
+    ``iterations + 1`` Solutions (1 for a single film or ``iterations < 1``).
+
+    Extensions: ``tolerance`` stops the fixed-count loop early once
+    ``max_f max|g_k - g_{k-1}| / max|g_k| < tolerance`` (the reference has no convergence test,
+    SURVEY.md quirk 6; ``iterations`` stays the upper bound); ``coupling`` is an optional
+    :class:`superscreen_amd.parallel.CouplingPlan` that spreads the inter-film Biot-Savart sums
+    over several GPUs (one RCCL all-reduce per iteration).
+    """
+    import torch
+
+    from . import kernels
+
+    if log_level is not None:
+        logging.basicConfig(level=log_level)
+    if save_path is not None:
+        raise NotImplementedError("HDF5 persistence (save_path) is out of scope.")
+    if model is None:
+        if device is None:
+            raise ValueError("Either a model or a device must be provided.")
+        model = factorize_model(device=device, current_units=current_units,
+                                terminal_currents=terminal_currents,
+                                circulating_currents=circulating_currents, vortices=vortices)
+    else:
+        if (device is not None or terminal_currents is not None
+                or circulating_currents is not None or vortices is not None):
+            raise ValueError("If model argument is provided, device, terminal_currents,"
+                             " circulating_currents, and vortices must be None.")
+    if not isinstance(model, FactorizedModel):
+        raise TypeError(f"model must be an instance of FactorizedModel (got {type(model)}).")
+
+    device = model.device
+    film_info = model.film_info
+    current_units = model.current_units
+    if not device.meshes:
+        raise ValueError("The device does not have a mesh. Call device.make_mesh() to generate it.")
+    dtype = device.solve_dtype
+    meshes = device.meshes
+    applied_field = applied_field or ConstantField(0)
+    conv = field_conversion_factor(field_units, current_units, length_units=device.length_units)
+
+    applied_h, applied_d = {}, {}
+    for film, mesh in meshes.items():
+        z0 = film_info[film].z0 * np.ones(len(mesh.sites))
+        Hz = np.squeeze(np.asarray(applied_field(mesh.sites[:, 0], mesh.sites[:, 1], z0)) * conv)
+        Hz = np.asarray(Hz * np.ones(len(mesh.sites)) if Hz.ndim == 0 else Hz).astype(dtype, copy=False)
+        if Hz.ndim != 1:
+            raise ValueError(f"Expected applied_field to return a 1D vector, got a {Hz.shape[1]}D vector.")
+        applied_h[film] = Hz
+        applied_d[film] = torch.from_numpy(np.ascontiguousarray(Hz)).to(model.film_data[film].device)
+    _ = vortex_flux(current_units, device.length_units)  # solve.py:441-442 (vortex branch unused)
+
+    solution_kwargs = dict(applied_field_func=applied_field, field_units=field_units,
+                           current_units=current_units,
+                           circulating_currents=model.circulating_currents,
+                           terminal_currents=model.terminal_currents, vortices=model.vortices,
+                           solver=_solver)
+    solutions: List[Solution] = []
+    films = list(device.films)
+
+    def run_pass(other_d):
+        results = {}
+        for name in films:
+            results[name] = _solve_film_device(model, name, applied_d[name],
+                                               None if other_d is None else other_d[name],
+                                               check_inversion)
+        return results
+
+    def package(results, other_d):
+        fs = {name: _film_solution(results[name], applied_h[name],
+                                   None if other_d is None else other_d[name], conv)
+              for name in films}
+        return Solution(device=device, film_solutions=fs, **solution_kwargs)
+
+    results = run_pass(None)
+    if return_solutions:
+        solutions.append(package(results, None))
+    if len(films) < 2 or iterations < 1:
+        return solutions if return_solutions else None
+
+    for it in range(iterations):
+        other_d = {name: torch.zeros(model.film_data[name].n, dtype=model.film_data[name].tdtype,
+                                     device=model.film_data[name].device) for name in films}
+        if coupling is not None:
+            coupling.accumulate(model, results, other_d)
+        else:
+            for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
+                if src == tgt:
+                    continue
+                s, t = model.film_data[src], model.film_data[tgt]
+                kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,
+                                    film_info[tgt].z0 - film_info[src].z0, other_d[tgt],
+                                    accumulate=True)
+        prev = results
+        results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
+        if return_solutions:
+            solutions.append(package(results, other_d))
+        if tolerance is not None:
+            change = max(((results[n].g - prev[n].g).abs().max() / results[n].g.abs().max()).item()
+                         for n in films)
+            logger.debug(f"iteration {it + 1}: relative change {change:.3e}")
+            if change < tolerance:
+                break
+    return solutions if return_solutions else None

@@ -1,0 +1,148 @@
+"""CPU tests of the host layer: operators vs fixtures recorded from the reference, index logic,
+units, API/error conventions, and that the C-ABI library exports what the header declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import superscreen_amd as sc
+from superscreen_amd import fem, synthetic, units
+from superscreen_amd.mesh import Mesh, MeshOperators
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csr(d, prefix, shape):
+    return sp.csr_array((d[f"{prefix}_data"], d[f"{prefix}_indices"], d[f"{prefix}_indptr"]), shape=shape)
+
+
+@pytest.mark.parametrize("name", ["disk_K10.npz", "disk_K26.npz", "washer_K17.npz"])
+def test_mesh_operators_match_reference(golden, name):
+    d = golden(name)
+    mesh = Mesh.from_triangulation(d["sites"], d["elements"])
+    n, m = len(d["sites"]), len(d["elements"])
+    assert np.array_equal(mesh.boundary_indices, d["boundary_indices"])
+    assert np.allclose(mesh.triangle_areas, d["triangle_areas"], rtol=1e-13, atol=0)
+    assert np.allclose(mesh.vertex_areas, d["weights"], rtol=1e-13, atol=0)
+    assert np.allclose(MeshOperators.C_vector(d["sites"]), d["C"], rtol=1e-14, atol=0)
+    ops = mesh.operators
+    for prefix, op, shape in [("lap", ops.laplacian, (n, n)), ("gx", ops.gradient_x, (n, n)),
+                              ("gy", ops.gradient_y, (n, n)), ("Gx", ops.gradient_tri_x, (m, n)),
+                              ("Gy", ops.gradient_tri_y, (m, n))]:
+        ref = csr(d, prefix, shape)
+        assert abs(op - ref).max() <= 1e-11 * abs(ref).max(), prefix
+    ptr_, idx_, vx, vy = fem.shared_pattern(ops.gradient_x, ops.gradient_y)
+    gx2 = sp.csr_array((vx, idx_, ptr_), shape=(n, n))
+    gy2 = sp.csr_array((vy, idx_, ptr_), shape=(n, n))
+    assert abs(gx2 - ops.gradient_x).max() == 0 and abs(gy2 - ops.gradient_y).max() == 0
+
+
+def test_film_info_indices_match_reference(golden):
+    from superscreen_amd.solver import make_film_info
+
+    d = golden("washer_K17.npz")
+    device = synthetic.make_stack_device(int(d["K"]), ("washer",), solve_dtype="float64")
+    info = make_film_info(device=device, vortices=[], circulating_currents={"hole0": 1.0},
+                          terminal_currents={})["washer0"]
+    interior = np.setdiff1d(info.interior_indices, info.hole_indices["hole0"])
+    assert np.array_equal(interior, d["film_indices"])
+    assert np.array_equal(info.hole_indices["hole0"], d["hole_indices"])
+    assert info.circulating_currents == {"hole0": 1.0}
+    assert not info.lambda_info.inhomogeneous
+    assert info.weights.dtype == np.float64 and info.lambda_info.Lambda.shape == (len(d["sites"]), 1)
+
+
+def test_synthetic_sizes():
+    # n and n_i of the BASELINE configs
+    for K, n, ni in [(26, 2107, 1657), (81, 19927, 16207), (91, 25117, 20419), (129, 50311, 41419)]:
+        assert synthetic.num_vertices(K) == n
+        Kf = synthetic.film_rings(K)
+        assert 1 + 3 * Kf * (Kf + 1) == ni
+
+
+def test_units():
+    assert units.field_conversion_factor("mT", "uA", "um") == pytest.approx(795.7747150262763, rel=1e-12)
+    assert units.field_conversion_factor("A/m", "uA", "um") == pytest.approx(1.0)
+    assert units.field_conversion_factor("Oe", "A", "m") == pytest.approx(1e3 / (4 * np.pi))
+    assert units.vortex_flux("uA", "um") == pytest.approx(1645.5298914814798, rel=1e-12)
+    assert units.convert_field(2.0, "uT", old_units="mT", with_units=False) == pytest.approx(2000.0)
+    assert float(units.Quantity(1.0, "mT * um**2").to("Phi_0").magnitude) == pytest.approx(
+        1e-15 / units.PHI_0)
+    assert units.current_to_float("1 mA", "uA") == pytest.approx(1000.0)
+    with pytest.raises(ValueError):
+        units.parse_units("furlong")
+
+
+def test_device_api_and_errors():
+    layers = [sc.Layer("base", Lambda=0.1, z0=0), sc.Layer("top", london_lambda=0.3, thickness=0.1, z0=1)]
+    assert layers[1].Lambda == pytest.approx(0.9)
+    with pytest.raises(ValueError):
+        sc.Layer("bad")
+    with pytest.raises(ValueError):
+        sc.Layer("bad", Lambda=1, thickness=1)
+    cw = synthetic.circle_points(2.0)[::-1]  # clockwise input gets re-oriented CCW
+    film = sc.Polygon("film", layer="base", points=cw)
+    x, y = film.points[:, 0], film.points[:, 1]
+    assert np.sum(x[:-1] * y[1:] - x[1:] * y[:-1]) > 0
+    assert film.contains_points([[0, 0], [3, 0]]).tolist() == [True, False]
+    assert film.contains_points([[0, 0], [3, 0]], index=True).tolist() == [0]
+    hole = sc.Polygon("hole", layer="base", points=synthetic.circle_points(0.5))
+    dev = sc.Device("d", layers=layers, films=[film], holes=[hole], solve_dtype="float64")
+    assert dev.solve_dtype == np.float64 and dev.length_units == "um"
+    assert [h.name for h in dev.holes_by_film()["film"]] == ["hole"]
+    assert dev.copy().solve_dtype == np.float32  # reference quirk (device/device.py:232-240)
+    with pytest.raises(ValueError):
+        sc.Device("d", layers=layers, films=[sc.Polygon("f", layer="nope", points=cw)])
+    with pytest.raises(ValueError):
+        dev.solve_dtype = "int32"
+    with pytest.raises(ValueError):  # no mesh
+        sc.solve(dev, applied_field=sc.ConstantField(1))
+    with pytest.raises(ValueError):
+        sc.solve(dev, model=object())
+    with pytest.raises(TypeError):
+        sc.solve(model=object())
+    with pytest.raises(ValueError):
+        sc.solve()
+
+
+def test_parameter():
+    f = sc.Parameter(lambda x, y, a=1: a * (x + y), a=2.0)
+    assert np.allclose(f(np.ones(3), np.ones(3)), 4.0)
+    assert np.allclose((f * 2 + 1)(np.ones(2), np.ones(2)), 9.0)
+    with pytest.raises(ValueError):
+        sc.Parameter(lambda a, b: a)
+    assert sc.Constant(0.25)(np.zeros(4), np.zeros(4)).tolist() == [0.25] * 4
+    assert sc.ConstantField(3)(np.zeros(2), np.zeros(2), np.zeros(2)).tolist() == [3.0, 3.0]
+
+
+def test_library_exports_every_declared_symbol():
+    from superscreen_amd import _hip
+
+    header = open(os.path.join(ROOT, "include", "superscreen_hip.h")).read()
+    declared = set(re.findall(r"\b(ssa_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip("library not built (run python -m superscreen_amd.build)")
+    lib = _hip.load_library()  # checks every symbol; no compute call is made without a GPU
+    assert lib.ssa_abi_version() == 1
+    assert lib.ssa_error_string(-3).decode().startswith("workspace")
+    perm = np.empty(4, dtype=np.int64)
+    ipiv = np.array([2, 1, 3, 3], dtype=np.int32)
+    assert lib.ssa_lu_pivots_to_permutation(ipiv.ctypes.data, 4, perm.ctypes.data) == 0
+    assert perm.tolist() == [2, 1, 3, 0]
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from superscreen_amd._hip import HipLibraryError
+
+    device = synthetic.make_stack_device(6, ("disk",), solve_dtype="float64")
+    with pytest.raises(HipLibraryError):
+        sc.solve(device, applied_field=sc.ConstantField(1))
+    with pytest.raises(HipLibraryError):
+        _ = device.meshes["disk0"].operators.Q

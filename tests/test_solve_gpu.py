@@ -1,0 +1,174 @@
+"""End-to-end GPU parity: ``superscreen_amd.solve`` (HIP path through the C ABI) against
+(a) fixtures recorded from the reference itself and (b) the CPU oracle on the same inputs.
+Tolerance for float64: stream function max-rel-error < 1e-9 (north_star asks < 1e-6)."""
+import numpy as np
+import pytest
+
+import superscreen_oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import superscreen_amd
+
+    return superscreen_amd
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("name,kind", [("disk_K10.npz", "disk"), ("disk_K26.npz", "disk"),
+                                       ("washer_K17.npz", "washer")])
+@pytest.mark.parametrize("mode", ["matrix_free", "dense"])
+def test_single_film_vs_reference_fixture(sc, golden, name, kind, mode):
+    from superscreen_amd import synthetic
+
+    d = golden(name)
+    for li, Lam in enumerate(d["Lambdas"]):
+        device = synthetic.make_stack_device(int(d["K"]), (kind,), Lambda=float(Lam), solve_dtype="float64")
+        for ci, circ in enumerate(d["circs"]):
+            cc = {"hole0": float(circ)} if kind == "washer" else None
+            model = sc.factorize_model(device=device, current_units="uA", circulating_currents=cc,
+                                       self_field=mode)
+            film = f"{kind}0"
+            assert np.array_equal(model.film_systems[film].indices, d["film_indices"])
+            sols = sc.solve(model=model, applied_field=sc.ConstantField(1.0), field_units="mT",
+                            iterations=3, check_inversion=True)
+            assert len(sols) == 1  # single film: solve.py:486-489
+            fs = sols[0].film_solutions[film]
+            tag = f"L{li}_c{ci}"
+            assert relerr(fs.stream, d[f"g_{tag}"]) < TOL
+            assert relerr(fs.current_density, d[f"J_{tag}"]) < TOL
+            assert relerr(fs.self_field, d[f"self_field_{tag}"]) < TOL
+            assert relerr(fs.applied_field, d[f"applied_field_{tag}"]) < 1e-15
+            assert fs.field_from_other_films is None
+            if ci == 0 and mode == "matrix_free":
+                sysm = model.film_systems[film]
+                rows = d[f"A_rows_idx_L{li}"]
+                assert relerr(sysm.A[rows], d[f"A_rows_L{li}"]) < 1e-12
+                lu, piv = sysm.lu_piv
+                assert np.array_equal(piv, d[f"piv_L{li}"])
+                if kind == "washer":
+                    Ah = model.hole_systems[film]["hole0"].A
+                    assert relerr(Ah[d["sample_rows"]], d[f"A_hole_rows_L{li}"]) < 1e-12
+
+
+def test_mesh_operators_Q_property(sc, golden):
+    from superscreen_amd.mesh import Mesh
+
+    d = golden("disk_K10.npz")
+    mesh = Mesh.from_triangulation(d["sites"], d["elements"])
+    assert relerr(mesh.operators.Q, d["Q"]) < 1e-13
+
+
+@pytest.mark.parametrize("name,kinds", [("stack2_K12.npz", ("washer", "disk")),
+                                        ("stack3_K8.npz", ("disk", "washer", "disk"))])
+def test_coupled_films_jacobi_trace_and_fluxoid(sc, golden, name, kinds):
+    from superscreen_amd import synthetic
+
+    d = golden(name)
+    K = int(d["K"])
+    device = synthetic.make_stack_device(K, kinds, Lambda=float(d["Lambda"]), solve_dtype="float64",
+                                         z_spacing=float(d["z0s"][1] - d["z0s"][0]))
+    names = [str(s) for s in d["names"]]
+    assert list(device.films) == names
+    cc = {f"hole{i}": float(d["circ"]) for i, k in enumerate(kinds) if k == "washer"}
+    iters = int(d["iterations"])
+    sols = sc.solve(device, applied_field=sc.ConstantField(float(d["field_mT"])), field_units="mT",
+                    current_units="uA", circulating_currents=cc, iterations=iters)
+    assert len(sols) == iters + 1
+    for it, sol in enumerate(sols):
+        for nm in names:
+            fs = sol.film_solutions[nm]
+            assert relerr(fs.stream, d[f"g_{nm}_it{it}"]) < TOL
+            assert relerr(fs.current_density, d[f"J_{nm}_it{it}"]) < TOL
+            assert relerr(fs.self_field, d[f"self_field_{nm}_it{it}"]) < TOL
+            if it == 0:
+                assert fs.field_from_other_films is None
+            else:
+                assert relerr(fs.field_from_other_films, d[f"other_{nm}_it{it}"]) < TOL
+    # fluxoid of a circle around the washer hole: both parts vs the reference's own arrays
+    nm = str(d["fluxoid_film"])
+    poly = d["fluxoid_poly"]
+    raw_units = "mT * um**2"
+    fl = sols[-1].polygon_fluxoid(poly, film=nm, units=raw_units, with_units=False)
+    assert abs(fl.flux_part - float(d["flux_part_raw"])) < 1e-9 * abs(float(d["flux_part_raw"]))
+    sc_raw = orc.MU_0 * float(d["int_J_raw"]) * 1e-12 / (1e-3 * 1e-12)  # mu_0 [uA um] -> mT um^2
+    assert abs(fl.supercurrent_part - sc_raw) < 1e-9 * abs(sc_raw)
+    hole = [h for h in device.holes if h.endswith(nm[-1])][0]
+    fq = sols[-1].hole_fluxoid(hole, points=poly)  # Phi_0, Quantity
+    ref_flux, ref_sc = orc.fluxoid_in_Phi0(float(d["flux_part_raw"]), float(d["int_J_raw"]))
+    assert abs(float(fq.flux_part.magnitude) - ref_flux) < 1e-9 * abs(ref_flux)
+    assert abs(float(fq.supercurrent_part.magnitude) - ref_sc) < 1e-9 * abs(ref_sc)
+    # early stop on tolerance returns a prefix of the same trace
+    short = sc.solve(device, applied_field=sc.ConstantField(float(d["field_mT"])), circulating_currents=cc,
+                     iterations=iters, tolerance=1e-2)
+    assert 2 <= len(short) <= iters + 1
+    assert relerr(short[-1].film_solutions[names[0]].stream, d[f"g_{names[0]}_it{len(short) - 1}"]) < TOL
+
+
+def _oracle_stack(K, kinds, z_spacing, Lambda, dtype):
+    from matplotlib.path import Path
+
+    from superscreen_amd import synthetic
+
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = orc.make_mesh(sites, elements)
+    Kf = synthetic.film_rings(K)
+    film_poly = synthetic.circle_points((Kf + 0.5) * dr)
+    hole_poly = synthetic.circle_points((Kf // 3 + 0.5) * dr, 201)
+    films = []
+    for i, kind in enumerate(kinds):
+        holes = {f"hole{i}": Path(hole_poly, closed=True).contains_points(sites)} if kind == "washer" else {}
+        films.append(orc.make_film(f"{kind}{i}", mesh, z0=i * z_spacing, Lambda=Lambda,
+                                   in_film=Path(film_poly, closed=True).contains_points(sites),
+                                   holes_mask=holes, dtype=dtype))
+    return films
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 5e-3)])
+def test_two_film_vs_oracle_medium(sc, dtype, tol):
+    """n = 1951 per film (K = 25): a size the reference-under-stubs cannot reach quickly."""
+    from superscreen_amd import synthetic
+
+    K, kinds = 25, ("washer", "disk")
+    device = synthetic.make_stack_device(K, kinds, solve_dtype=dtype)
+    sols = sc.solve(device, applied_field=sc.ConstantField(0.7), circulating_currents={"hole0": "3 uA"},
+                    iterations=4)
+    films = _oracle_stack(K, kinds, 0.5, 0.1, dtype)
+    trace = orc.solve(films, 0.7, iterations=4, circulating_currents={"hole0": 3.0})
+    for sol, ref in zip(sols, trace):
+        for nm in device.films:
+            assert sol.film_solutions[nm].stream.dtype == np.dtype(dtype)
+            assert relerr(sol.film_solutions[nm].stream, ref[nm].stream) < tol
+            assert relerr(sol.film_solutions[nm].self_field, ref[nm].self_field) < tol
+            assert relerr(sol.film_solutions[nm].current_density, ref[nm].current_density) < tol * 10
+
+
+def test_model_reuse_and_linearity(sc):
+    """A factorized model is reusable (solve never mutates it) and the response is linear in the
+    applied field -- the size-independent property used at BASELINE scale."""
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(20, ("washer", "disk"), solve_dtype="float64")
+    model = sc.factorize_model(device=device, current_units="uA")
+    a = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=2)[-1]
+    b = sc.solve(model=model, applied_field=sc.ConstantField(2.5), iterations=2)[-1]
+    a2 = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=2)[-1]
+    for nm in device.films:
+        assert np.array_equal(a.film_solutions[nm].stream, a2.film_solutions[nm].stream)
+        assert relerr(b.film_solutions[nm].stream, 2.5 * a.film_solutions[nm].stream) < 1e-12
+    model.set_circulating_currents({"hole0": 1.0})
+    c = sc.solve(model=model, applied_field=sc.ConstantField(0.0))[0]
+    assert np.all(c.film_solutions["washer0"].stream[model.film_info["washer0"].hole_indices["hole0"]] == 1.0)
+    with pytest.raises(KeyError):
+        model.set_circulating_currents({"nope": 1.0})
