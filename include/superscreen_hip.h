@@ -221,6 +221,15 @@ int ssa_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64
              const void *B, int64_t ldb, double beta, void *C, int64_t ldc, int dtype,
              void *stream);
 
+/*
+ * Instrumentation for bench.py: between ssa_profile_begin() and ssa_profile_end() every launch
+ * of the f64 MFMA GEMM kernel (gemm_kernel<double, true>: LU trailing updates) is bracketed by
+ * HIP events on its own stream.  ssa_profile_end() waits for the recorded events and returns the
+ * summed kernel time, the summed algorithmic flops (2 M N K per launch) and the launch count.
+ */
+int ssa_profile_begin(void);
+int ssa_profile_end(double *gemm_ms, double *gemm_flops, int64_t *gemm_launches);
+
 /* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern (roofline peak). */
 int ssa_fill_probe(void *dst, size_t bytes, void *stream);
 

@@ -16,6 +16,8 @@
 // Workgroup ids are remapped (a) per XCD: ids that share an L2 get a contiguous range, and
 // (b) in groups of 8 tile-rows, so that the ~64 tiles resident on one XCD form an 8 x 8 block
 // sharing 8 A-panels and 8 B-panels (about 4 MiB at K = 256 in f64: one L2).
+#include <vector>
+
 #include "common.hpp"
 
 namespace ssa {
@@ -217,6 +219,39 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
     }
 }
 
+// ---- optional instrumentation: HIP events around every gemm_kernel<.., ALIGNED=true> launch ---
+struct GemmProfile {
+    bool enabled = false;
+    std::vector<hipEvent_t> start, stop;
+    std::vector<double> flops;
+    size_t used = 0;
+};
+static GemmProfile g_prof;
+
+struct ProfileScope {
+    bool active;
+    hipStream_t st;
+    ProfileScope(bool aligned, double flops, hipStream_t s) : active(false), st(s) {
+        if (!g_prof.enabled || !aligned) return;
+        if (g_prof.used == g_prof.start.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            g_prof.start.push_back(a);
+            g_prof.stop.push_back(b);
+            g_prof.flops.push_back(0.0);
+        }
+        g_prof.flops[g_prof.used] = flops;
+        (void)hipEventRecord(g_prof.start[g_prof.used], st);
+        active = true;
+    }
+    ~ProfileScope() {
+        if (active) {
+            (void)hipEventRecord(g_prof.stop[g_prof.used], st);
+            ++g_prof.used;
+        }
+    }
+};
+
 template <typename T>
 int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64_t lda,
                 const void *B, int64_t ldb, double beta, void *C, int64_t ldc, hipStream_t st) {
@@ -238,6 +273,7 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, in
             return SSA_ERR_HIP;
         attr_set = true;
     }
+    ProfileScope scope(aligned && sizeof(T) == 8, 2.0 * M * N * K, st);
     if (aligned) {
         hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(kGemmThreads), smem, st, M, N, K,
                            static_cast<T>(alpha), static_cast<const T *>(A), lda,
@@ -266,6 +302,30 @@ int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int6
 }  // namespace ssa
 
 using namespace ssa;
+
+extern "C" int ssa_profile_begin(void) {
+    g_prof.used = 0;
+    g_prof.enabled = true;
+    return SSA_OK;
+}
+
+extern "C" int ssa_profile_end(double *gemm_ms, double *gemm_flops, int64_t *gemm_launches) {
+    g_prof.enabled = false;
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess ||
+            hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]) != hipSuccess)
+            return SSA_ERR_HIP;
+        ms += t;
+        fl += g_prof.flops[i];
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_flops) *gemm_flops = fl;
+    if (gemm_launches) *gemm_launches = static_cast<int64_t>(g_prof.used);
+    g_prof.used = 0;
+    return SSA_OK;
+}
 
 extern "C" int ssa_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A,
                         int64_t lda, const void *B, int64_t ldb, double beta, void *C,

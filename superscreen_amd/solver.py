@@ -168,25 +168,32 @@ class FilmDeviceData:
         dev = torch.device("cuda", torch.cuda.current_device())
         ops = mesh.operators
 
-        def put(a, dt=None):
-            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            return t if dt is None else t.to(dt)
+        def put(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
+        # Mesh geometry and sparse operators are uploaded once per (mesh, GPU, dtype) and stay
+        # resident in HBM across factorize_model calls.
+        key = (dev.index, str(dtype))
+        geo = ops._device_cache.get(key)
+        if geo is None:
+            lap = ops.laplacian.tocsr()
+            lap.sort_indices()
+            ptr_, idx_, vx, vy = fem.shared_pattern(ops.gradient_x, ops.gradient_y)
+            w = put(ops.weights)
+            geo = dict(
+                xy=put(mesh.sites), w=w, w_t=w.to(tdt), C=put(ops.C),
+                lap=(put(lap.indptr.astype(np.int64)), put(lap.indices.astype(np.int64)), put(lap.data)),
+                grad=(put(ptr_), put(idx_), put(vx), put(vy)),
+            )
+            ops._device_cache[key] = geo
         self.n = len(mesh.sites)
         self.dtype, self.tdtype, self.device = dtype, tdt, dev
-        self.xy = put(mesh.sites)
-        self.w = put(ops.weights)                      # float64 geometry
-        self.w_t = self.w.to(tdt)                      # film_info.weights (solve dtype)
+        self.xy, self.w, self.w_t = geo["xy"], geo["w"], geo["w_t"]  # w: f64 geometry; w_t: solve dtype
+        self.lap, self.grad = geo["lap"], geo["grad"]
         self.Lambda = put(info.lambda_info.Lambda[:, 0].astype(np.float64))
-        lap = ops.laplacian.tocsr()
-        lap.sort_indices()
-        self.lap = (put(lap.indptr.astype(np.int64)), put(lap.indices.astype(np.int64)), put(lap.data))
-        ptr_, idx_, vx, vy = fem.shared_pattern(ops.gradient_x, ops.gradient_y)
-        self.grad = (put(ptr_), put(idx_), put(vx), put(vy))
-        C = put(ops.C)
         # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
         # unless the dense Q is wanted for the self-field GEMV.
-        self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, C, dtype, want_Q=store_Q)
+        self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, geo["C"], dtype, want_Q=store_Q)
 
 
 @dataclass
