@@ -47,8 +47,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.hpp"),
-               os.path.join(os.path.dirname(PKG), "include", "superscreen_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "superscreen_hip.h"))
 
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)

@@ -105,6 +105,16 @@ int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *
     return SSA_OK;
 }
 
+// Used by lu.hip (single right-hand-side triangular solves).
+int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
+             double alpha, double beta, hipStream_t st) {
+    return launch_gemv<double>(M, nr, nc, ldm, x, nullptr, nullptr, y, alpha, beta, st);
+}
+int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
+             double alpha, double beta, hipStream_t st) {
+    return launch_gemv<float>(M, nr, nc, ldm, x, nullptr, nullptr, y, alpha, beta, st);
+}
+
 // ---------------------------------------------------------------------------------------
 // Small elementwise / gather / scatter kernels
 // ---------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@
 // i?amax does -- is what ?getf2 would produce.  Inter-workgroup hand-offs follow the CDNA4
 // recipe: sc1 payload stores, per-wave vmcnt(0) drain, relaxed agent-scope counter,
 // relaxed poll, sc1 loads; every spin is bounded.
+#include <utility>
+
 #include "common.hpp"
 
 namespace ssa {
@@ -42,6 +44,24 @@ int gemm_t<float>(int64_t M, int64_t N, int64_t K, double alpha, const float *A,
                   const float *B, int64_t ldb, double beta, float *C, int64_t ldc,
                   hipStream_t st) {
     return gemm_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+
+int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
+             double alpha, double beta, hipStream_t st);
+int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
+             double alpha, double beta, hipStream_t st);
+template <typename T>
+int gemv_t(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha,
+           double beta, hipStream_t st);
+template <>
+int gemv_t<double>(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x,
+                   double *y, double alpha, double beta, hipStream_t st) {
+    return gemv_f64(M, nr, nc, ldm, x, y, alpha, beta, st);
+}
+template <>
+int gemv_t<float>(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
+                  double alpha, double beta, hipStream_t st) {
+    return gemv_f32(M, nr, nc, ldm, x, y, alpha, beta, st);
 }
 
 constexpr int NB = 256;         // outer panel width
@@ -106,10 +126,21 @@ struct PanelArgs {
     unsigned long long *hdr;      // [2][G][2]: {absval bits, pos << 32 | orig}
     T *rows;                      // [2][G][PW]
     unsigned int *timeout;        // set when a bounded spin gives up
+    // speculation protocol (lu_panel_spec_kernel runs first):
+    const T *backup;              // [m][PW] original sub-panel, or nullptr: read A
+    const int *spec_flag;         // != 0: speculation failed, this kernel must redo the sub-panel
+    const int *zero_col;          // 1-based column of a zero pivot seen by the speculative pass
 };
 
 template <typename T>
 __global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(PanelArgs<T> a) {
+    if (a.spec_flag != nullptr && *a.spec_flag == 0) {
+        // The speculative pass was exact (no row below the diagonal block ever beat its pivot):
+        // nothing to redo.  Only the LAPACK info of an exactly-zero pivot column is finalised.
+        if (blockIdx.x == 0 && threadIdx.x == 0 && *a.zero_col != 0 && *a.info == 0)
+            *a.info = static_cast<int32_t>(a.j0 + *a.zero_col);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T *slab = reinterpret_cast<T *>(smem_raw);                       // [PW][kSlabStride]
     T *piv = slab + PW * kSlabStride;                                // [PW]
@@ -129,7 +160,10 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(PanelArgs<T> a)
 
     // ---- load the slab: wave <-> row, lane <-> column (coalesced 512 B row segments) ----
     for (int r = wave; r < myrows; r += kPanelThreads / kWave) {
-        if (lane < jb) slab[lane * kSlabStride + r] = Ap[static_cast<int64_t>(row_base + r) * a.lda + lane];
+        if (lane < jb)
+            slab[lane * kSlabStride + r] =
+                a.backup ? a.backup[static_cast<int64_t>(row_base + r) * PW + lane]
+                         : Ap[static_cast<int64_t>(row_base + r) * a.lda + lane];
     }
     if (tid < PW) row_at_top[tid] = tid;
     const int orig = row_base + tid;
@@ -277,6 +311,11 @@ constexpr size_t panel_smem_bytes() {
     return sizeof(T) * (PW * kSlabStride + PW) + 8 * sizeof(double) +
            sizeof(int) * (24 + PW + PW + 4 + kPanelThreads) + 64;
 }
+
+}  // namespace ssa
+#include "lu_spec.hpp"
+#include "lu_spec3.hpp"
+namespace ssa {
 
 // ---- row interchanges on column ranges [c0a,c1a) and [c0b,c1b) -------------------------
 template <typename T>
@@ -440,33 +479,60 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
     unsigned int *timeout = cnt + kShards * 32;
     unsigned long long *hdr = cv.take<unsigned long long>(2 * kMaxPanelGroups * 2);
     T *rows = cv.take<T>(2 * static_cast<size_t>(kMaxPanelGroups) * PW);
+    const int64_t nsub = ceil_div(n, PW) + ceil_div(n, NB);  // upper bound on sub-panels
+    int *flags = cv.take<int>(2 * nsub);                     // [nsub] spec flags, [nsub] zero cols
+    T *backup = cv.take<T>(static_cast<size_t>(n) * PW);
+    T *dinv = cv.take<T>(static_cast<size_t>(NB / PW) * 64 * 64);  // inv(L11) of the sub-panels
 
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_panel_kernel<T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(panel_smem_bytes<T>())) != hipSuccess)
+                                static_cast<int>(panel_smem_bytes<T>())) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_panel_spec3_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(spec3_smem_bytes<T>())) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_lower_inv_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(trsm_inv_smem_bytes<T>())) != hipSuccess)
             return SSA_ERR_HIP;
         attr_set = true;
     }
     if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
+    if (hipMemsetAsync(flags, 0, 2 * nsub * sizeof(int), st) != hipSuccess) return SSA_ERR_HIP;
 
     int rc;
+    int64_t sub = 0;
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
         const int64_t kb = (n - k0 < NB) ? n - k0 : NB;
-        for (int64_t j0 = k0; j0 < k0 + kb; j0 += PW) {
+        for (int64_t j0 = k0; j0 < k0 + kb; j0 += PW, ++sub) {
             const int64_t jb = (k0 + kb - j0 < PW) ? k0 + kb - j0 : PW;
             const int64_t m = n - j0;
+            // (1) speculative pass: pivots assumed inside the diagonal block, verified on the fly
+            const int64_t sidx = (j0 - k0) / PW;
+            Spec3Args<T> sa;
+            sa.A = A; sa.lda = lda; sa.j0 = j0; sa.m = static_cast<int>(m); sa.jb = static_cast<int>(jb);
+            sa.ipiv = ipiv; sa.backup = backup; sa.spec_flag = flags + sub; sa.zero_col = flags + nsub + sub;
+            sa.cnt = cnt; sa.dinv = dinv + sidx * 64 * 64;
+            hipLaunchKernelGGL((lu_panel_spec3_kernel<T>), dim3(ceil_div(m, kSpec3Rows) + 1), dim3(256),
+                               spec3_smem_bytes<T>(), st, sa);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+            // (2) exact cooperative pass: returns immediately unless the speculation failed
             const int G = static_cast<int>(ceil_div(m, kPanelThreads));
             const int rpw = static_cast<int>(ceil_div(m, G));
-            if (hipMemsetAsync(cnt, 0, (kShards * 32 + 32) * sizeof(unsigned int), st) != hipSuccess)
-                return SSA_ERR_HIP;
             PanelArgs<T> pa;
             pa.A = A; pa.lda = lda; pa.j0 = j0; pa.m = static_cast<int>(m);
             pa.jb = static_cast<int>(jb); pa.rpw = rpw; pa.ipiv = ipiv; pa.info = info;
             pa.cnt = cnt; pa.hdr = hdr; pa.rows = rows; pa.timeout = timeout;
+            pa.backup = backup; pa.spec_flag = flags + sub; pa.zero_col = flags + nsub + sub;
             hipLaunchKernelGGL((lu_panel_kernel<T>), dim3(G), dim3(kPanelThreads),
                                panel_smem_bytes<T>(), st, pa);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+            // (3) inverse of the unit-lower diagonal block for the block trsm: already written by
+            //     the speculative kernel; recomputed only if the cooperative kernel had to run
+            hipLaunchKernelGGL((trtri_lower64_kernel<T>), dim3(1), dim3(256), 0, st, A + j0 * lda + j0, lda,
+                               static_cast<int64_t>(0), static_cast<int>(jb), 1, dinv + sidx * 64 * 64,
+                               static_cast<const int *>(flags + sub));
             SSA_RETURN_IF_LAUNCH_FAILED();
             // interchanges for the other columns of the outer panel
             const int64_t wa = j0 - k0, wb = (k0 + kb) - (j0 + jb);
@@ -478,8 +544,10 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
             if (wb > 0) {
                 T *L11 = A + j0 * lda + j0;
                 T *U12 = A + j0 * lda + j0 + jb;
-                rc = launch_trsm<T, false, false>(L11, lda, 0, U12, lda, 0, static_cast<int>(jb), wb, 1, st);
-                if (rc != SSA_OK) return rc;
+                hipLaunchKernelGGL((trsm_lower_inv_kernel<T>), dim3(ceil_div(wb, 32)), dim3(256),
+                                   trsm_inv_smem_bytes<T>(), st, L11, lda, dinv + sidx * 64 * 64, U12, lda,
+                                   static_cast<int>(jb), wb);
+                SSA_RETURN_IF_LAUNCH_FAILED();
                 const int64_t mm = n - j0 - jb;
                 if (mm > 0) {
                     rc = gemm_t<T>(mm, wb, jb, -1.0, A + (j0 + jb) * lda + j0, lda, U12, lda, 1.0,
@@ -498,8 +566,10 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
         if (right > 0) {
             T *L11 = A + k0 * lda + k0;
             T *U12 = A + k0 * lda + k0 + kb;
-            rc = launch_trsm<T, false, false>(L11, lda, 0, U12, lda, 0, static_cast<int>(kb), right, 1, st);
-            if (rc != SSA_OK) return rc;
+            hipLaunchKernelGGL((trsm_lower_inv_kernel<T>), dim3(ceil_div(right, 32)), dim3(256),
+                               trsm_inv_smem_bytes<T>(), st, L11, lda, dinv, U12, lda, static_cast<int>(kb),
+                               right);
+            SSA_RETURN_IF_LAUNCH_FAILED();
             rc = gemm_t<T>(right, right, kb, -1.0, A + (k0 + kb) * lda + k0, lda, U12, lda, 1.0,
                            A + (k0 + kb) * lda + k0 + kb, lda, st);
             if (rc != SSA_OK) return rc;
@@ -538,6 +608,29 @@ int getrs(const T *LU, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs,
     const T *invL = aux, *invU = aux + nblk * NB * NB;
     const int64_t ldx = nrhs;
     int rc;
+    if (nrhs == 1 && ldb == 1) {
+        // single right-hand side: every block step is a pair of HBM-bound GEMVs
+        for (int64_t k = 0; k < nblk; ++k) {
+            const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
+            rc = gemv_t<T>(invL + k * NB * NB, kb, kb, NB, B + r0, X + r0, 1.0, 0.0, st);
+            if (rc != SSA_OK) return rc;
+            const int64_t below = n - r0 - kb;
+            if (below > 0) {
+                rc = gemv_t<T>(LU + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
+                if (rc != SSA_OK) return rc;
+            }
+        }
+        for (int64_t k = nblk - 1; k >= 0; --k) {
+            const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
+            rc = gemv_t<T>(invU + k * NB * NB, kb, kb, NB, X + r0, B + r0, 1.0, 0.0, st);
+            if (rc != SSA_OK) return rc;
+            if (r0 > 0) {
+                rc = gemv_t<T>(LU + r0, r0, kb, lda, B + r0, X, -1.0, 1.0, st);
+                if (rc != SSA_OK) return rc;
+            }
+        }
+        return SSA_OK;
+    }
     for (int64_t k = 0; k < nblk; ++k) {
         const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
         rc = gemm_t<T>(kb, nrhs, kb, 1.0, invL + k * NB * NB, NB, B + r0 * ldb, ldb, 0.0,
@@ -568,9 +661,11 @@ int getrs(const T *LU, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs,
 using namespace ssa;
 
 extern "C" size_t ssa_lu_factor_workspace_bytes(int64_t n, int dtype) {
-    (void)n;
+    const size_t es = dtype == SSA_F64 ? 8 : 4;
     const size_t rows = dtype == SSA_F64 ? PanelScratchBytes::rows<double>() : PanelScratchBytes::rows<float>();
-    return PanelScratchBytes::cnt + PanelScratchBytes::hdr + rows + 4 * 256;
+    const size_t nsub = static_cast<size_t>(ceil_div(n, PW) + ceil_div(n, NB));
+    return PanelScratchBytes::cnt + PanelScratchBytes::hdr + rows + 2 * nsub * sizeof(int) +
+           static_cast<size_t>(n) * PW * es + (NB / PW) * 64 * 64 * es + 10 * 256;
 }
 
 extern "C" size_t ssa_lu_aux_bytes(int64_t n, int dtype) {

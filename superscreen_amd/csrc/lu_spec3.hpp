@@ -1,0 +1,255 @@
+// Speculative sub-panel factorization, register-resident and fully unrolled (included by lu.hip).
+//
+// Guess (stronger than "pivots inside the diagonal block"): NO row interchange is needed in
+// this 64-column sub-panel, i.e. at every column J the diagonal entry already has the largest
+// magnitude of the column (ties go to the lowest index, which is the diagonal itself) -- what
+// i?amax would pick.  That is the normal case for the diagonally dominant London systems
+// (ipiv == arange).  The guess is VERIFIED exactly for every (row, column) while the factors are
+// computed; any violation raises the sub-panel's flag and the cooperative kernel
+// (lu_panel_kernel) redoes the sub-panel from the backup copy with full partial pivoting.
+//
+// Structure (one workgroup = 256 threads = 256 panel rows, no inter-workgroup traffic):
+//   1. every workgroup factors the 64 x 64 diagonal block redundantly, in registers: thread
+//      (r, q) holds columns q + 4 i of row r; per column one LDS hop broadcasts row J, the
+//      multiplier comes from a DPP quad broadcast; all indices are compile-time constants;
+//   2. workgroup 0 also inverts the unit-lower factor (Gauss-Jordan in the same register
+//      layout) for the block triangular solve that follows, and writes L11\U11 + ipiv;
+//   3. every thread then owns one row below the block in 64 registers and forward-substitutes
+//      it against U11 (right-looking, 2016 FMAs, U broadcast from LDS), checking
+//      |a_rJ| <= |u_JJ| on the way; rows travel HBM <-> registers through a padded LDS
+//      transpose so that global accesses stay coalesced.
+#pragma once
+
+namespace ssa {
+
+constexpr int kSpec3Rows = 256;
+
+template <typename T>
+struct Spec3Args {
+    T *A;
+    int64_t lda;
+    int64_t j0;
+    int m;
+    int jb;
+    int32_t *ipiv;
+    T *backup;            // [m][PW]
+    int *spec_flag;
+    int *zero_col;
+    unsigned int *cnt;    // counters of the cooperative kernel, reset here
+    T *dinv;              // [64][64] inverse of the unit-lower diagonal block (written by WG 0)
+};
+
+// broadcast of lane (4 * (lane / 4) + S) inside every quad, for 64-bit and 32-bit payloads
+template <int S>
+__device__ __forceinline__ int quad_bcast_i32(int x) {
+    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
+    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
+}
+template <int S>
+__device__ __forceinline__ double quad_bcast(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = quad_bcast_i32<S>(static_cast<int>(b & 0xffffffffll));
+    const int hi = quad_bcast_i32<S>(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+template <int S>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(quad_bcast_i32<S>(__float_as_int(x)));
+}
+
+// Fast reciprocal: hardware seed + two Newton steps (relative error ~1e-16; the factors differ
+// from a correctly rounded 1/p by at most an ulp, far inside the parity tolerance).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    y = __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+    return y;
+}
+
+// One elimination step of the register-tiled 64 x 64 LU (no pivoting) -- J is a constant, so
+// the set of live register columns (i >= J / 4) is known at compile time.
+template <typename T, int J>
+__device__ __forceinline__ void top_lu_step(T (&v)[16], int r, int q, int nt, T *rowbuf, bool &viol,
+                                            int &zero_col) {
+    constexpr int I0 = J >> 2, S = J & 3;
+    T *rb = rowbuf + (J & 1) * PW;
+    if (r == J) {
+#pragma unroll
+        for (int i = I0; i < 16; ++i) rb[q + 4 * i] = v[i];
+    }
+    __syncthreads();
+    const T pv = rb[J];
+    const T a = quad_bcast<S>(v[I0]);  // column-J entry of this thread's row
+    const bool below = (r > J) && (r < nt);
+    viol = viol || (below && (fabs(static_cast<double>(a)) > fabs(static_cast<double>(pv))));
+    if (pv == T(0) && zero_col == 0) zero_col = J + 1;
+    const T lm = (pv != T(0)) ? a * fast_rcp(pv) : a;   // multiplier
+    const T l = below ? lm : T(0);
+    {   // register column I0 holds c = q + 4 I0: c > J <=> q > S, c == J <=> q == S
+        const T upd = v[I0] - l * rb[q + 4 * I0];
+        v[I0] = (q > S) ? upd : ((q == S && below) ? lm : v[I0]);
+    }
+#pragma unroll
+    for (int i = I0 + 1; i < 16; ++i) v[i] -= l * rb[q + 4 * i];
+}
+template <typename T, int... Js>
+__device__ __forceinline__ void top_lu_all(T (&v)[16], int r, int q, int nt, int nsteps, T *rowbuf,
+                                           bool &viol, int &zero_col, std::integer_sequence<int, Js...>) {
+    ((Js < nsteps ? top_lu_step<T, Js>(v, r, q, nt, rowbuf, viol, zero_col) : (void)0), ...);
+}
+
+// One Gauss-Jordan step of X = inv(L11) in the same register layout: rows r > K subtract
+// L[r][K] * X[K][:].  L[r][K] = v[K >> 2] of quad lane K & 3; X[K][c] is nonzero only for
+// c <= K, i.e. register columns i <= K / 4.
+template <typename T, int K>
+__device__ __forceinline__ void trtri_step(const T (&v)[16], T (&x)[16], int r, int q, int nt, T *rowbuf) {
+    constexpr int I0 = K >> 2, S = K & 3;
+    T *rb = rowbuf + (K & 1) * PW;
+    if (r == K) {
+#pragma unroll
+        for (int i = 0; i <= I0; ++i) rb[q + 4 * i] = x[i];
+    }
+    __syncthreads();
+    const T lraw = quad_bcast<S>(v[I0]);
+    const T l = (r > K && r < nt) ? lraw : T(0);
+#pragma unroll
+    for (int i = 0; i <= I0; ++i) x[i] -= l * rb[q + 4 * i];
+}
+template <typename T, int... Ks>
+__device__ __forceinline__ void trtri_all(const T (&v)[16], T (&x)[16], int r, int q, int nt, T *rowbuf,
+                                          std::integer_sequence<int, Ks...>) {
+    (trtri_step<T, Ks>(v, x, r, q, nt, rowbuf), ...);
+}
+
+// Forward substitution of one row held in registers against U (LDS, row-major [64][65]).
+template <typename T, int J>
+__device__ __forceinline__ void fwd_step(T (&a)[PW], const T *U, const T *rdiag, bool &viol) {
+    constexpr int TS = PW + 1;
+    const T pv = U[J * TS + J];
+    viol = viol || (fabs(static_cast<double>(a[J])) > fabs(static_cast<double>(pv)));
+    const T l = a[J] * rdiag[J];
+    a[J] = l;
+#pragma unroll
+    for (int c = J + 1; c < PW; ++c) a[c] -= l * U[J * TS + c];
+}
+template <typename T, int... Js>
+__device__ __forceinline__ void fwd_all(T (&a)[PW], const T *U, const T *rdiag, int jb, bool &viol,
+                                        std::integer_sequence<int, Js...>) {
+    ((Js < jb ? fwd_step<T, Js>(a, U, rdiag, viol) : (void)0), ...);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lu_panel_spec3_kernel(Spec3Args<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TS = PW + 1;        // stride of the diagonal block image
+    constexpr int SS = 32 + 1;        // stride of the transpose staging tiles
+    T *U = reinterpret_cast<T *>(smem_raw);          // [64][TS]
+    T *rowbuf = U + PW * TS;                         // [2][64]
+    T *rdiag = rowbuf + 2 * PW;                      // [64] reciprocals of the pivots
+    T *stage = rdiag + PW;                           // [4 waves][64 rows][SS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const bool inverse_wg = (g == static_cast<int>(gridDim.x) - 1);  // extra workgroup: inv(L11) only
+    const int row_base = g * kSpec3Rows;
+    const int jb = a.jb;
+    const int nt = min(PW, a.m);
+    T *Ap = a.A + a.j0 * a.lda + a.j0;
+
+    if (g == 0) {
+        for (int i = tid; i < kShards * 32 + 32; i += 256) a.cnt[i] = 0u;
+    }
+    for (int rr = wave; rr < PW; rr += 4)
+        U[rr * TS + lane] = (rr < nt && lane < jb) ? Ap[static_cast<int64_t>(rr) * a.lda + lane] : T(0);
+    __syncthreads();
+
+    // ---- (1) diagonal block: unpivoted LU in registers, with the exactness check --------------
+    const int r = tid >> 2, q = tid & 3;
+    T v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = U[r * TS + q + 4 * i];
+    bool viol = false;
+    int zero_col = 0;
+    const int nsteps = min(jb, nt);
+    top_lu_all<T>(v, r, q, nt, nsteps, rowbuf, viol, zero_col, std::make_integer_sequence<int, PW>{});
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) U[r * TS + q + 4 * i] = v[i];
+    __syncthreads();
+    if (tid < PW) {
+        const T d = U[tid * TS + tid];
+        rdiag[tid] = (d != T(0)) ? T(1) / d : T(1);
+    }
+
+    // ---- (2) the extra workgroup: inverse of the unit-lower factor (off the critical path) -----
+    if (inverse_wg) {
+        T x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = (q + 4 * i == r) ? T(1) : T(0);
+        trtri_all<T>(v, x, r, q, nt, rowbuf, std::make_integer_sequence<int, PW - 1>{});
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.dinv[r * 64 + q + 4 * i] = x[i];
+        return;
+    }
+    if (g == 0) {
+        if (tid < jb) a.ipiv[a.j0 + tid] = static_cast<int32_t>(a.j0 + tid);
+        if (tid == 0) *a.zero_col = zero_col;
+    }
+    __syncthreads();
+
+    // ---- (3) rows of this workgroup: HBM -> (LDS transpose) -> registers ------------------------
+    T *st = stage + wave * 64 * SS;
+    const int wrow0 = row_base + wave * 64;      // first panel row of this wave
+    T arow[PW];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
+            const int pr = wrow0 + rr;
+            T val = T(0);
+            if (pr < a.m && c < jb) {
+                val = Ap[static_cast<int64_t>(pr) * a.lda + c];
+                a.backup[static_cast<int64_t>(pr) * PW + c] = val;
+            }
+            st[rr * SS + (lane & 31)] = val;
+        }
+        // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+        for (int i = 0; i < 32; ++i) arow[32 * h + i] = st[lane * SS + i];
+    }
+    const int prow = wrow0 + lane;
+    const bool active = (prow < a.m && prow >= nt);
+    bool v2 = false;
+    fwd_all<T>(arow, U, rdiag, jb, v2, std::make_integer_sequence<int, PW>{});
+    viol = viol || (active && v2);
+    if (__any(viol) && lane == 0) atomicOr(a.spec_flag, 1);
+
+    // ---- write back (top rows of workgroup 0 come from the factored block image) ----------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) st[lane * SS + i] = arow[32 * h + i];
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
+            const int pr = wrow0 + rr;
+            if (pr < a.m && c < jb) {
+                const T val = (pr < nt) ? U[pr * TS + c] : st[rr * SS + (lane & 31)];
+                Ap[static_cast<int64_t>(pr) * a.lda + c] = val;
+            }
+        }
+    }
+}
+
+template <typename T>
+constexpr size_t spec3_smem_bytes() {
+    return sizeof(T) * (PW * (PW + 1) + 2 * PW + PW + 4 * 64 * 33) + 64;
+}
+
+}  // namespace ssa

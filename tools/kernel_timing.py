@@ -33,7 +33,7 @@ def timeit(fn, reps=5, warmup=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--K", type=int, default=129)
-    ap.add_argument("--lu", type=int, default=16384)
+    ap.add_argument("--luK", type=int, default=91)
     ap.add_argument("--what", default="fill,q,a,gemm,lu,solve,gemv,bs")
     ap.add_argument("--dtype", default="float64")
     args = ap.parse_args()
@@ -94,23 +94,40 @@ def main():
             del A, B, Cm
 
     if "lu" in what or "solve" in what:
-        for nlu in sorted({2048, 8192, args.lu}):
-            ld = K.padded_ld(nlu, args.dtype)
-            A0 = torch.randn((nlu, ld), dtype=dt, device="cuda")
-            A0 += torch.eye(nlu, ld, dtype=dt, device="cuda") * (2.0 * nlu ** 0.5)
+        from matplotlib.path import Path
+
+        for Klu in sorted({26, 58, args.luK}):
+            # representative matrix: -A of a disk film on the K-ring mesh (diagonally dominant)
+            s2, e2, dr2 = synthetic.ring_disk_mesh(Klu)
+            Kf = synthetic.film_rings(Klu)
+            w2 = orc.vertex_areas(s2, e2)
+            lap = orc.laplace_operator(s2, e2, w2).tocsr()
+            lap.sort_indices()
+            inside = Path(synthetic.circle_points((Kf + 0.5) * dr2), closed=True).contains_points(s2)
+            ix = np.setdiff1d(np.where(inside)[0], orc.find_boundary_indices(e2)).astype(np.int64)
+            nlu = len(ix)
+            put = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            xy2, wd2, C2 = put(s2), put(w2), put(orc.C_vector(s2))
+            _, qd2 = K.q_assemble(xy2, wd2, C2, args.dtype, want_Q=False)
+            lap_d = (put(lap.indptr.astype(np.int64)), put(lap.indices.astype(np.int64)), put(lap.data))
+            Lam = torch.full((len(s2),), 0.1, dtype=torch.float64, device="cuda")
+            ixd = put(ix)
+            asm = lambda: K.system_assemble(xy2, wd2, qd2, Lam, *lap_d, ixd, ixd, sign=-1.0, dtype=args.dtype)
+            med, mn = timeit(asm, reps=3)
+            print(f"system_assemble n_i={nlu}: {med*1e3:.3f} ms -> {nlu*nlu*es/med/1e12:.3f} TB/s")
+            A0 = asm()
             A = A0.clone()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            f = K.lu_factor(A, nlu)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter() - t0
-            A.copy_(A0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            f = K.lu_factor(A, nlu)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter() - t0
-            print(f"lu_factor n={nlu}: first {t1*1e3:.1f} ms, second {t2*1e3:.1f} ms -> {2/3*nlu**3/t2/1e12:.2f} TFLOP/s; info={f.info}")
+            ts = []
+            for _ in range(3):
+                A.copy_(A0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                f = K.lu_factor(A, nlu)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t2 = min(ts)
+            print(f"lu_factor n={nlu}: {[round(t*1e3,1) for t in ts]} ms -> {2/3*nlu**3/t2/1e12:.2f} TFLOP/s; info={f.info}; "
+                  f"pivots off-diagonal: {int((f.ipiv.cpu() != torch.arange(nlu, dtype=torch.int32)).sum())}")
             b = torch.randn(nlu, dtype=dt, device="cuda")
             x = K.lu_solve(f, b)
             r = (A0[:, :nlu] @ x - b).abs().max().item() / b.abs().max().item()
