@@ -7,6 +7,14 @@
 // stages of KC = 16, double-buffered in LDS (global -> registers -> LDS; the loads of stage
 // t+1 are issued before the MFMAs of stage t and written after them, one barrier per stage).
 //
+// Two code paths, chosen per workgroup (uniform branch):
+//   FULL   interior tiles (no bounds checks anywhere; K a multiple of KC; 16-byte aligned
+//          operands): the accumulators are INITIALISED with beta * C in the prologue -- those
+//          loads overlap the first operand stage -- alpha is folded into the A tile as it is
+//          staged, so the epilogue is stores only and the main loop is branch-free
+//          (ds_read / MFMA / global_load only).
+//   EDGE   boundary tiles and odd shapes: every access guarded, MFMAs skipped on padding.
+//
 // LDS images (conflict-free for the 16x16x4 operand maps, lane l: i|j = l & 15, k = l >> 4):
 //   A tile [128][KC + pad]   row-major as in memory (k contiguous); pad chosen so that the 16
 //                            rows read by a half-wave land in distinct 8-byte bank pairs
@@ -65,7 +73,154 @@ struct GemmSmem {
     T b[2][KC * SB];
 };
 
-// One 16-byte global load with bounds handling; returns VEC elements (zero outside).
+__device__ __forceinline__ void remap_tile(int64_t pid, int64_t ntm, int64_t ntn, int64_t &tm,
+                                           int64_t &tn) {
+    // (a) XCD-contiguous, bijective for any grid size.
+    const int64_t nwg = ntm * ntn;
+    const int64_t q = nwg / 8, r = nwg % 8;
+    const int64_t xcd = pid % 8;
+    const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pid / 8;
+    // (b) groups of 8 tile-rows, column-major inside a group.
+    constexpr int64_t G = 8;
+    const int64_t per_group = G * ntn;
+    const int64_t group = wg / per_group;
+    const int64_t first_m = group * G;
+    const int64_t gsize = (ntm - first_m < G) ? ntm - first_m : G;
+    const int64_t in_group = wg % per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+}
+
+// staging shapes (global -> registers -> LDS), 256 threads
+template <typename T>
+struct Stage {
+    static constexpr int VEC = Mfma<T>::VEC;
+    static constexpr int A_VPR = KC / VEC;              // vectors per A row
+    static constexpr int A_RPP = kGemmThreads / A_VPR;  // A rows per pass
+    static constexpr int A_PASS = BM / A_RPP;
+    static constexpr int B_VPR = BN / VEC;              // vectors per B row
+    static constexpr int B_RPP = kGemmThreads / B_VPR;  // B rows per pass
+    static constexpr int B_PASS = KC / B_RPP;
+};
+
+// ---------------------------------------------------------------------------------------
+// FULL path: operands go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR staging, so
+// the 128 accumulator registers + fragments stay far below the 256-VGPR budget of two
+// waves per SIMD -- a register-staged version of this loop spilled its prefetch registers).
+//
+// LDS images of one stage:
+//   A [128][16]  UNPADDED (LDS-DMA writes 1 KiB = 8 rows contiguously per wave-instruction);
+//                bank conflicts of the operand reads are removed by an XOR swizzle of the
+//                k index, kpos = k ^ 2 * ((row >> 1) & 7), applied to the per-lane SOURCE
+//                address (pairs (k, k+1) stay adjacent, so 16-byte granules survive) and to
+//                the read address -- the same involution on both sides.
+//   B [16][144]  one k-row (1 KiB) per wave-instruction, rows padded by 16 doubles so that
+//                lanes 16..31 (k + 1) use the other half of the banks.
+// The accumulators start at (beta / alpha) * C, loaded while the first stage is in flight;
+// the epilogue stores alpha * acc, so no C read sits on the critical tail.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<const __attribute__((address_space(1))) void *>(
+            reinterpret_cast<uintptr_t>(gsrc)),
+        (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T>
+struct FullSmem {  // f64 only (16-byte granule = 2 elements)
+    static constexpr int SB = BN + 16;
+    T a[2][BM * KC];
+    T b[2][KC * SB];
+};
+
+__device__ __forceinline__ void gemm_tile_full_f64(int64_t K, double alpha, const double *__restrict__ A,
+                                                   int64_t lda, const double *__restrict__ B, int64_t ldb,
+                                                   double beta, double *__restrict__ C, int64_t ldc,
+                                                   int64_t m0, int64_t n0, char *smem_raw) {
+    using MF = Mfma<double>;
+    using acc_t = MF::acc_t;
+    FullSmem<double> &sm = *reinterpret_cast<FullSmem<double> *>(smem_raw);
+    constexpr int SB = FullSmem<double>::SB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // LDS-DMA source addresses of this lane.  A: instruction t = wave + 4 u covers rows 8 t .. 8 t + 7;
+    // lane -> row 8 t + lane / 8, LDS slot kpos = 2 (lane % 8), source k = kpos ^ swz(row).
+    const int a_sub = lane >> 3, a_kpos = (lane & 7) * 2;
+    const double *a_src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = 8 * (wave + 4 * u) + a_sub;
+        const int ksrc = a_kpos ^ (2 * ((row >> 1) & 7));
+        a_src[u] = A + (m0 + row) * lda + ksrc;
+    }
+    // B: instruction t = wave + 4 u covers k-row t; lane -> columns 2 lane, 2 lane + 1.
+    const double *b_src = B + n0 + 2 * lane;
+    auto issue_stage = [&](int64_t k0, int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) glds16(a_src[u] + k0, &sm.a[buf][8 * (wave + 4 * u) * KC]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            glds16(b_src + (k0 + wave + 4 * u) * ldb, &sm.b[buf][(wave + 4 * u) * SB]);
+    };
+
+    issue_stage(0, 0);
+    acc_t acc[4][4];
+    double *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
+    if (beta != 0.0) {
+        const double scale = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int swz = 2 * ((li >> 1) & 7);  // rows of this lane are (multiple of 16) + li
+    const int64_t nk = K / KC;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = static_cast<int>(kt & 1);
+        if (kt + 1 < nk) issue_stage((kt + 1) * KC, cur ^ 1);
+        const double *sa = &sm.a[cur][(wm * 64 + li) * KC];
+        const double *sb = &sm.b[cur][lk * SB + wn * 64 + li];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            double fa[4], fb[4];
+            const int kk = (ks * 4 + lk) ^ swz;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = sa[i * 16 * KC + kk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = sb[ks * 4 * SB + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = MF::run(fa[i], fb[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of the next stage has landed
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+}
+
+// ---------------------------------------------------------------------------------------
+// EDGE path: guarded everywhere
+// ---------------------------------------------------------------------------------------
 template <typename T, bool ALIGNED>
 __device__ __forceinline__ void load_row_vec(const T *__restrict__ base, int64_t ld, int64_t row,
                                              int64_t nrows, int64_t col, int64_t ncols,
@@ -84,47 +239,17 @@ __device__ __forceinline__ void load_row_vec(const T *__restrict__ base, int64_t
     }
 }
 
-__device__ __forceinline__ void remap_tile(int64_t pid, int64_t ntm, int64_t ntn, int64_t &tm,
-                                           int64_t &tn) {
-    // (a) XCD-contiguous, bijective for any grid size (hipcc guide, T1).
-    const int64_t nwg = ntm * ntn;
-    const int64_t q = nwg / 8, r = nwg % 8;
-    const int64_t xcd = pid % 8;
-    const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pid / 8;
-    // (b) groups of 8 tile-rows, column-major inside a group.
-    constexpr int64_t G = 8;
-    const int64_t per_group = G * ntn;
-    const int64_t group = wg / per_group;
-    const int64_t first_m = group * G;
-    const int64_t gsize = (ntm - first_m < G) ? ntm - first_m : G;
-    const int64_t in_group = wg % per_group;
-    tm = first_m + in_group % gsize;
-    tn = in_group / gsize;
-}
-
 template <typename T, bool ALIGNED>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
-    int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
-    const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
-    int64_t ntn) {
+__device__ __forceinline__ void gemm_tile_edge(int64_t M, int64_t N, int64_t K, T alpha,
+                                               const T *__restrict__ A, int64_t lda,
+                                               const T *__restrict__ B, int64_t ldb, T beta,
+                                               T *__restrict__ C, int64_t ldc, int64_t m0, int64_t n0,
+                                               GemmSmem<T> &sm) {
     using MF = Mfma<T>;
     using acc_t = typename MF::acc_t;
+    using S = Stage<T>;
     constexpr int VEC = MF::VEC;
     constexpr int SA = GemmSmem<T>::SA, SB = GemmSmem<T>::SB;
-    // global -> register staging shapes
-    constexpr int A_VPR = KC / VEC;                   // vectors per A row
-    constexpr int A_RPP = kGemmThreads / A_VPR;       // A rows per pass
-    constexpr int A_PASS = BM / A_RPP;
-    constexpr int B_VPR = BN / VEC;                   // vectors per B row
-    constexpr int B_RPP = kGemmThreads / B_VPR;       // B rows per pass
-    constexpr int B_PASS = KC / B_RPP;
-
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    GemmSmem<T> &sm = *reinterpret_cast<GemmSmem<T> *>(smem_raw);
-
-    int64_t tm, tn;
-    remap_tile(blockIdx.x, ntm, ntn, tm, tn);
-    const int64_t m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
@@ -134,28 +259,28 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
     const int mt_cnt = mrem <= 0 ? 0 : (mrem >= 64 ? 4 : static_cast<int>((mrem + 15) / 16));
     const int nt_cnt = nrem <= 0 ? 0 : (nrem >= 64 ? 4 : static_cast<int>((nrem + 15) / 16));
 
-    const int a_r = tid / A_VPR, a_c = (tid % A_VPR) * VEC;
-    const int b_r = tid / B_VPR, b_c = (tid % B_VPR) * VEC;
+    const int a_r = tid / S::A_VPR, a_c = (tid % S::A_VPR) * VEC;
+    const int b_r = tid / S::B_VPR, b_c = (tid % S::B_VPR) * VEC;
 
-    T ra[A_PASS][VEC], rb[B_PASS][VEC];
+    T ra[S::A_PASS][VEC], rb[S::B_PASS][VEC];
     auto load_stage = [&](int64_t k0) {
 #pragma unroll
-        for (int p = 0; p < A_PASS; ++p)
-            load_row_vec<T, ALIGNED>(A, lda, m0 + a_r + p * A_RPP, M, k0 + a_c, K, ra[p]);
+        for (int p = 0; p < S::A_PASS; ++p)
+            load_row_vec<T, ALIGNED>(A, lda, m0 + a_r + p * S::A_RPP, M, k0 + a_c, K, ra[p]);
 #pragma unroll
-        for (int p = 0; p < B_PASS; ++p)
-            load_row_vec<T, ALIGNED>(B, ldb, k0 + b_r + p * B_RPP, K, n0 + b_c, N, rb[p]);
+        for (int p = 0; p < S::B_PASS; ++p)
+            load_row_vec<T, ALIGNED>(B, ldb, k0 + b_r + p * S::B_RPP, K, n0 + b_c, N, rb[p]);
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < A_PASS; ++p) {
-            T *dst = &sm.a[buf][(a_r + p * A_RPP) * SA + a_c];
+        for (int p = 0; p < S::A_PASS; ++p) {
+            T *dst = &sm.a[buf][(a_r + p * S::A_RPP) * SA + a_c];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) dst[k] = ra[p][k];
         }
 #pragma unroll
-        for (int p = 0; p < B_PASS; ++p) {
-            T *dst = &sm.b[buf][(b_r + p * B_RPP) * SB + b_c];
+        for (int p = 0; p < S::B_PASS; ++p) {
+            T *dst = &sm.b[buf][(b_r + p * S::B_RPP) * SB + b_c];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) dst[k] = rb[p][k];
         }
@@ -219,7 +344,27 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
     }
 }
 
-// ---- optional instrumentation: HIP events around every gemm_kernel<.., ALIGNED=true> launch ---
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
+    int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
+    const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
+    int64_t ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GemmSmem<T> &sm = *reinterpret_cast<GemmSmem<T> *>(smem_raw);
+    int64_t tm, tn;
+    remap_tile(blockIdx.x, ntm, ntn, tm, tn);
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const bool full = ALIGNED && sizeof(T) == 8 && (m0 + BM <= M) && (n0 + BN <= N) &&
+                      (K % KC == 0) && (K > 0) && alpha != T(0);
+    if (full) {
+        if constexpr (sizeof(T) == 8)
+            gemm_tile_full_f64(K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
+    } else {
+        gemm_tile_edge<T, ALIGNED>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, sm);
+    }
+}
+
+// ---- optional instrumentation: HIP events around every gemm_kernel<double, true> launch ----
 struct GemmProfile {
     bool enabled = false;
     std::vector<hipEvent_t> start, stop;
