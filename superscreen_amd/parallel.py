@@ -1,0 +1,115 @@
+"""Multi-GPU execution of the solver path: one process per GPU, ``torch.distributed`` (backend
+``"nccl"`` = RCCL over xGMI on MI355X nodes; ``"gloo"`` in the CPU tests).
+
+The reference is single-process; this decomposition is new:
+
+* **Applied-field sweeps, circulating-current scans, mutual-inductance columns** are independent
+  solves on one factorized model (``solve`` never mutates it, ``solver/solve.py:391-399``):
+  :func:`shard_range` gives each rank a contiguous slice of the sweep; there is NO collective in
+  the data path (weak scaling).  Every rank factorizes its own replica (about 0.15 s per 20k-film
+  on MI355X, cheaper than shipping 6.6 GB of LU over xGMI).
+
+* **Inter-film Biot-Savart coupling** (``solver/solve.py:499-515``) is a sum over sources, so it is
+  split by SOURCE SLICE: for every ordered (source, target) film pair, rank r evaluates the
+  sources ``shard_range(n_src, r, world)`` with ``ssa_biot_savart(src_begin, src_end)`` into a
+  zero-initialised concatenated field vector; ONE ``all_reduce(SUM)`` per Jacobi iteration
+  (sum_f n_f values, 0.97 MB for the 4 x 30k stack) completes it.  xGMI is point-to-point, so the
+  single fused buffer (one latency-bound ring pass) is preferred over one collective per film.
+  Per-film factor/solve work is replicated on every rank (a film's dense LU does not shard
+  naturally), so the 1 -> N gain is bounded by the coupling share.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced ``[begin, end)`` slice of ``range(n)`` for ``rank``."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"Invalid rank {rank} for world size {world}.")
+    base, extra = divmod(n, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_list(items: Sequence, rank: int, world: int) -> List:
+    b, e = shard_range(len(items), rank, world)
+    return list(items[b:e])
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+class CouplingPlan:
+    """Distributes the inter-film coupling sums of one Jacobi iteration over the ranks of a
+    process group and completes them with a single all-reduce.
+
+    ``pair_kernel(src, tgt, begin, end, out)`` must ADD into ``out`` the field at film ``tgt`` due
+    to sources ``[begin, end)`` of film ``src``.  The default (``None``) is the HIP kernel
+    ``ssa_biot_savart`` on the model's device-resident data; the CPU tests inject the oracle.
+    """
+
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                 pair_kernel: Optional[Callable] = None):
+        dist = _dist()
+        if rank is None or world is None:
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed is not initialised.")
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world, self.group = rank, world, group
+        self.pair_kernel = pair_kernel
+
+    # -- pure bookkeeping (unit-tested without any process group) --------------------------
+    @staticmethod
+    def tasks(films: Sequence[str], sizes: Dict[str, int], rank: int, world: int):
+        """``(src, tgt, begin, end)`` work items of ``rank``: every ordered pair, this rank's
+        source slice (ordering = ``itertools.product(films, repeat=2)``, ``solve.py:499``)."""
+        out = []
+        for src, tgt in itertools.product(films, repeat=2):
+            if src == tgt:
+                continue
+            b, e = shard_range(sizes[src], rank, world)
+            if e > b:
+                out.append((src, tgt, b, e))
+        return out
+
+    # -- execution --------------------------------------------------------------------------
+    def reduce_fields(self, films: Sequence[str], other: Dict[str, "object"]) -> None:
+        """In-place SUM all-reduce of all films' partial fields as ONE flat buffer."""
+        import torch
+
+        if self.world == 1:
+            return
+        flat = torch.cat([other[f].reshape(-1) for f in films])
+        _dist().all_reduce(flat, op=_dist().ReduceOp.SUM, group=self.group)
+        off = 0
+        for f in films:
+            k = other[f].numel()
+            other[f].copy_(flat[off:off + k].view_as(other[f]))
+            off += k
+
+    def accumulate(self, model, results, other_d) -> None:
+        """Called by :func:`superscreen_amd.solver.solve` once per iteration: fills
+        ``other_d[film]`` (zero-initialised) with the complete field from all other films."""
+        films = list(model.device.films)
+        sizes = {f: model.film_data[f].n for f in films}
+        kernel = self.pair_kernel or self._hip_pair_kernel(model, results)
+        for src, tgt, b, e in self.tasks(films, sizes, self.rank, self.world):
+            kernel(src, tgt, b, e, other_d[tgt])
+        self.reduce_fields(films, other_d)
+
+    @staticmethod
+    def _hip_pair_kernel(model, results):
+        from . import kernels
+
+        def run(src, tgt, b, e, out):
+            s, t = model.film_data[src], model.film_data[tgt]
+            dz = model.film_info[tgt].z0 - model.film_info[src].z0
+            kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy, dz, out, accumulate=True,
+                                src_begin=b, src_end=e)
+
+        return run
