@@ -82,6 +82,10 @@ int ssa_q_assemble(const double *xy, const double *w, const double *C, int64_t n
  *   qdiag [n] f64 from ssa_q_assemble;  Lambda [n] f64 (cast to dtype inside, like
  *   solver/utils.py:269);  lap_* CSR of the mesh Laplacian (n x n, f64 values)
  *   sign = -1 writes -A directly, which is what gets LU-factored (solve_film.py:279).
+ *   row_scale [n] f64 or NULL: out[r,c] is additionally multiplied by row_scale[rows[r]]; with
+ *   row_scale = w this is S = diag(w) A, which is symmetric positive definite for a
+ *   homogeneous film (see ssa_chol_factor).  lower_only != 0 (needs rows == cols): only the
+ *   entries on or below the diagonal are guaranteed to be written.
  *   workspace: ssa_system_assemble_workspace_bytes(n, nr, nc)
  */
 size_t ssa_system_assemble_workspace_bytes(int64_t n, int64_t nr, int64_t nc);
@@ -89,8 +93,9 @@ int ssa_system_assemble(const double *xy, const double *w, const double *qdiag,
                         const double *Lambda, int64_t n, const int64_t *lap_indptr,
                         const int64_t *lap_indices, const double *lap_data,
                         const int64_t *rows, int64_t nr, const int64_t *cols, int64_t nc,
-                        double sign, void *out, int64_t ldo, int dtype, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        double sign, const double *row_scale, int lower_only, void *out,
+                        int64_t ldo, int dtype, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* ---------------------------------------------------------------------------------- */
 /* (2) Dense LU factor / solve                                                         */
@@ -128,6 +133,27 @@ size_t ssa_lu_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
 int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *B,
                  int64_t nrhs, int64_t ldb, int dtype, void *workspace,
                  size_t workspace_bytes, void *stream);
+
+/*
+ * Cholesky alternative to the pair above for homogeneous films.  The reference solves
+ *   gf = lu_solve(lu_factor(-A), h)                       solver/solve_film.py:279, :530
+ * with A = Q[ix,ix] w[ix] - Lambda Del2[ix,ix].  S = diag(w[ix]) A is symmetric positive
+ * definite (Q is symmetric off its diagonal, Del2 = diag(1/w) L with L symmetric, and S is
+ * strictly diagonally dominant with a positive diagonal), so  gf = -S^-1 (w[ix] .* h):
+ *   ssa_chol_factor: in-place  S = L L^T  on the lower triangle of S [n,lda] (what
+ *                    ssa_system_assemble(row_scale = w, lower_only = 1, sign = +1) writes);
+ *                    (1/3) n^3 flops, trailing update = MFMA SYRK on the lower tiles only.
+ *                    info [1] int32 (device): 0, or > 0 if a pivot was not positive (then the
+ *                    caller must fall back to ssa_lu_factor on a freshly assembled -A).
+ *                    aux: ssa_chol_aux_bytes(n, dtype) (inverses of the diagonal blocks of L).
+ *   ssa_chol_solve:  L L^T X = B in place, nrhs >= 1; workspace ssa_chol_solve_workspace_bytes.
+ */
+size_t ssa_chol_aux_bytes(int64_t n, int dtype);
+int ssa_chol_factor(void *S, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,
+                    void *stream);
+size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
+int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
+                   int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------- */
 /* (3) Per-film vector kernels of solve_film                                           */
@@ -222,13 +248,26 @@ int ssa_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64
              void *stream);
 
 /*
+ * C = alpha * op(A) * op(B) + beta * C with op = 0 (as stored) or 1 (transposed), row-major;
+ * lower_only != 0 (square C) computes only the 128 x 128 tiles on or below the diagonal -- the
+ * SYRK-shaped trailing update of the Cholesky factorization.
+ */
+int ssa_gemm_ex(int opA, int opB, int lower_only, int64_t M, int64_t N, int64_t K, double alpha,
+                const void *A, int64_t lda, const void *B, int64_t ldb, double beta, void *C,
+                int64_t ldc, int dtype, void *stream);
+
+/*
  * Instrumentation for bench.py: between ssa_profile_begin() and ssa_profile_end() every launch
- * of the f64 MFMA GEMM kernel (gemm_kernel<double, true>: LU trailing updates) is bracketed by
- * HIP events on its own stream.  ssa_profile_end() waits for the recorded events and returns the
- * summed kernel time, the summed algorithmic flops (2 M N K per launch) and the launch count.
+ * of the f64 MFMA GEMM kernels is bracketed by HIP events on its own stream.
+ * ssa_profile_read(kind, ...) waits for the recorded events of one kernel kind and returns the
+ * summed kernel time [ms], the summed algorithmic flops and the launch count:
+ *   kind 0: gemm_kernel<double, true>                 (LU trailing / in-panel updates, 2 M N K)
+ *   kind 1: gemm_op_kernel<double, N, T>, lower_only  (Cholesky trailing SYRK; flops of the
+ *           tiles actually computed: K * M * (M + 128))
  */
 int ssa_profile_begin(void);
-int ssa_profile_end(double *gemm_ms, double *gemm_flops, int64_t *gemm_launches);
+int ssa_profile_read(int kind, double *ms, double *flops, int64_t *launches);
+int ssa_profile_end(void);
 
 /* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern (roofline peak). */
 int ssa_fill_probe(void *dst, size_t bytes, void *stream);

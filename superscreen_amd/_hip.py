@@ -32,8 +32,15 @@ SIGNATURES = {
     "ssa_device_info": (c_int, [P, P, P, c_int]),
     "ssa_q_assemble": (c_int, [P, P, P, I64, P, I64, c_int, P, P]),
     "ssa_system_assemble_workspace_bytes": (c_size_t, [I64, I64, I64]),
-    "ssa_system_assemble": (c_int, [P, P, P, P, I64, P, P, P, P, I64, P, I64, c_double, P, I64,
-                                    c_int, P, c_size_t, P]),
+    "ssa_system_assemble": (c_int, [P, P, P, P, I64, P, P, P, P, I64, P, I64, c_double, P, c_int,
+                                    P, I64, c_int, P, c_size_t, P]),
+    "ssa_chol_aux_bytes": (c_size_t, [I64, c_int]),
+    "ssa_chol_factor": (c_int, [P, I64, I64, P, P, c_int, P]),
+    "ssa_chol_solve_workspace_bytes": (c_size_t, [I64, I64, c_int]),
+    "ssa_chol_solve": (c_int, [P, I64, I64, P, P, I64, I64, c_int, P, c_size_t, P]),
+    "ssa_gemm_ex": (c_int, [c_int, c_int, c_int, I64, I64, I64, c_double, P, I64, P, I64, c_double,
+                            P, I64, c_int, P]),
+    "ssa_profile_read": (c_int, [c_int, P, P, P]),
     "ssa_lu_factor_workspace_bytes": (c_size_t, [I64, c_int]),
     "ssa_lu_aux_bytes": (c_size_t, [I64, c_int]),
     "ssa_lu_factor": (c_int, [P, I64, I64, P, P, P, c_int, P, c_size_t, P]),
@@ -55,7 +62,7 @@ SIGNATURES = {
     "ssa_gemm": (c_int, [I64, I64, I64, c_double, P, I64, P, I64, c_double, P, I64, c_int, P]),
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),
     "ssa_profile_begin": (c_int, []),
-    "ssa_profile_end": (c_int, [P, P, P]),
+    "ssa_profile_end": (c_int, []),
 }
 
 _lib: Optional[ctypes.CDLL] = None

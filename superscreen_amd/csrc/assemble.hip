@@ -128,9 +128,11 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
     const double *__restrict__ col_w, const double *__restrict__ col_lam,
     const int64_t *__restrict__ col_id, int64_t nc, OutT sign, OutT *__restrict__ out,
     int64_t ldo, const int64_t *__restrict__ lap_indptr, const int64_t *__restrict__ lap_indices,
-    const double *__restrict__ lap_data, const int32_t *__restrict__ col_pos) {
+    const double *__restrict__ lap_data, const int32_t *__restrict__ col_pos,
+    const double *__restrict__ row_rs, int lower_only) {
     __shared__ double s_x[TR];
     __shared__ double s_y[TR];
+    __shared__ double s_rs[TR];
     __shared__ double s_qd[TR];
     __shared__ int64_t s_id[TR];
     const int tid = threadIdx.x;
@@ -143,10 +145,13 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
         s_y[tid] = row_y[r];
         s_qd[tid] = row_qd[r];
         s_id[tid] = row_id[r];
+        s_rs[tid] = row_rs ? row_rs[r] : 1.0;
     }
     __syncthreads();
 
-    for (int64_t c = 2 * tid; c < nc; c += 2 * kAsmThreads) {
+    // lower_only (rows == cols): nothing right of the strip's last diagonal entry is needed
+    const int64_t c_end = (lower_only && r0 + TR < nc) ? r0 + TR : nc;
+    for (int64_t c = 2 * tid; c < c_end; c += 2 * kAsmThreads) {
         const bool has1 = (c + 1 < nc);
         const double xj0 = col_x[c], yj0 = col_y[c];
         const double xj1 = has1 ? col_x[c + 1] : 0.0;
@@ -168,8 +173,9 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
             q1 = (i == id1) ? s_qd[r] : q1;
             // Q is cast to the solve dtype before the product (solver/utils.py:291,
             // solve_film.py:305): out = Q[ix,ix] * w[ix]  (column scaling).
-            const OutT v0 = sign * (static_cast<OutT>(q0) * w0);
-            const OutT v1 = has1 ? sign * (static_cast<OutT>(q1) * w1) : OutT(0);
+            const OutT rs = sign * static_cast<OutT>(s_rs[r]);  // optional row scaling (w_i: S = W A)
+            const OutT v0 = rs * (static_cast<OutT>(q0) * w0);
+            const OutT v1 = has1 ? rs * (static_cast<OutT>(q1) * w1) : OutT(0);
             OutT *dst = out + (r0 + r) * ldo + c;
             if (has1 || c + 1 < ldo) {
                 store_pair<OutT>(dst, v0, v1);
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
             if (c >= 0) {
                 OutT *dst = out + (r0 + r) * ldo + c;
                 const OutT t = static_cast<OutT>(col_lam[c]) * static_cast<OutT>(lap_data[p]);
-                *dst = *dst - sign * t;
+                if (!lower_only || c <= r0 + r) *dst = *dst - sign * static_cast<OutT>(s_rs[r]) * t;
             }
         }
     }
@@ -219,7 +225,7 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
 
 extern "C" size_t ssa_system_assemble_workspace_bytes(int64_t n, int64_t nr, int64_t nc) {
     size_t b = 0;
-    b += 4 * align_up(static_cast<size_t>(nr) * 8, 256);  // row x, y, qd, id
+    b += 5 * align_up(static_cast<size_t>(nr) * 8, 256);  // row x, y, qd, id, scale
     b += 5 * align_up(static_cast<size_t>(nc) * 8, 256);  // col x, y, w, lam, id
     b += align_up(static_cast<size_t>(n) * 4, 256);       // col_pos
     return b + 256;
@@ -229,13 +235,15 @@ extern "C" int ssa_system_assemble(const double *xy, const double *w, const doub
                                    const double *Lambda, int64_t n, const int64_t *lap_indptr,
                                    const int64_t *lap_indices, const double *lap_data,
                                    const int64_t *rows, int64_t nr, const int64_t *cols,
-                                   int64_t nc, double sign, void *out, int64_t ldo, int dtype,
+                                   int64_t nc, double sign, const double *row_scale,
+                                   int lower_only, void *out, int64_t ldo, int dtype,
                                    void *workspace, size_t workspace_bytes, void *stream) {
     if (n <= 0 || nr <= 0 || nc <= 0 || !xy || !w || !qdiag || !Lambda || !out || !cols ||
         !lap_indptr || !lap_indices || !lap_data)
         return SSA_ERR_INVALID_ARGUMENT;
     if (ldo < nc) return SSA_ERR_INVALID_ARGUMENT;
     if ((ldo & 1) && nc > 1) return SSA_ERR_INVALID_ARGUMENT;
+    if (lower_only && nr != nc) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     if (!workspace || workspace_bytes < ssa_system_assemble_workspace_bytes(n, nr, nc))
         return SSA_ERR_WORKSPACE_TOO_SMALL;
@@ -244,6 +252,7 @@ extern "C" int ssa_system_assemble(const double *xy, const double *w, const doub
     double *row_x = cv.take<double>(nr), *row_y = cv.take<double>(nr);
     double *row_qd = cv.take<double>(nr);
     int64_t *row_id = cv.take<int64_t>(nr);
+    double *row_rs = cv.take<double>(nr);
     double *col_x = cv.take<double>(nc), *col_y = cv.take<double>(nc);
     double *col_w = cv.take<double>(nc), *col_lam = cv.take<double>(nc);
     int64_t *col_id = cv.take<int64_t>(nc);
@@ -252,21 +261,22 @@ extern "C" int ssa_system_assemble(const double *xy, const double *w, const doub
         return SSA_ERR_HIP;
     const int tb = 256;
     hipLaunchKernelGGL(gather_vertex_kernel, dim3(ceil_div(nr, tb)), dim3(tb), 0, st, xy, qdiag,
-                       (const double *)nullptr, rows, nr, row_x, row_y, row_qd,
-                       (double *)nullptr, row_id, (int32_t *)nullptr);
+                       row_scale, rows, nr, row_x, row_y, row_qd,
+                       row_scale ? row_rs : (double *)nullptr, row_id, (int32_t *)nullptr);
     hipLaunchKernelGGL(gather_vertex_kernel, dim3(ceil_div(nc, tb)), dim3(tb), 0, st, xy, w,
                        Lambda, cols, nc, col_x, col_y, col_w, col_lam, col_id, col_pos);
+    const double *rs = row_scale ? row_rs : nullptr;
     const dim3 grid(static_cast<unsigned>(ceil_div(nr, kStripRows)));
     if (dtype == SSA_F64) {
         hipLaunchKernelGGL((system_assemble_kernel<double, kStripRows>), grid, dim3(kAsmThreads),
                            0, st, row_x, row_y, row_qd, row_id, nr, col_x, col_y, col_w, col_lam,
                            col_id, nc, sign, static_cast<double *>(out), ldo, lap_indptr,
-                           lap_indices, lap_data, col_pos);
+                           lap_indices, lap_data, col_pos, rs, lower_only);
     } else {
         hipLaunchKernelGGL((system_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads),
                            0, st, row_x, row_y, row_qd, row_id, nr, col_x, col_y, col_w, col_lam,
                            col_id, nc, static_cast<float>(sign), static_cast<float *>(out), ldo,
-                           lap_indptr, lap_indices, lap_data, col_pos);
+                           lap_indptr, lap_indices, lap_data, col_pos, rs, lower_only);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;

@@ -1,0 +1,394 @@
+// Dense Cholesky factor / solve for gfx950 (lower triangular, row-major, in place).
+//
+// Why it exists: for a homogeneous film the system the reference LU-factors,
+//     A = Q[ix,ix] * w[ix] - Lambda * Del2[ix,ix]          (solver/solve_film.py:296-305),
+// becomes SYMMETRIC after scaling its rows by the vertex areas:  S = diag(w) A, because
+// Q is symmetric off the diagonal and Del2 = diag(1/w) L with L symmetric (fem.py:259-296).
+// S has a positive diagonal and is strictly diagonally dominant, hence positive definite, so
+//     gf = lu_solve(lu_factor(-A), h)   ==   - S^-1 (w .* h)
+// can be computed with a Cholesky factorization S = L L^T: (1/3) n^3 flops instead of (2/3) n^3,
+// no pivoting, no row interchanges, no triangular solve between panel and trailing update, and
+// the trailing update is a SYRK on the lower triangle only (half the tiles, gemm_ops.hip).
+// A non-positive pivot is reported through `info` (LAPACK ?potrf convention) and the host
+// falls back to the LU path (lu.hip).
+//
+// Blocking mirrors lu.hip: 256-column outer panels whose trailing update is one MFMA SYRK with
+// K = 256, 64-column sub-panels factored by a register-resident, fully unrolled kernel
+// (diagonal block per workgroup in registers, the rows below forward-substituted one row per
+// thread), in-panel updates by the NT GEMM.
+#include <utility>
+
+#include "common.hpp"
+
+namespace ssa {
+
+int gemm_op_f64(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double alpha,
+                const double *A, int64_t lda, const double *B, int64_t ldb, double beta, double *C,
+                int64_t ldc, hipStream_t st);
+int gemm_op_f32(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double alpha,
+                const float *A, int64_t lda, const float *B, int64_t ldb, double beta, float *C,
+                int64_t ldc, hipStream_t st);
+int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+             const double *B, int64_t ldb, double beta, double *C, int64_t ldc, hipStream_t st);
+int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+             const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st);
+int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
+             double alpha, double beta, hipStream_t st);
+int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
+             double alpha, double beta, hipStream_t st);
+int trtri_lower_blocks_f64(const double *A, int64_t lda, int64_t n, double *inv, hipStream_t st);
+int trtri_lower_blocks_f32(const float *A, int64_t lda, int64_t n, float *inv, hipStream_t st);
+
+namespace {
+
+constexpr int CNB = 256;  // outer panel
+constexpr int CPW = 64;   // sub-panel
+constexpr int kCholRows = 256;
+
+inline int gemm_op_t(int oa, int ob, int lower, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
+                     int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
+                     hipStream_t st) {
+    return gemm_op_f64(oa, ob, lower, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+inline int gemm_op_t(int oa, int ob, int lower, int64_t M, int64_t N, int64_t K, double alpha, const float *A,
+                     int64_t lda, const float *B, int64_t ldb, double beta, float *C, int64_t ldc,
+                     hipStream_t st) {
+    return gemm_op_f32(oa, ob, lower, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+inline int gemm_nn_t(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     const double *B, int64_t ldb, double beta, double *C, int64_t ldc, hipStream_t st) {
+    return gemm_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+inline int gemm_nn_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                     const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st) {
+    return gemm_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+inline int gemv_n_t(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
+                    double alpha, double beta, hipStream_t st) {
+    return gemv_f64(M, nr, nc, ldm, x, y, alpha, beta, st);
+}
+inline int gemv_n_t(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
+                    double alpha, double beta, hipStream_t st) {
+    return gemv_f32(M, nr, nc, ldm, x, y, alpha, beta, st);
+}
+inline int trtri_t(const double *A, int64_t lda, int64_t n, double *inv, hipStream_t st) {
+    return trtri_lower_blocks_f64(A, lda, n, inv, st);
+}
+inline int trtri_t(const float *A, int64_t lda, int64_t n, float *inv, hipStream_t st) {
+    return trtri_lower_blocks_f32(A, lda, n, inv, st);
+}
+
+__device__ __forceinline__ double rsqrt_t(double x) { return rsqrt_f64(x); }
+__device__ __forceinline__ float rsqrt_t(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    return y * (1.5f - 0.5f * x * y * y);
+}
+
+template <int S>
+__device__ __forceinline__ int cquad_i32(int x) {
+    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
+    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
+}
+
+// One column of the register-tiled 64 x 64 Cholesky: thread (r, q) holds a[r][q + 4 i].
+template <typename T, int J>
+__device__ __forceinline__ void chol_step(T (&v)[16], int r, int q, T *colbuf, bool &bad) {
+    constexpr int I0 = J >> 2, S = J & 3;
+    T *cb = colbuf + (J & 1) * CPW;
+    if (q == S) cb[r] = v[I0];  // unscaled column J (rows above J publish stale values, never read)
+    __syncthreads();
+    const T d = cb[J];
+    bad = bad || !(d > T(0));
+    const T inv = rsqrt_t(d);
+    const T lr = (r >= J) ? cb[r] * inv : T(0);  // l_rJ (= sqrt(d) for r == J)
+    {   // register column I0: c = q + 4 I0;  c == J <=> q == S,  c > J <=> q > S
+        const int c = q + 4 * I0;
+        const T upd = v[I0] - lr * (cb[c] * inv);
+        v[I0] = (q == S) ? ((r >= J) ? lr : v[I0]) : ((q > S && c <= r) ? upd : v[I0]);
+    }
+#pragma unroll
+    for (int i = I0 + 1; i < 16; ++i) {
+        const int c = q + 4 * i;
+        const T upd = v[i] - lr * (cb[c] * inv);
+        v[i] = (c <= r) ? upd : v[i];
+    }
+}
+template <typename T, int... Js>
+__device__ __forceinline__ void chol_all(T (&v)[16], int r, int q, int nsteps, T *colbuf, bool &bad,
+                                         std::integer_sequence<int, Js...>) {
+    ((Js < nsteps ? chol_step<T, Js>(v, r, q, colbuf, bad) : (void)0), ...);
+}
+
+// row x (in registers) <- row x * inv(L11^T):  x_J = (a_J - sum_{k<J} x_k L11[J][k]) / L11[J][J],
+// right-looking; Ut[J][c] = L11[c][J] is read as an LDS broadcast.
+template <typename T, int J>
+__device__ __forceinline__ void chol_fwd_step(T (&a)[CPW], const T *Ut, const T *rdiag) {
+    constexpr int TS = CPW + 1;
+    const T l = a[J] * rdiag[J];
+    a[J] = l;
+#pragma unroll
+    for (int c = J + 1; c < CPW; ++c) a[c] -= l * Ut[J * TS + c];
+}
+template <typename T, int... Js>
+__device__ __forceinline__ void chol_fwd_all(T (&a)[CPW], const T *Ut, const T *rdiag, int jb,
+                                             std::integer_sequence<int, Js...>) {
+    ((Js < jb ? chol_fwd_step<T, Js>(a, Ut, rdiag) : (void)0), ...);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int64_t j0, int m, int jb,
+                                                         int32_t *info) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TS = CPW + 1, SS = 32 + 1;
+    T *Ut = reinterpret_cast<T *>(smem_raw);       // [64][TS]: first the block itself, then L11^T
+    T *colbuf = Ut + CPW * TS;                      // [2][64]
+    T *rdiag = colbuf + 2 * CPW;                    // [64]
+    T *stage = rdiag + CPW;                         // [4 waves][64][SS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
+    const int row_base = g * kCholRows;
+    const int nt = min(CPW, m);
+    T *Ap = A + j0 * lda + j0;
+
+    for (int rr = wave; rr < CPW; rr += 4)
+        Ut[rr * TS + lane] = (rr < nt && lane < jb) ? Ap[static_cast<int64_t>(rr) * lda + lane] : T(0);
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;
+    T v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = Ut[r * TS + q + 4 * i];
+    // rows beyond the block (last, partial sub-panel) get a unit diagonal so that the padding
+    // stays positive definite
+    if (r >= nt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (q + 4 * i == r) ? T(1) : T(0);
+    }
+    bool bad = false;
+    chol_all<T>(v, r, q, min(jb, nt), colbuf, bad, std::make_integer_sequence<int, CPW>{});
+    __syncthreads();
+    // Ut[J][c] = L11[c][J] (c >= J), zero elsewhere; reciprocals of the diagonal
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = q + 4 * i;
+        if (c <= r) Ut[c * TS + r] = v[i];
+    }
+    __syncthreads();
+    if (tid < CPW) {
+        const T d = Ut[tid * TS + tid];
+        rdiag[tid] = (d != T(0)) ? T(1) / d : T(1);
+    }
+    if (g == 0) {
+        if (bad && tid == 0 && *info == 0) *info = static_cast<int32_t>(j0 + 1);
+        // L11 (lower triangle) back to A
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = q + 4 * i;
+            if (r < nt && c <= r && c < jb) Ap[static_cast<int64_t>(r) * lda + c] = v[i];
+        }
+    }
+    __syncthreads();
+
+    // rows below the block: HBM -> (LDS transpose) -> registers -> substitute -> back
+    T *st = stage + wave * 64 * SS;
+    const int wrow0 = row_base + wave * 64;
+    T arow[CPW];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
+            const int pr = wrow0 + rr;
+            T val = T(0);
+            if (pr < m && pr >= nt && c < jb) val = Ap[static_cast<int64_t>(pr) * lda + c];
+            st[rr * SS + (lane & 31)] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) arow[32 * h + i] = st[lane * SS + i];
+    }
+    chol_fwd_all<T>(arow, Ut, rdiag, jb, std::make_integer_sequence<int, CPW>{});
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) st[lane * SS + i] = arow[32 * h + i];
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
+            const int pr = wrow0 + rr;
+            if (pr < m && pr >= nt && c < jb) Ap[static_cast<int64_t>(pr) * lda + c] = st[rr * SS + (lane & 31)];
+        }
+    }
+}
+
+template <typename T>
+constexpr size_t chol_panel_smem() {
+    return sizeof(T) * (CPW * (CPW + 1) + 2 * CPW + CPW + 4 * 64 * 33) + 64;
+}
+
+// y[c] = alpha * sum_r M[r][c] x[r] + beta * y[c]  (M is nr x nc row-major): the transposed GEMV of
+// the backward substitution with L^T.  Workgroup = 128 columns; each wave sums a quarter of the
+// rows with 16-byte loads (lane <-> 2 columns, no cross-lane reduction), the four partial sums
+// meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_t_kernel(const T *__restrict__ M, int64_t nr, int64_t nc,
+                                                     int64_t ldm, const T *__restrict__ x,
+                                                     T *__restrict__ y, T alpha, T beta) {
+    __shared__ T part[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 128 + 2 * lane;
+    T s0 = T(0), s1 = T(0);
+    const int64_t rows_per = (nr + 3) / 4;
+    const int64_t r_begin = wave * rows_per, r_end = (r_begin + rows_per < nr) ? r_begin + rows_per : nr;
+    if (c0 + 1 < nc) {
+#pragma unroll 8
+        for (int64_t r = r_begin; r < r_end; ++r) {
+            const T xv = x[r];
+            const T *p = M + r * ldm + c0;
+            s0 += p[0] * xv;
+            s1 += p[1] * xv;
+        }
+    } else if (c0 < nc) {
+        for (int64_t r = r_begin; r < r_end; ++r) s0 += M[r * ldm + c0] * x[r];
+    }
+    part[wave][2 * lane] = s0;
+    part[wave][2 * lane + 1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int64_t c = static_cast<int64_t>(blockIdx.x) * 128 + threadIdx.x;
+        if (c < nc) {
+            const T s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+            T out = alpha * s;
+            if (beta != T(0)) out += beta * y[c];
+            y[c] = out;
+        }
+    }
+}
+
+template <typename T>
+int gemv_trans(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha, double beta,
+               hipStream_t st) {
+    if (nr <= 0 || nc <= 0) return SSA_OK;
+    hipLaunchKernelGGL((gemv_t_kernel<T>), dim3(static_cast<unsigned>(ceil_div(nc, 128))), dim3(256), 0, st, M,
+                       nr, nc, ldm, x, y, static_cast<T>(alpha), static_cast<T>(beta));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+template <typename T>
+int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_panel_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(chol_panel_smem<T>())) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
+    int rc;
+    for (int64_t k0 = 0; k0 < n; k0 += CNB) {
+        const int64_t kb = (n - k0 < CNB) ? n - k0 : CNB;
+        for (int64_t j0 = k0; j0 < k0 + kb; j0 += CPW) {
+            const int64_t jb = (k0 + kb - j0 < CPW) ? k0 + kb - j0 : CPW;
+            const int64_t m = n - j0;
+            hipLaunchKernelGGL((chol_panel_kernel<T>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
+                               dim3(256), chol_panel_smem<T>(), st, A, lda, j0, static_cast<int>(m),
+                               static_cast<int>(jb), info);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+            const int64_t rest = (k0 + kb) - (j0 + jb);
+            const int64_t mm = n - (j0 + jb);
+            if (rest > 0 && mm > 0) {
+                const T *P = A + (j0 + jb) * lda + j0;  // rows below the sub-panel, its 64 columns
+                rc = gemm_op_t(0, 1, 0, mm, rest, jb, -1.0, P, lda, P, lda, 1.0,
+                               A + (j0 + jb) * lda + (j0 + jb), lda, st);
+                if (rc != SSA_OK) return rc;
+            }
+        }
+        const int64_t right = n - k0 - kb;
+        if (right > 0) {
+            const T *P = A + (k0 + kb) * lda + k0;
+            rc = gemm_op_t(0, 1, 1, right, right, kb, -1.0, P, lda, P, lda, 1.0,
+                           A + (k0 + kb) * lda + (k0 + kb), lda, st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    return trtri_t(A, lda, n, aux, st);  // inverses of the 256 x 256 diagonal blocks of L
+}
+
+// L L^T X = B.  Single right-hand side: GEMV / transposed-GEMV chain over 256-row blocks;
+// several: the same recurrence on the MFMA GEMMs (NN forward, TN backward).
+template <typename T>
+int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb, T *X,
+          hipStream_t st) {
+    const int64_t nblk = ceil_div(n, CNB);
+    const int64_t ldx = nrhs;
+    int rc;
+    for (int64_t k = 0; k < nblk; ++k) {  // forward: L y = b
+        const int64_t r0 = k * CNB, kb = (n - r0 < CNB) ? n - r0 : CNB;
+        const int64_t below = n - r0 - kb;
+        const T *inv = aux + k * CNB * CNB;
+        if (nrhs == 1 && ldb == 1) {
+            rc = gemv_n_t(inv, kb, kb, CNB, B + r0, X + r0, 1.0, 0.0, st);
+            if (rc == SSA_OK && below > 0)
+                rc = gemv_n_t(L + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
+        } else {
+            rc = gemm_nn_t(kb, nrhs, kb, 1.0, inv, CNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, st);
+            if (rc == SSA_OK && below > 0)
+                rc = gemm_nn_t(below, nrhs, kb, -1.0, L + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx, 1.0,
+                               B + (r0 + kb) * ldb, ldb, st);
+        }
+        if (rc != SSA_OK) return rc;
+    }
+    for (int64_t k = nblk - 1; k >= 0; --k) {  // backward: L^T x = y   (y lives in X, x goes to B)
+        const int64_t r0 = k * CNB, kb = (n - r0 < CNB) ? n - r0 : CNB;
+        const T *inv = aux + k * CNB * CNB;
+        if (nrhs == 1 && ldb == 1) {
+            rc = gemv_trans(inv, kb, kb, CNB, X + r0, B + r0, 1.0, 0.0, st);
+            if (rc == SSA_OK && r0 > 0)
+                rc = gemv_trans(L + r0 * lda, kb, r0, lda, B + r0, X, -1.0, 1.0, st);
+        } else {
+            rc = gemm_op_t(1, 0, 0, kb, nrhs, kb, 1.0, inv, CNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
+            if (rc == SSA_OK && r0 > 0)
+                rc = gemm_op_t(1, 0, 0, r0, nrhs, kb, -1.0, L + r0 * lda, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
+        }
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
+}  // namespace
+}  // namespace ssa
+
+using namespace ssa;
+
+extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
+    return static_cast<size_t>(ceil_div(n, CNB)) * CNB * CNB * (dtype == SSA_F64 ? 8 : 4);
+}
+
+extern "C" int ssa_chol_factor(void *A, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,
+                               void *stream) {
+    if (!A || !info || !aux || n <= 0 || lda < n) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype == SSA_F64)
+        return potrf<double>(static_cast<double *>(A), n, lda, info, static_cast<double *>(aux), as_stream(stream));
+    if (dtype == SSA_F32)
+        return potrf<float>(static_cast<float *>(A), n, lda, info, static_cast<float *>(aux), as_stream(stream));
+    return SSA_ERR_INVALID_ARGUMENT;
+}
+
+extern "C" size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype) {
+    return static_cast<size_t>(n) * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) + 256;
+}
+
+extern "C" int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B,
+                              int64_t nrhs, int64_t ldb, int dtype, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!L || !aux || !B || n <= 0 || nrhs <= 0 || lda < n || ldb < nrhs) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_chol_solve_workspace_bytes(n, nrhs, dtype))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    if (dtype == SSA_F64)
+        return potrs<double>(static_cast<const double *>(L), n, lda, static_cast<const double *>(aux),
+                             static_cast<double *>(B), nrhs, ldb, static_cast<double *>(workspace),
+                             as_stream(stream));
+    return potrs<float>(static_cast<const float *>(L), n, lda, static_cast<const float *>(aux),
+                        static_cast<float *>(B), nrhs, ldb, static_cast<float *>(workspace), as_stream(stream));
+}

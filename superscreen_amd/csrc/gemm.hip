@@ -26,44 +26,10 @@
 // sharing 8 A-panels and 8 B-panels (about 4 MiB at K = 256 in f64: one L2).
 #include <vector>
 
-#include "common.hpp"
+#include "gemm_profile.hpp"
+#include "mfma_traits.hpp"
 
 namespace ssa {
-
-constexpr int kGemmThreads = 256;
-constexpr int BM = 128, BN = 128, KC = 16;
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T>
-struct Mfma;
-template <>
-struct Mfma<double> {
-    using acc_t = f64x4;
-    using vec_t = double2;
-    static constexpr int VEC = 2;
-    static constexpr int APAD = 2;
-    static constexpr int BPAD = 16;
-    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
-        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-};
-template <>
-struct Mfma<float> {
-    using acc_t = f32x4;
-    using vec_t = float4;
-    static constexpr int VEC = 4;
-    static constexpr int APAD = 4;
-    static constexpr int BPAD = 16;
-    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
-    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-};
 
 template <typename T>
 struct GemmSmem {
@@ -119,13 +85,6 @@ struct Stage {
 // The accumulators start at (beta / alpha) * C, loaded while the first stage is in flight;
 // the epilogue stores alpha * acc, so no C read sits on the critical tail.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(
-        reinterpret_cast<const __attribute__((address_space(1))) void *>(
-            reinterpret_cast<uintptr_t>(gsrc)),
-        (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
 template <typename T>
 struct FullSmem {  // f64 only (16-byte granule = 2 elements)
     static constexpr int SB = BN + 16;
@@ -364,39 +323,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
     }
 }
 
-// ---- optional instrumentation: HIP events around every gemm_kernel<double, true> launch ----
-struct GemmProfile {
-    bool enabled = false;
-    std::vector<hipEvent_t> start, stop;
-    std::vector<double> flops;
-    size_t used = 0;
-};
-static GemmProfile g_prof;
-
-struct ProfileScope {
-    bool active;
-    hipStream_t st;
-    ProfileScope(bool aligned, double flops, hipStream_t s) : active(false), st(s) {
-        if (!g_prof.enabled || !aligned) return;
-        if (g_prof.used == g_prof.start.size()) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            g_prof.start.push_back(a);
-            g_prof.stop.push_back(b);
-            g_prof.flops.push_back(0.0);
-        }
-        g_prof.flops[g_prof.used] = flops;
-        (void)hipEventRecord(g_prof.start[g_prof.used], st);
-        active = true;
-    }
-    ~ProfileScope() {
-        if (active) {
-            (void)hipEventRecord(g_prof.stop[g_prof.used], st);
-            ++g_prof.used;
-        }
-    }
-};
-
 template <typename T>
 int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64_t lda,
                 const void *B, int64_t ldb, double beta, void *C, int64_t ldc, hipStream_t st) {
@@ -418,7 +344,7 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, in
             return SSA_ERR_HIP;
         attr_set = true;
     }
-    ProfileScope scope(aligned && sizeof(T) == 8, 2.0 * M * N * K, st);
+    ProfileScope scope(aligned && sizeof(T) == 8, kProfileGemmNN, 2.0 * M * N * K, st);
     if (aligned) {
         hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(kGemmThreads), smem, st, M, N, K,
                            static_cast<T>(alpha), static_cast<const T *>(A), lda,
@@ -454,20 +380,28 @@ extern "C" int ssa_profile_begin(void) {
     return SSA_OK;
 }
 
-extern "C" int ssa_profile_end(double *gemm_ms, double *gemm_flops, int64_t *gemm_launches) {
-    g_prof.enabled = false;
+extern "C" int ssa_profile_read(int kind, double *ms_out, double *flops_out, int64_t *launches_out) {
+    if (kind < 0 || kind >= kProfileKinds) return SSA_ERR_INVALID_ARGUMENT;
     double ms = 0.0, fl = 0.0;
+    int64_t cnt = 0;
     for (size_t i = 0; i < g_prof.used; ++i) {
+        if (g_prof.kind[i] != kind) continue;
         float t = 0.f;
         if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess ||
             hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]) != hipSuccess)
             return SSA_ERR_HIP;
         ms += t;
         fl += g_prof.flops[i];
+        ++cnt;
     }
-    if (gemm_ms) *gemm_ms = ms;
-    if (gemm_flops) *gemm_flops = fl;
-    if (gemm_launches) *gemm_launches = static_cast<int64_t>(g_prof.used);
+    if (ms_out) *ms_out = ms;
+    if (flops_out) *flops_out = fl;
+    if (launches_out) *launches_out = cnt;
+    return SSA_OK;
+}
+
+extern "C" int ssa_profile_end(void) {
+    g_prof.enabled = false;
     g_prof.used = 0;
     return SSA_OK;
 }

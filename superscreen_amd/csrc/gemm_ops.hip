@@ -1,0 +1,334 @@
+// C = alpha * op(A) * op(B) + beta * C with op in {N, T}, optionally restricted to the tiles on or
+// below the diagonal of a square C ("lower": the SYRK-shaped trailing update of the Cholesky
+// factorization, C -= L21 * L21^T, and nothing above the diagonal is touched or needed).
+//
+// Same tiling and LDS-DMA pipeline as gemm.hip (128 x 128 tile, 4 waves x (4 x 4) MFMA tiles of
+// v_mfma_f64_16x16x4_f64, KC = 16 stages, accumulators initialised from C).  An operand slab
+// (128 rows of m or n  x  16 k) is staged in one of two LDS images, depending on which index is
+// contiguous in memory:
+//   K-MAJOR  (k contiguous: A for op N, B for op T)   [128][16]  unpadded, XOR-swizzled k
+//   K-MINOR  (m|n contiguous: A for op T, B for op N) [16][128 + 16]
+// so NT (SYRK: both operands are row panels of the same matrix) uses two K-MAJOR images and TN
+// (backward substitution with L^T on many right-hand sides) two K-MINOR images.
+#include "gemm_profile.hpp"
+#include "mfma_traits.hpp"
+
+namespace ssa {
+
+enum : int { OP_N = 0, OP_T = 1 };
+
+constexpr int KMINOR_STRIDE = BN + 16;
+constexpr int IMG_ELEMS = KC * KMINOR_STRIDE;  // the larger of the two images
+
+struct OpSmemF64 {
+    double a[2][IMG_ELEMS];
+    double b[2][IMG_ELEMS];
+};
+
+// ---- FULL path (f64, interior tiles) -------------------------------------------------------
+// kmajor: element (r, k) lives at X[(x0 + r) * ld + k]; else at X[k * ld + x0 + r].
+template <bool KMAJOR>
+struct OperandF64 {
+    const double *src[4];
+    int64_t ld;
+    __device__ __forceinline__ void init(const double *X, int64_t ldx, int64_t x0, int lane, int wave) {
+        ld = ldx;
+        if (KMAJOR) {
+            const int sub = lane >> 3, kpos = (lane & 7) * 2;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = 8 * (wave + 4 * u) + sub;
+                src[u] = X + (x0 + row) * ldx + (kpos ^ (2 * ((row >> 1) & 7)));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) src[u] = X + static_cast<int64_t>(wave + 4 * u) * ldx + x0 + 2 * lane;
+        }
+    }
+    __device__ __forceinline__ void issue(int64_t k0, double *img, int wave) const {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (KMAJOR) glds16(src[u] + k0, img + 8 * (wave + 4 * u) * KC);
+            else glds16(src[u] + k0 * ld, img + (wave + 4 * u) * KMINOR_STRIDE);
+        }
+    }
+    // fragment of sub-tile t (16 rows) of the wave's 64-row half `w`, k-step ks
+    static __device__ __forceinline__ double frag(const double *img, int w, int t, int ks, int li, int lk,
+                                                  int swz) {
+        if (KMAJOR) return img[(w * 64 + t * 16 + li) * KC + ((ks * 4 + lk) ^ swz)];
+        return img[(ks * 4 + lk) * KMINOR_STRIDE + w * 64 + t * 16 + li];
+    }
+};
+
+template <int TA, int TB>
+__device__ __forceinline__ void tile_full_f64(int64_t K, double alpha, const double *__restrict__ A,
+                                              int64_t lda, const double *__restrict__ B, int64_t ldb,
+                                              double beta, double *__restrict__ C, int64_t ldc,
+                                              int64_t m0, int64_t n0, char *smem_raw) {
+    using MF = Mfma<double>;
+    using acc_t = MF::acc_t;
+    constexpr bool A_KMAJOR = (TA == OP_N), B_KMAJOR = (TB == OP_T);
+    OpSmemF64 &sm = *reinterpret_cast<OpSmemF64 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int swz = 2 * ((li >> 1) & 7);
+
+    OperandF64<A_KMAJOR> opa;
+    OperandF64<B_KMAJOR> opb;
+    opa.init(A, lda, m0, lane, wave);
+    opb.init(B, ldb, n0, lane, wave);
+    opa.issue(0, sm.a[0], wave);
+    opb.issue(0, sm.b[0], wave);
+
+    acc_t acc[4][4];
+    double *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
+    if (beta != 0.0) {
+        const double scale = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int64_t nk = K / KC;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = static_cast<int>(kt & 1);
+        if (kt + 1 < nk) {
+            opa.issue((kt + 1) * KC, sm.a[cur ^ 1], wave);
+            opb.issue((kt + 1) * KC, sm.b[cur ^ 1], wave);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            double fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = OperandF64<A_KMAJOR>::frag(sm.a[cur], wm, i, ks, li, lk, swz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = OperandF64<B_KMAJOR>::frag(sm.b[cur], wn, j, ks, li, lk, swz);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = MF::run(fa[i], fb[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+}
+
+// ---- EDGE path: any type, any shape, guarded element-wise staging --------------------------
+template <typename T>
+struct EdgeSmem {
+    static constexpr int SA = KC + Mfma<T>::APAD;
+    static constexpr int SB = BN + Mfma<T>::BPAD;
+    T a[BM * SA];
+    T b[KC * SB];
+};
+
+template <typename T, int TA, int TB>
+__device__ __forceinline__ void tile_edge(int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A,
+                                          int64_t lda, const T *__restrict__ B, int64_t ldb, T beta,
+                                          T *__restrict__ C, int64_t ldc, int64_t m0, int64_t n0,
+                                          char *smem_raw) {
+    using MF = Mfma<T>;
+    using acc_t = typename MF::acc_t;
+    EdgeSmem<T> &sm = *reinterpret_cast<EdgeSmem<T> *>(smem_raw);
+    constexpr int SA = EdgeSmem<T>::SA, SB = EdgeSmem<T>::SB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t mrem = M - (m0 + wm * 64), nrem = N - (n0 + wn * 64);
+    const int mt_cnt = mrem <= 0 ? 0 : (mrem >= 64 ? 4 : static_cast<int>((mrem + 15) / 16));
+    const int nt_cnt = nrem <= 0 ? 0 : (nrem >= 64 ? 4 : static_cast<int>((nrem + 15) / 16));
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+    for (int64_t k0 = 0; k0 < K; k0 += KC) {
+        __syncthreads();
+        for (int e = tid; e < BM * KC; e += kGemmThreads) {
+            int r, k;
+            if (TA == OP_N) { r = e / KC; k = e % KC; } else { k = e / BM; r = e % BM; }
+            const int64_t gr = m0 + r, gk = k0 + k;
+            T v = T(0);
+            if (gr < M && gk < K) v = (TA == OP_N) ? A[gr * lda + gk] : A[gk * lda + gr];
+            sm.a[r * SA + k] = v;
+        }
+        for (int e = tid; e < KC * BN; e += kGemmThreads) {
+            int c, k;
+            if (TB == OP_N) { k = e / BN; c = e % BN; } else { c = e / KC; k = e % KC; }
+            const int64_t gc = n0 + c, gk = k0 + k;
+            T v = T(0);
+            if (gc < N && gk < K) v = (TB == OP_N) ? B[gk * ldb + gc] : B[gc * ldb + gk];
+            sm.b[k * SB + c] = v;
+        }
+        __syncthreads();
+        const T *sa = &sm.a[(wm * 64 + li) * SA + lk];
+        const T *sb = &sm.b[lk * SB + wn * 64 + li];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            T fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = sa[i * 16 * SA + ks * 4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = sb[ks * 4 * SB + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < mt_cnt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < nt_cnt) acc[i][j] = MF::run(fa[i], fb[j], acc[i][j]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i >= mt_cnt) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nt_cnt) continue;
+            const int64_t col = n0 + wn * 64 + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * 64 + i * 16 + MF::row(lane, r);
+                if (row < M && col < N) {
+                    T *dst = C + row * ldc + col;
+                    T v = alpha * acc[i][j][r];
+                    if (beta != T(0)) v += beta * (*dst);
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TA, int TB>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
+    int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
+    const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
+    int64_t ntn, int lower, int aligned) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int64_t tm, tn;
+    if (lower) {
+        // lower-triangular tile enumeration: id -> (tm, tn <= tm), row by row
+        const int64_t id = xcd_contiguous(blockIdx.x, gridDim.x);
+        tm = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5);
+        while (tm * (tm + 1) / 2 > id) --tm;
+        while ((tm + 1) * (tm + 2) / 2 <= id) ++tm;
+        tn = id - tm * (tm + 1) / 2;
+    } else {
+        const int64_t wg = xcd_contiguous(blockIdx.x, ntm * ntn);
+        constexpr int64_t G = 8;
+        const int64_t per_group = G * ntn;
+        const int64_t group = wg / per_group;
+        const int64_t first_m = group * G;
+        const int64_t gsize = (ntm - first_m < G) ? ntm - first_m : G;
+        tm = first_m + (wg % per_group) % gsize;
+        tn = (wg % per_group) / gsize;
+    }
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const bool full = aligned && sizeof(T) == 8 && (m0 + BM <= M) && (n0 + BN <= N) &&
+                      (K % KC == 0) && (K > 0) && alpha != T(0);
+    if (full) {
+        if constexpr (sizeof(T) == 8)
+            tile_full_f64<TA, TB>(K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
+    } else {
+        tile_edge<T, TA, TB>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
+    }
+}
+
+template <typename T, int TA, int TB>
+int launch_op(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B,
+              int64_t ldb, double beta, T *C, int64_t ldc, int lower, hipStream_t st) {
+    if (M <= 0 || N <= 0) return SSA_OK;
+    if (lower && M != N) return SSA_ERR_INVALID_ARGUMENT;
+    const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
+    const size_t smem = sizeof(OpSmemF64) > sizeof(EdgeSmem<T>) ? sizeof(OpSmemF64) : sizeof(EdgeSmem<T>);
+    const int aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
+                        ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
+    const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(smem)) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    // algorithmic flops of what is actually computed (lower: the tiles on/below the diagonal)
+    const double flops = 2.0 * static_cast<double>(K) * (lower ? 0.5 * static_cast<double>(M) * (M + BM)
+                                                                : static_cast<double>(M) * N);
+    ProfileScope scope(aligned && sizeof(T) == 8 && lower && TA == OP_N && TB == OP_T, kProfileSyrkLower,
+                       flops, st);
+    hipLaunchKernelGGL((gemm_op_kernel<T, TA, TB>), dim3(static_cast<unsigned>(nwg)), dim3(kGemmThreads),
+                       smem, st, M, N, K, static_cast<T>(alpha), A, lda, B, ldb, static_cast<T>(beta), C,
+                       ldc, ntm, ntn, lower, aligned);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+template <typename T>
+int gemm_op(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double alpha, const T *A,
+            int64_t lda, const T *B, int64_t ldb, double beta, T *C, int64_t ldc, hipStream_t st) {
+    if (opA == OP_N && opB == OP_T)
+        return launch_op<T, OP_N, OP_T>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, st);
+    if (opA == OP_T && opB == OP_N)
+        return launch_op<T, OP_T, OP_N>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, st);
+    if (opA == OP_N && opB == OP_N)
+        return launch_op<T, OP_N, OP_N>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, st);
+    return launch_op<T, OP_T, OP_T>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, st);
+}
+
+// used by chol.hip
+int gemm_op_f64(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double alpha,
+                const double *A, int64_t lda, const double *B, int64_t ldb, double beta, double *C,
+                int64_t ldc, hipStream_t st) {
+    return gemm_op<double>(opA, opB, lower, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+int gemm_op_f32(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double alpha,
+                const float *A, int64_t lda, const float *B, int64_t ldb, double beta, float *C,
+                int64_t ldc, hipStream_t st) {
+    return gemm_op<float>(opA, opB, lower, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+
+}  // namespace ssa
+
+using namespace ssa;
+
+extern "C" int ssa_gemm_ex(int opA, int opB, int lower_only, int64_t M, int64_t N, int64_t K,
+                           double alpha, const void *A, int64_t lda, const void *B, int64_t ldb,
+                           double beta, void *C, int64_t ldc, int dtype, void *stream) {
+    if (M < 0 || N < 0 || K < 0 || !A || !B || !C) return SSA_ERR_INVALID_ARGUMENT;
+    if ((opA != OP_N && opA != OP_T) || (opB != OP_N && opB != OP_T)) return SSA_ERR_INVALID_ARGUMENT;
+    if (ldc < N) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype == SSA_F64)
+        return gemm_op<double>(opA, opB, lower_only, M, N, K, alpha, static_cast<const double *>(A), lda,
+                               static_cast<const double *>(B), ldb, beta, static_cast<double *>(C), ldc,
+                               as_stream(stream));
+    if (dtype == SSA_F32)
+        return gemm_op<float>(opA, opB, lower_only, M, N, K, alpha, static_cast<const float *>(A), lda,
+                              static_cast<const float *>(B), ldb, beta, static_cast<float *>(C), ldc,
+                              as_stream(stream));
+    return SSA_ERR_INVALID_ARGUMENT;
+}

@@ -1,0 +1,52 @@
+// Optional instrumentation shared by the MFMA GEMM kernels: between ssa_profile_begin() and
+// ssa_profile_end() every launch of the f64 full-tile kernels is bracketed by HIP events on its
+// own stream (what bench.py's `roofline` object is computed from).
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+
+namespace ssa {
+
+enum ProfileKind : int {
+    kProfileGemmNN = 0,    // gemm_kernel<double, true>            (LU trailing / in-panel updates)
+    kProfileSyrkLower = 1, // gemm_op_kernel<double, N, T, lower>  (Cholesky trailing update)
+    kProfileKinds = 2
+};
+
+struct GemmProfile {
+    bool enabled = false;
+    std::vector<hipEvent_t> start, stop;
+    std::vector<double> flops;
+    std::vector<int> kind;
+    size_t used = 0;
+};
+inline GemmProfile g_prof;
+
+struct ProfileScope {
+    bool active;
+    hipStream_t st;
+    ProfileScope(bool wanted, int kind, double flops, hipStream_t s) : active(false), st(s) {
+        if (!g_prof.enabled || !wanted) return;
+        if (g_prof.used == g_prof.start.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            g_prof.start.push_back(a);
+            g_prof.stop.push_back(b);
+            g_prof.flops.push_back(0.0);
+            g_prof.kind.push_back(0);
+        }
+        g_prof.flops[g_prof.used] = flops;
+        g_prof.kind[g_prof.used] = kind;
+        (void)hipEventRecord(g_prof.start[g_prof.used], st);
+        active = true;
+    }
+    ~ProfileScope() {
+        if (active) {
+            (void)hipEventRecord(g_prof.stop[g_prof.used], st);
+            ++g_prof.used;
+        }
+    }
+};
+
+}  // namespace ssa

@@ -349,7 +349,7 @@ __global__ void laswp_kernel(T *__restrict__ A, int64_t lda, int64_t c0a, int64_
 constexpr int TS = 32;   // strip width
 constexpr int TBLK = 64; // LDS block of the triangular matrix
 
-template <typename T, bool UPPER, bool IDENT>
+template <typename T, bool UPPER, bool IDENT, bool UNITDIAG = true>
 __global__ __launch_bounds__(256) void trsm_block_kernel(const T *__restrict__ Tri, int64_t ldt,
                                                          int64_t tri_batch_stride, T *__restrict__ B,
                                                          int64_t ldb, int64_t b_batch_stride,
@@ -410,9 +410,9 @@ __global__ __launch_bounds__(256) void trsm_block_kernel(const T *__restrict__ T
         for (int kk = 0; kk < rows_here; ++kk) {
             const int k = UPPER ? rows_here - 1 - kk : kk;
             T xk = Bs[(rb * TBLK + k) * SBs + c];
-            if (UPPER) xk = xk / Ls[k * SLs + k];
+            if (UPPER || !UNITDIAG) xk = xk / Ls[k * SLs + k];
             __syncthreads();
-            if (UPPER && rg == 0) Bs[(rb * TBLK + k) * SBs + c] = xk;
+            if ((UPPER || !UNITDIAG) && rg == 0) Bs[(rb * TBLK + k) * SBs + c] = xk;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int i = rg + 8 * t;
@@ -433,20 +433,20 @@ constexpr size_t trsm_smem_bytes() {
     return sizeof(T) * (NB * (TS + 1) + TBLK * (TBLK + 1));
 }
 
-template <typename T, bool UPPER, bool IDENT>
+template <typename T, bool UPPER, bool IDENT, bool UNITDIAG = true>
 int launch_trsm(const T *Tri, int64_t ldt, int64_t tri_bs, T *B, int64_t ldb, int64_t b_bs, int kb,
                 int64_t N, int batch, hipStream_t st) {
     if (kb <= 0 || N <= 0 || batch <= 0) return SSA_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_block_kernel<T, UPPER, IDENT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_block_kernel<T, UPPER, IDENT, UNITDIAG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(trsm_smem_bytes<T>())) != hipSuccess)
             return SSA_ERR_HIP;
         attr_set = true;
     }
     const dim3 grid(static_cast<unsigned>(ceil_div(N, TS)), static_cast<unsigned>(batch));
-    hipLaunchKernelGGL((trsm_block_kernel<T, UPPER, IDENT>), grid, dim3(256), trsm_smem_bytes<T>(), st,
+    hipLaunchKernelGGL((trsm_block_kernel<T, UPPER, IDENT, UNITDIAG>), grid, dim3(256), trsm_smem_bytes<T>(), st,
                        Tri, ldt, tri_bs, B, ldb, b_bs, kb, N);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
@@ -654,6 +654,29 @@ int getrs(const T *LU, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs,
         }
     }
     return SSA_OK;
+}
+
+// Inverses of the NB x NB diagonal blocks of a NON-unit lower triangular factor (Cholesky),
+// inv [ceil(n / NB)][NB][NB]; used by chol.hip.
+template <typename T>
+int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t st) {
+    const int64_t full = n / NB;
+    int rc = SSA_OK;
+    if (full > 0)
+        rc = launch_trsm<T, false, true, false>(A, lda, NB * (lda + 1), inv, NB, NB * NB, NB, NB,
+                                                static_cast<int>(full), st);
+    if (rc == SSA_OK && full * NB < n) {
+        const int kb = static_cast<int>(n - full * NB);
+        rc = launch_trsm<T, false, true, false>(A + full * NB * (lda + 1), lda, 0, inv + full * NB * NB, NB, 0,
+                                                kb, kb, 1, st);
+    }
+    return rc;
+}
+int trtri_lower_blocks_f64(const double *A, int64_t lda, int64_t n, double *inv, hipStream_t st) {
+    return trtri_lower_blocks<double>(A, lda, n, inv, st);
+}
+int trtri_lower_blocks_f32(const float *A, int64_t lda, int64_t n, float *inv, hipStream_t st) {
+    return trtri_lower_blocks<float>(A, lda, n, inv, st);
 }
 
 }  // namespace ssa

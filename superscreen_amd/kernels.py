@@ -60,9 +60,11 @@ def q_assemble(xy: torch.Tensor, w: torch.Tensor, C: torch.Tensor, dtype, *,
 
 
 def system_assemble(xy, w, qdiag, Lambda, lap_indptr, lap_indices, lap_data, rows, cols, *,
-                    sign: float, dtype, ld: Optional[int] = None) -> torch.Tensor:
+                    sign: float, dtype, ld: Optional[int] = None, row_scale=None,
+                    lower_only: bool = False) -> torch.Tensor:
     """``_build_system_2d`` / ``_build_system_1d`` (solver/solve_film.py:285-305):
-    ``sign * (Q[rows, cols] * w[cols] - Lambda[cols] * Del2[rows, cols])`` as ``[nr, ld]``."""
+    ``sign * row_scale[rows] * (Q[rows, cols] * w[cols] - Lambda[cols] * Del2[rows, cols])`` as
+    ``[nr, ld]``; ``lower_only`` writes only the entries on / below the diagonal."""
     lib = load_library()
     n = xy.shape[0]
     nr = n if rows is None else rows.shape[0]
@@ -73,9 +75,57 @@ def system_assemble(xy, w, qdiag, Lambda, lap_indptr, lap_indices, lap_data, row
     ws = _ws(nbytes, xy.device)
     check(lib.ssa_system_assemble(ptr(xy), ptr(w), ptr(qdiag), ptr(Lambda), n, ptr(lap_indptr),
                                   ptr(lap_indices), ptr(lap_data), ptr(rows), nr, ptr(cols), nc,
-                                  float(sign), ptr(out), ldo, dtype_code(dtype), ptr(ws), nbytes,
-                                  current_stream()), "ssa_system_assemble")
+                                  float(sign), ptr(row_scale), int(bool(lower_only)), ptr(out), ldo,
+                                  dtype_code(dtype), ptr(ws), nbytes, current_stream()),
+          "ssa_system_assemble")
     return out
+
+
+@dataclass
+class CholFactors:
+    """Device-resident result of :func:`chol_factor`: ``S = L L^T`` (lower triangle of ``L``)."""
+
+    L: torch.Tensor
+    n: int
+    aux: torch.Tensor
+    info: int
+    dtype: torch.dtype
+
+    @property
+    def lda(self) -> int:
+        return self.L.shape[1]
+
+
+def chol_factor(S: torch.Tensor, n: int) -> CholFactors:
+    """In-place Cholesky of the symmetric positive definite ``S [n, lda]`` (lower triangle)."""
+    lib = load_library()
+    dt = dtype_code(S.dtype)
+    info = torch.zeros(1, dtype=torch.int32, device=S.device)
+    aux = torch.empty(lib.ssa_chol_aux_bytes(n, dt) // S.element_size(), dtype=S.dtype, device=S.device)
+    check(lib.ssa_chol_factor(ptr(S), n, S.shape[1], ptr(info), ptr(aux), dt, current_stream()),
+          "ssa_chol_factor")
+    return CholFactors(L=S, n=n, aux=aux, info=int(info.item()), dtype=S.dtype)
+
+
+def chol_solve(f: CholFactors, B: torch.Tensor) -> torch.Tensor:
+    """``L L^T X = B`` in place; ``B [n]`` or ``[n, nrhs]``."""
+    lib = load_library()
+    dt = dtype_code(f.dtype)
+    nrhs = 1 if B.dim() == 1 else B.shape[1]
+    nbytes = lib.ssa_chol_solve_workspace_bytes(f.n, nrhs, dt)
+    ws = _ws(nbytes, B.device)
+    check(lib.ssa_chol_solve(ptr(f.L), f.n, f.lda, ptr(f.aux), ptr(B), nrhs, nrhs, dt, ptr(ws), nbytes,
+                             current_stream()), "ssa_chol_solve")
+    return B
+
+
+def gemm_ex(opA: int, opB: int, lower_only: bool, A, B, C, M: int, N: int, K: int,
+            alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+    lib = load_library()
+    check(lib.ssa_gemm_ex(opA, opB, int(lower_only), M, N, K, float(alpha), A.data_ptr(), A.stride(0),
+                          B.data_ptr(), B.stride(0), float(beta), C.data_ptr(), C.stride(0),
+                          dtype_code(C.dtype), current_stream()), "ssa_gemm_ex")
+    return C
 
 
 # ---------------------------------------------------------------------------------------

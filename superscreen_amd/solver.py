@@ -207,9 +207,12 @@ class LinearSystem:
     grad_Lambda_term: Union[float, np.ndarray] = 0.0
     _assemble: Optional[Callable[[], "np.ndarray"]] = None   # -> host A
     factors: Optional[object] = None                         # kernels.LUFactors
+    chol: Optional[object] = None                            # kernels.CholFactors of diag(w) A
+    neg_w_device: Optional[object] = None                    # -w[indices]: rhs scaling of the Cholesky route
     A_device: Optional[object] = None                        # hole systems: [n, ld] tensor
     indices_device: Optional[object] = None
     rhs_indices_device: Optional[object] = None              # indices[perm] (LU row order)
+    _lu_factorize: Optional[Callable[[], object]] = None     # builds LUFactors on demand
     _A_host: Optional[np.ndarray] = None
 
     @property
@@ -220,16 +223,27 @@ class LinearSystem:
 
     @property
     def lu_piv(self) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        """``(lu, piv)`` of ``-A`` as ``scipy.linalg.lu_factor`` returns them.  When the film was
+        factorized through the Cholesky route the LU is computed here, on demand."""
         if self.factors is None:
-            return None
+            if self._lu_factorize is None:
+                return None
+            self.factors = self._lu_factorize()
         f = self.factors
         return f.lu[:, :f.n].cpu().numpy(), f.ipiv.cpu().numpy()
 
 
 def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo], *,
-                             store_Q: bool = False):
+                             store_Q: bool = False, method: str = "auto"):
     """``factorize_linear_systems`` (``solver/solve_film.py:151-282``) on the GPU.
-    Returns ``(film_systems, hole_systems, terminal_systems, film_data)``."""
+    Returns ``(film_systems, hole_systems, terminal_systems, film_data)``.
+
+    ``method``: ``"lu"`` factors ``-A`` like the reference (LAPACK getrf semantics);
+    ``"cholesky"`` / ``"auto"`` factor the symmetric positive definite ``diag(w) A`` instead
+    (half the flops, same solution to rounding), ``"auto"`` falling back to LU if a pivot is
+    not positive."""
+    if method not in ("auto", "cholesky", "lu"):
+        raise ValueError(f"Unknown factorization method {method!r}.")
     import torch
 
     from . import _hip, kernels
@@ -265,16 +279,36 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             interior = np.setdiff1d(interior, np.concatenate(list(info.hole_indices.values())))
         ix_d = torch.from_numpy(interior.astype(np.int64)).to(dev)
         ni = len(interior)
-        minusA = assemble(ix_d, ix_d, -1.0)          # -A, written once, factored in place
-        factors = kernels.lu_factor(minusA, ni)      # solve_film.py:279
-        if factors.info > 0:
-            logger.warning(f"LU of film {name!r}: exactly singular U[{factors.info - 1}, "
-                           f"{factors.info - 1}] (LAPACK info = {factors.info}).")
-        film_systems[name] = LinearSystem(
-            indices=interior, factors=factors, indices_device=ix_d,
-            rhs_indices_device=ix_d[factors.perm].contiguous(),
-            _assemble=lambda ix_d=ix_d, ni=ni, assemble=assemble: assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy(),
-        )
+        def lu_route(ix_d=ix_d, ni=ni, assemble=assemble, name=name):
+            minusA = assemble(ix_d, ix_d, -1.0)      # -A, written once, factored in place
+            factors = kernels.lu_factor(minusA, ni)  # solve_film.py:279
+            if factors.info > 0:
+                logger.warning(f"LU of film {name!r}: exactly singular U[{factors.info - 1}, "
+                               f"{factors.info - 1}] (LAPACK info = {factors.info}).")
+            return factors
+
+        host_A = lambda ix_d=ix_d, ni=ni, assemble=assemble: assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy()  # noqa: E731
+        system = None
+        if method in ("auto", "cholesky"):
+            # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
+            # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
+            S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
+                                        dtype=dtype, row_scale=fd.w, lower_only=True)
+            chol = kernels.chol_factor(S, ni)
+            if chol.info == 0:
+                system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,
+                                      neg_w_device=(-fd.w_t[ix_d]).contiguous(),
+                                      _lu_factorize=lu_route, _assemble=host_A)
+            else:
+                if method == "cholesky":
+                    raise RuntimeError(f"diag(w) A of film {name!r} is not positive definite.")
+                logger.warning(f"Film {name!r}: Cholesky pivot not positive, falling back to LU.")
+                del S, chol
+        if system is None:
+            factors = lu_route()
+            system = LinearSystem(indices=interior, factors=factors, indices_device=ix_d,
+                                  rhs_indices_device=ix_d[factors.perm].contiguous(), _assemble=host_A)
+        film_systems[name] = system
     return film_systems, hole_systems, {}, film_data
 
 
@@ -320,12 +354,14 @@ def factorize_model(*, device: Device, current_units: str,
                     terminal_currents: Optional[Dict[str, Dict[str, Union[float, str]]]] = None,
                     circulating_currents: Optional[Dict[str, Union[float, str]]] = None,
                     vortices: Optional[Sequence[Vortex]] = None,
-                    self_field: str = "matrix_free") -> FactorizedModel:
+                    self_field: str = "matrix_free", method: str = "auto") -> FactorizedModel:
     """``factorize_model`` (``solver/solve.py:223-287``).
 
     ``self_field`` (extension): ``"matrix_free"`` regenerates q_ij on the fly for
     ``Q @ (w * g)`` (2.2x faster than streaming a stored Q at n = 50k, and n^2 words less HBM);
     ``"dense"`` stores Q in the solve dtype like the reference and uses a GEMV.
+    ``method`` (extension): ``"auto"`` (default) / ``"cholesky"`` / ``"lu"``, see
+    :func:`factorize_linear_systems`.
     """
     if self_field not in ("matrix_free", "dense"):
         raise ValueError(f"Unknown self_field mode {self_field!r}.")
@@ -347,7 +383,7 @@ def factorize_model(*, device: Device, current_units: str,
     if vortices:
         raise NotImplementedError("Vortices are not on the accelerated path yet.")
     film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
-        device, film_info, store_Q=(self_field == "dense"))
+        device, film_info, store_Q=(self_field == "dense"), method=method)
     return FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
                            terminal_currents, circulating_currents, vortices, current_units,
                            film_data=film_data, self_field_mode=self_field)
@@ -380,10 +416,14 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
         kernels.index_add_scalar(g, hs.indices_device, current)        # g[hole] += I_circ
         kernels.gemv(hs.A_device, fd.n, len(hs.indices), g, xidx=hs.indices_device,
                      y=ha_eff, alpha=-1.0, beta=1.0)                      # Ha_eff += -(A @ g[ix])
-    h = kernels.film_rhs(applied_d, other_d, ha_eff, system.rhs_indices_device)
-    if check_inversion:
+    if system.chol is not None:
         h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
-    gf = kernels.lu_solve_permuted(system.factors, h)                    # = lu_solve(lu_piv, h)
+        gf = kernels.chol_solve(system.chol, kernels.row_scale(h_nat, system.neg_w_device))
+    else:
+        h = kernels.film_rhs(applied_d, other_d, ha_eff, system.rhs_indices_device)
+        if check_inversion:
+            h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
+        gf = kernels.lu_solve_permuted(system.factors, h)                # = lu_solve(lu_piv, h)
     if check_inversion:  # solve_film.py:533-540: warn, never raise
         A = torch.from_numpy(system.A).to(fd.device)
         hsim = -(kernels.gemv(A, len(system.indices), len(system.indices), gf))

@@ -221,3 +221,83 @@ def test_biot_savart_golden(K, golden, dtype):
             K.biot_savart(dev(d["sites1"]), dev(areas), dev(d["J"]), dev(tgt), zb - za, acc,
                           accumulate=True, src_begin=b, src_end=e)
         assert relerr(acc.cpu().numpy(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 1e-5)])
+@pytest.mark.parametrize("case", [(0, 1, False, 300, 200, 64), (0, 1, True, 517, 517, 256), (0, 1, True, 1024, 1024, 64),
+                                  (1, 0, False, 640, 3, 256), (1, 0, False, 256, 130, 203), (0, 0, False, 384, 256, 32),
+                                  (1, 1, False, 130, 140, 50)])
+def test_gemm_ex(K, dtype, tol, case):
+    opA, opB, lower, M, N, Kd = case
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((M, Kd) if opA == 0 else (Kd, M)).astype(dtype)
+    B = rng.standard_normal((Kd, N) if opB == 0 else (N, Kd)).astype(dtype)
+    C = rng.standard_normal((M, N)).astype(dtype)
+    Cd = dev(C)
+    K.gemm_ex(opA, opB, lower, dev(A), dev(B), Cd, M, N, Kd, alpha=-1.0, beta=1.0)
+    Am = A.astype(np.float64) if opA == 0 else A.astype(np.float64).T
+    Bm = B.astype(np.float64) if opB == 0 else B.astype(np.float64).T
+    ref = C.astype(np.float64) - Am @ Bm
+    got = Cd.cpu().numpy().astype(np.float64)
+    if lower:
+        mask = np.tril(np.ones((M, N), dtype=bool))
+        assert np.max(np.abs(got[mask] - ref[mask])) / np.max(np.abs(ref)) < tol
+        # strictly above the 128-tile diagonal nothing may have been touched
+        tm, tn = np.arange(M)[:, None] // 128, np.arange(N)[None, :] // 128
+        untouched = tn > tm
+        assert np.array_equal(got[untouched], C.astype(np.float64)[untouched])
+    else:
+        assert relerr(got, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 2e-4)])
+@pytest.mark.parametrize("n", [40, 64, 200, 257, 777, 1500])
+def test_cholesky_factor_solve(K, dtype, tol, n):
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, n))
+    S = (X @ X.T / n + np.eye(n) * 2.0).astype(dtype)
+    ld = K.padded_ld(n, dtype)
+    Sd = torch.zeros((n, ld), dtype=getattr(torch, dtype), device="cuda")
+    Sd[:, :n] = dev(np.tril(S))  # only the lower triangle is given
+    f = K.chol_factor(Sd, n)
+    assert f.info == 0
+    L = np.tril(f.L.cpu().numpy()[:, :n].astype(np.float64))
+    assert relerr(L, np.linalg.cholesky(S.astype(np.float64))) < tol * 10
+    for nrhs in (1, 5):
+        b = rng.standard_normal((n, nrhs)).astype(dtype)
+        bd = dev(b[:, 0].copy()) if nrhs == 1 else dev(b)
+        x = K.chol_solve(f, bd).cpu().numpy().reshape(n, nrhs)
+        assert relerr(x, np.linalg.solve(S.astype(np.float64), b.astype(np.float64))) < tol * 10
+    # not positive definite -> info > 0
+    Sbad = S.copy()
+    Sbad[n // 2, n // 2] = -1.0
+    Sd2 = torch.zeros((n, ld), dtype=getattr(torch, dtype), device="cuda")
+    Sd2[:, :n] = dev(np.tril(Sbad))
+    assert K.chol_factor(Sd2, n).info > 0
+
+
+def test_system_assemble_symmetric_scaled(K, disk):
+    """S = diag(w) A is symmetric; the lower_only assembly equals tril(w_i * A_ij)."""
+    sites, elements, mesh = disk
+    n = len(sites)
+    rng = np.random.default_rng(9)
+    ix = np.sort(rng.choice(n, size=333, replace=False)).astype(np.int64)
+    lap = mesh.laplacian.tocsr()
+    lap.sort_indices()
+    Lam = 0.1 * np.ones(n)
+    _, qd = K.q_assemble(dev(sites), dev(mesh.weights), dev(orc.C_vector(sites)), "float64", want_Q=False)
+    A = orc.build_system_2d(mesh.Q, mesh.weights, Lam, lap, ix)
+    S_ref = mesh.weights[ix][:, None] * A
+    assert relerr(S_ref, S_ref.T) < 1e-13
+    S = K.system_assemble(dev(sites), dev(mesh.weights), qd, dev(Lam), dev(lap.indptr.astype(np.int64)),
+                          dev(lap.indices.astype(np.int64)), dev(lap.data), dev(ix), dev(ix), sign=1.0,
+                          dtype="float64", row_scale=dev(mesh.weights), lower_only=True)
+    got = S.cpu().numpy()[:, :len(ix)]
+    mask = np.tril(np.ones_like(S_ref, dtype=bool))
+    assert np.max(np.abs(got[mask] - S_ref[mask])) / np.max(np.abs(S_ref)) < 1e-13
+    # and the Cholesky route reproduces the LU route: gf = lu_solve(lu_factor(-A), h) = -S^-1 (w h)
+    h = rng.standard_normal(len(ix))
+    f = K.chol_factor(S, len(ix))
+    assert f.info == 0
+    x = K.chol_solve(f, dev(-mesh.weights[ix] * h)).cpu().numpy()
+    assert relerr(x, la.lu_solve(la.lu_factor(-A), h)) < 1e-12

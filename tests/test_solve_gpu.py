@@ -154,6 +154,27 @@ def test_two_film_vs_oracle_medium(sc, dtype, tol):
             assert relerr(sol.film_solutions[nm].current_density, ref[nm].current_density) < tol * 10
 
 
+@pytest.mark.parametrize("method", ["lu", "cholesky"])
+def test_factorization_methods_agree(sc, method):
+    """LU of -A (the reference's algorithm) and Cholesky of diag(w) A give the same solution."""
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(22, ("washer", "disk"), solve_dtype="float64")
+    ref = sc.solve(model=sc.factorize_model(device=device, current_units="uA", method="lu"),
+                   applied_field=sc.ConstantField(1.3), iterations=3, check_inversion=True)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": 2.0},
+                               method=method)
+    assert (model.film_systems["disk1"].chol is not None) == (method == "cholesky")
+    model.set_circulating_currents({})
+    got = sc.solve(model=model, applied_field=sc.ConstantField(1.3), iterations=3, check_inversion=True)
+    for a, b in zip(ref, got):
+        for nm in device.films:
+            assert relerr(b.film_solutions[nm].stream, a.film_solutions[nm].stream) < 1e-11
+            assert relerr(b.film_solutions[nm].current_density, a.film_solutions[nm].current_density) < 1e-10
+    lu, piv = model.film_systems["disk1"].lu_piv  # available on demand for either route
+    assert np.array_equal(piv, np.arange(len(piv)))
+
+
 def test_model_reuse_and_linearity(sc):
     """A factorized model is reusable (solve never mutates it) and the response is linear in the
     applied field -- the size-independent property used at BASELINE scale."""
