@@ -36,8 +36,10 @@ int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double 
              double alpha, double beta, hipStream_t st);
 int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
              double alpha, double beta, hipStream_t st);
-int trtri_lower_blocks_f64(const double *A, int64_t lda, int64_t n, double *inv, hipStream_t st);
-int trtri_lower_blocks_f32(const float *A, int64_t lda, int64_t n, float *inv, hipStream_t st);
+int trtri_lower_batched_f64(const double *Ablk, int64_t lda, int64_t a_stride, int kb, double *out,
+                            int64_t ldo, int64_t o_stride, int batch, hipStream_t st);
+int trtri_lower_batched_f32(const float *Ablk, int64_t lda, int64_t a_stride, int kb, float *out,
+                            int64_t ldo, int64_t o_stride, int batch, hipStream_t st);
 
 namespace {
 
@@ -71,11 +73,33 @@ inline int gemv_n_t(const float *M, int64_t nr, int64_t nc, int64_t ldm, const f
                     double alpha, double beta, hipStream_t st) {
     return gemv_f32(M, nr, nc, ldm, x, y, alpha, beta, st);
 }
-inline int trtri_t(const double *A, int64_t lda, int64_t n, double *inv, hipStream_t st) {
-    return trtri_lower_blocks_f64(A, lda, n, inv, st);
+inline int trtri_batched_t(const double *A, int64_t lda, int64_t as, int kb, double *out, int64_t ldo,
+                           int64_t os, int batch, hipStream_t st) {
+    return trtri_lower_batched_f64(A, lda, as, kb, out, ldo, os, batch, st);
 }
-inline int trtri_t(const float *A, int64_t lda, int64_t n, float *inv, hipStream_t st) {
-    return trtri_lower_blocks_f32(A, lda, n, inv, st);
+inline int trtri_batched_t(const float *A, int64_t lda, int64_t as, int kb, float *out, int64_t ldo,
+                           int64_t os, int batch, hipStream_t st) {
+    return trtri_lower_batched_f32(A, lda, as, kb, out, ldo, os, batch, st);
+}
+
+constexpr int SNB = 1024;  // block size of the triangular solves (pre-inverted diagonal blocks)
+
+// inv <- inverse of the lower triangular diagonal block L[r0 : r0 + sz, r0 : r0 + sz], built
+// recursively:  inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]];  leaves (<= 256) by the
+// LDS substitution kernel, the off-diagonal quadrants by two MFMA GEMMs.  `inv` has leading
+// dimension ldi and is zero above the diagonal (the caller memsets it).
+template <typename T>
+int build_block_inverse(const T *L, int64_t lda, int64_t r0, int64_t sz, T *inv, int64_t ldi, T *tmp,
+                        hipStream_t st) {
+    if (sz <= 256) return SSA_OK;  // leaves are inverted by the caller, batched
+    const int64_t h = (sz > 512) ? 512 : 256;
+    int rc = build_block_inverse(L, lda, r0, h, inv, ldi, tmp, st);
+    if (rc != SSA_OK) return rc;
+    rc = build_block_inverse(L, lda, r0 + h, sz - h, inv + h * ldi + h, ldi, tmp, st);
+    if (rc != SSA_OK) return rc;
+    rc = gemm_nn_t(sz - h, h, h, 1.0, L + (r0 + h) * lda + r0, lda, inv, ldi, 0.0, tmp, 512, st);
+    if (rc != SSA_OK) return rc;
+    return gemm_nn_t(sz - h, h, sz - h, -1.0, inv + h * ldi + h, ldi, tmp, 512, 0.0, inv + h * ldi, ldi, st);
 }
 
 __device__ __forceinline__ double rsqrt_t(double x) { return rsqrt_f64(x); }
@@ -311,27 +335,55 @@ int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
             if (rc != SSA_OK) return rc;
         }
     }
-    return trtri_t(A, lda, n, aux, st);  // inverses of the 256 x 256 diagonal blocks of L
+    // aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch)
+    const int64_t nblk = ceil_div(n, SNB);
+    if (hipMemsetAsync(aux, 0, static_cast<size_t>(nblk) * SNB * SNB * sizeof(T), st) != hipSuccess)
+        return SSA_ERR_HIP;
+    T *tmp = aux + nblk * SNB * SNB;
+    // leaves: the 256 x 256 diagonal blocks, batched by their position s inside the SNB block
+    for (int s = 0; s < SNB / 256; ++s) {
+        const int64_t first = static_cast<int64_t>(s) * 256;  // first leaf of this class
+        if (first >= n) break;
+        const int64_t count_full = (n - first >= 256) ? ((n - first - 256) / SNB + 1) : 0;
+        if (count_full > 0) {
+            rc = trtri_batched_t(A + first * (lda + 1), lda, static_cast<int64_t>(SNB) * (lda + 1), 256,
+                                 aux + first * (SNB + 1), static_cast<int64_t>(SNB),
+                                 static_cast<int64_t>(SNB) * SNB, static_cast<int>(count_full), st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    if (n % 256 != 0) {  // the last, partial leaf
+        const int64_t r0 = n / 256 * 256, J = r0 / SNB, off = r0 - J * SNB;
+        rc = trtri_batched_t(A + r0 * (lda + 1), lda, 0, static_cast<int>(n - r0),
+                             aux + J * SNB * SNB + off * (SNB + 1), static_cast<int64_t>(SNB), 0, 1, st);
+        if (rc != SSA_OK) return rc;
+    }
+    for (int64_t k = 0; k < nblk; ++k) {
+        const int64_t r0 = k * SNB, sz = (n - r0 < SNB) ? n - r0 : SNB;
+        rc = build_block_inverse(A, lda, r0, sz, aux + k * SNB * SNB, static_cast<int64_t>(SNB), tmp, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
 }
 
-// L L^T X = B.  Single right-hand side: GEMV / transposed-GEMV chain over 256-row blocks;
+// L L^T X = B.  Single right-hand side: GEMV / transposed-GEMV chain over SNB-row blocks;
 // several: the same recurrence on the MFMA GEMMs (NN forward, TN backward).
 template <typename T>
 int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb, T *X,
           hipStream_t st) {
-    const int64_t nblk = ceil_div(n, CNB);
+    const int64_t nblk = ceil_div(n, SNB);
     const int64_t ldx = nrhs;
     int rc;
     for (int64_t k = 0; k < nblk; ++k) {  // forward: L y = b
-        const int64_t r0 = k * CNB, kb = (n - r0 < CNB) ? n - r0 : CNB;
+        const int64_t r0 = k * SNB, kb = (n - r0 < SNB) ? n - r0 : SNB;
         const int64_t below = n - r0 - kb;
-        const T *inv = aux + k * CNB * CNB;
+        const T *inv = aux + k * SNB * SNB;
         if (nrhs == 1 && ldb == 1) {
-            rc = gemv_n_t(inv, kb, kb, CNB, B + r0, X + r0, 1.0, 0.0, st);
+            rc = gemv_n_t(inv, kb, kb, SNB, B + r0, X + r0, 1.0, 0.0, st);
             if (rc == SSA_OK && below > 0)
                 rc = gemv_n_t(L + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
         } else {
-            rc = gemm_nn_t(kb, nrhs, kb, 1.0, inv, CNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, st);
+            rc = gemm_nn_t(kb, nrhs, kb, 1.0, inv, SNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, st);
             if (rc == SSA_OK && below > 0)
                 rc = gemm_nn_t(below, nrhs, kb, -1.0, L + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx, 1.0,
                                B + (r0 + kb) * ldb, ldb, st);
@@ -339,14 +391,14 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
         if (rc != SSA_OK) return rc;
     }
     for (int64_t k = nblk - 1; k >= 0; --k) {  // backward: L^T x = y   (y lives in X, x goes to B)
-        const int64_t r0 = k * CNB, kb = (n - r0 < CNB) ? n - r0 : CNB;
-        const T *inv = aux + k * CNB * CNB;
+        const int64_t r0 = k * SNB, kb = (n - r0 < SNB) ? n - r0 : SNB;
+        const T *inv = aux + k * SNB * SNB;
         if (nrhs == 1 && ldb == 1) {
-            rc = gemv_trans(inv, kb, kb, CNB, X + r0, B + r0, 1.0, 0.0, st);
+            rc = gemv_trans(inv, kb, kb, SNB, X + r0, B + r0, 1.0, 0.0, st);
             if (rc == SSA_OK && r0 > 0)
                 rc = gemv_trans(L + r0 * lda, kb, r0, lda, B + r0, X, -1.0, 1.0, st);
         } else {
-            rc = gemm_op_t(1, 0, 0, kb, nrhs, kb, 1.0, inv, CNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
+            rc = gemm_op_t(1, 0, 0, kb, nrhs, kb, 1.0, inv, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
             if (rc == SSA_OK && r0 > 0)
                 rc = gemm_op_t(1, 0, 0, r0, nrhs, kb, -1.0, L + r0 * lda, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
         }
@@ -361,7 +413,7 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
 using namespace ssa;
 
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
-    return static_cast<size_t>(ceil_div(n, CNB)) * CNB * CNB * (dtype == SSA_F64 ? 8 : 4);
+    return (static_cast<size_t>(ceil_div(n, SNB)) * SNB * SNB + 512 * 512) * (dtype == SSA_F64 ? 8 : 4);
 }
 
 extern "C" int ssa_chol_factor(void *A, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,

@@ -672,6 +672,16 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
     }
     return rc;
 }
+// Inverses of `batch` non-unit lower triangular blocks (kb <= NB): block b is read at
+// Ablk + b * a_stride and its inverse written at out + b * o_stride with leading dimension ldo.
+int trtri_lower_batched_f64(const double *Ablk, int64_t lda, int64_t a_stride, int kb, double *out,
+                            int64_t ldo, int64_t o_stride, int batch, hipStream_t st) {
+    return launch_trsm<double, false, true, false>(Ablk, lda, a_stride, out, ldo, o_stride, kb, kb, batch, st);
+}
+int trtri_lower_batched_f32(const float *Ablk, int64_t lda, int64_t a_stride, int kb, float *out,
+                            int64_t ldo, int64_t o_stride, int batch, hipStream_t st) {
+    return launch_trsm<float, false, true, false>(Ablk, lda, a_stride, out, ldo, o_stride, kb, kb, batch, st);
+}
 int trtri_lower_blocks_f64(const double *A, int64_t lda, int64_t n, double *inv, hipStream_t st) {
     return trtri_lower_blocks<double>(A, lda, n, inv, st);
 }

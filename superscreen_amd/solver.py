@@ -106,6 +106,17 @@ def get_holes_and_vortices_by_film(device: Device, vortices: Sequence[Vortex]):
     return holes_by_film, vortices_by_film
 
 
+def _sites_in_polygon(mesh, polygon) -> np.ndarray:
+    """``polygon.contains_points(mesh.sites, index=True)`` (``solver/utils.py:271-274, 302``),
+    memoised per (mesh, polygon geometry): the point-in-polygon test is pure host work that
+    repeated ``factorize_model`` calls on the same device would otherwise redo."""
+    cache = mesh.__dict__.setdefault("_contains_cache", {})
+    key = hash(polygon.points.tobytes())
+    if key not in cache:
+        cache[key] = polygon.contains_points(mesh.sites, index=True)
+    return cache[key]
+
+
 def make_film_info(*, device: Device, vortices: Sequence[Vortex],
                    circulating_currents: Dict[str, float],
                    terminal_currents: Dict[str, Dict[str, float]]) -> Dict[str, FilmInfo]:
@@ -130,8 +141,7 @@ def make_film_info(*, device: Device, vortices: Sequence[Vortex],
             london_lambda = np.asarray(
                 london_lambda(mesh.sites[:, 0], mesh.sites[:, 1]) * np.ones(len(mesh.sites))
             ).astype(dtype, copy=False)[:, np.newaxis]
-        hole_indices = {hole.name: hole.contains_points(mesh.sites, index=True)
-                        for hole in holes_by_film[name]}
+        hole_indices = {hole.name: _sites_in_polygon(mesh, hole) for hole in holes_by_film[name]}
         in_hole = np.zeros(len(mesh.sites), dtype=bool)
         if hole_indices:
             in_hole[np.concatenate(list(hole_indices.values()))] = True
@@ -141,7 +151,7 @@ def make_film_info(*, device: Device, vortices: Sequence[Vortex],
         if name in device.terminals:
             raise NotImplementedError("Terminal currents are not on the accelerated path yet.")
         boundary = mesh.boundary_indices
-        interior = np.setdiff1d(film.contains_points(mesh.sites, index=True), boundary)
+        interior = np.setdiff1d(_sites_in_polygon(mesh, film), boundary)
         film_info[name] = FilmInfo(
             name=name, layer=layer.name, lambda_info=lambda_info,
             vortices=tuple(vortices_by_film[name]), interior_indices=interior,
