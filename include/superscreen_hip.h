@@ -140,6 +140,9 @@ int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *
  * with A = Q[ix,ix] w[ix] - Lambda Del2[ix,ix].  S = diag(w[ix]) A is symmetric positive
  * definite (Q is symmetric off its diagonal, Del2 = diag(1/w) L with L symmetric, and S is
  * strictly diagonally dominant with a positive diagonal), so  gf = -S^-1 (w[ix] .* h):
+ *   The factorization works on S padded with identity rows/columns to np = ssa_chol_padded_n(n)
+ *   (a multiple of 256, so that every MFMA tile is a full one): the S buffer must hold np rows
+ *   with lda >= np; rows / columns >= n are initialised by ssa_chol_factor itself.
  *   ssa_chol_factor: in-place  S = L L^T  on the lower triangle of S [n,lda] (what
  *                    ssa_system_assemble(row_scale = w, lower_only = 1, sign = +1) writes);
  *                    (1/3) n^3 flops, trailing update = MFMA SYRK on the lower tiles only.
@@ -148,6 +151,7 @@ int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *
  *                    aux: ssa_chol_aux_bytes(n, dtype) (inverses of the diagonal blocks of L).
  *   ssa_chol_solve:  L L^T X = B in place, nrhs >= 1; workspace ssa_chol_solve_workspace_bytes.
  */
+int64_t ssa_chol_padded_n(int64_t n);
 size_t ssa_chol_aux_bytes(int64_t n, int dtype);
 int ssa_chol_factor(void *S, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,
                     void *stream);

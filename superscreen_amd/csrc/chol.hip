@@ -413,21 +413,68 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
 using namespace ssa;
 
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
-    return (static_cast<size_t>(ceil_div(n, SNB)) * SNB * SNB + 512 * 512) * (dtype == SSA_F64 ? 8 : 4);
+    const int64_t np = ceil_div(n, CNB) * CNB;
+    return (static_cast<size_t>(ceil_div(np, SNB)) * SNB * SNB + 512 * 512) * (dtype == SSA_F64 ? 8 : 4);
 }
+
+extern "C" int64_t ssa_chol_padded_n(int64_t n) { return ceil_div(n, CNB) * CNB; }
+
+namespace ssa {
+namespace {
+// rows n .. np-1 of the padded matrix: zero with a unit diagonal (keeps it positive definite and
+// makes every panel / SYRK tile a full one)
+template <typename T>
+__global__ void pad_identity_kernel(T *A, int64_t lda, int64_t n, int64_t np) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t r = n + blockIdx.y;
+    if (c < np) A[r * lda + c] = (c == r) ? T(1) : T(0);
+}
+template <typename T>
+int potrf_padded(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
+    const int64_t np = ssa_chol_padded_n(n);
+    if (np > n) {
+        hipLaunchKernelGGL((pad_identity_kernel<T>), dim3(static_cast<unsigned>(ceil_div(np, 256)),
+                                                          static_cast<unsigned>(np - n)),
+                           dim3(256), 0, st, A, lda, n, np);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+    }
+    return potrf<T>(A, np, lda, info, aux, st);
+}
+template <typename T>
+int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb,
+                 T *ws, hipStream_t st) {
+    const int64_t np = ssa_chol_padded_n(n);
+    T *X = ws, *Bp = ws + np * nrhs;
+    if (hipMemcpy2DAsync(Bp, nrhs * sizeof(T), B, ldb * sizeof(T), nrhs * sizeof(T), n, hipMemcpyDeviceToDevice,
+                         st) != hipSuccess)
+        return SSA_ERR_HIP;
+    if (np > n && hipMemsetAsync(Bp + n * nrhs, 0, (np - n) * nrhs * sizeof(T), st) != hipSuccess)
+        return SSA_ERR_HIP;
+    const int rc = potrs<T>(L, np, lda, aux, Bp, nrhs, nrhs, X, st);
+    if (rc != SSA_OK) return rc;
+    if (hipMemcpy2DAsync(B, ldb * sizeof(T), Bp, nrhs * sizeof(T), nrhs * sizeof(T), n, hipMemcpyDeviceToDevice,
+                         st) != hipSuccess)
+        return SSA_ERR_HIP;
+    return SSA_OK;
+}
+}  // namespace
+}  // namespace ssa
 
 extern "C" int ssa_chol_factor(void *A, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,
                                void *stream) {
-    if (!A || !info || !aux || n <= 0 || lda < n) return SSA_ERR_INVALID_ARGUMENT;
+    if (!A || !info || !aux || n <= 0 || lda < ssa_chol_padded_n(n)) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype == SSA_F64)
-        return potrf<double>(static_cast<double *>(A), n, lda, info, static_cast<double *>(aux), as_stream(stream));
+        return potrf_padded<double>(static_cast<double *>(A), n, lda, info, static_cast<double *>(aux),
+                                    as_stream(stream));
     if (dtype == SSA_F32)
-        return potrf<float>(static_cast<float *>(A), n, lda, info, static_cast<float *>(aux), as_stream(stream));
+        return potrf_padded<float>(static_cast<float *>(A), n, lda, info, static_cast<float *>(aux),
+                                   as_stream(stream));
     return SSA_ERR_INVALID_ARGUMENT;
 }
 
 extern "C" size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype) {
-    return static_cast<size_t>(n) * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) + 256;
+    return 2 * static_cast<size_t>(ssa_chol_padded_n(n)) * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) +
+           256;
 }
 
 extern "C" int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B,
@@ -438,9 +485,10 @@ extern "C" int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void 
     if (!workspace || workspace_bytes < ssa_chol_solve_workspace_bytes(n, nrhs, dtype))
         return SSA_ERR_WORKSPACE_TOO_SMALL;
     if (dtype == SSA_F64)
-        return potrs<double>(static_cast<const double *>(L), n, lda, static_cast<const double *>(aux),
-                             static_cast<double *>(B), nrhs, ldb, static_cast<double *>(workspace),
-                             as_stream(stream));
-    return potrs<float>(static_cast<const float *>(L), n, lda, static_cast<const float *>(aux),
-                        static_cast<float *>(B), nrhs, ldb, static_cast<float *>(workspace), as_stream(stream));
+        return potrs_padded<double>(static_cast<const double *>(L), n, lda, static_cast<const double *>(aux),
+                                    static_cast<double *>(B), nrhs, ldb, static_cast<double *>(workspace),
+                                    as_stream(stream));
+    return potrs_padded<float>(static_cast<const float *>(L), n, lda, static_cast<const float *>(aux),
+                               static_cast<float *>(B), nrhs, ldb, static_cast<float *>(workspace),
+                               as_stream(stream));
 }

@@ -61,7 +61,7 @@ def q_assemble(xy: torch.Tensor, w: torch.Tensor, C: torch.Tensor, dtype, *,
 
 def system_assemble(xy, w, qdiag, Lambda, lap_indptr, lap_indices, lap_data, rows, cols, *,
                     sign: float, dtype, ld: Optional[int] = None, row_scale=None,
-                    lower_only: bool = False) -> torch.Tensor:
+                    lower_only: bool = False, alloc_rows: Optional[int] = None) -> torch.Tensor:
     """``_build_system_2d`` / ``_build_system_1d`` (solver/solve_film.py:285-305):
     ``sign * row_scale[rows] * (Q[rows, cols] * w[cols] - Lambda[cols] * Del2[rows, cols])`` as
     ``[nr, ld]``; ``lower_only`` writes only the entries on / below the diagonal."""
@@ -70,7 +70,7 @@ def system_assemble(xy, w, qdiag, Lambda, lap_indptr, lap_indices, lap_data, row
     nr = n if rows is None else rows.shape[0]
     nc = cols.shape[0]
     ldo = ld or (padded_ld(nc, dtype) if nc > 1 else 1)
-    out = torch.empty((nr, ldo), dtype=_tdtype(dtype), device=xy.device)
+    out = torch.empty((max(nr, alloc_rows or 0), ldo), dtype=_tdtype(dtype), device=xy.device)
     nbytes = lib.ssa_system_assemble_workspace_bytes(n, nr, nc)
     ws = _ws(nbytes, xy.device)
     check(lib.ssa_system_assemble(ptr(xy), ptr(w), ptr(qdiag), ptr(Lambda), n, ptr(lap_indptr),
@@ -96,9 +96,17 @@ class CholFactors:
         return self.L.shape[1]
 
 
+def chol_padded_n(n: int) -> int:
+    """Rows / leading dimension the buffer handed to :func:`chol_factor` must provide."""
+    return int(load_library().ssa_chol_padded_n(n))
+
+
 def chol_factor(S: torch.Tensor, n: int) -> CholFactors:
-    """In-place Cholesky of the symmetric positive definite ``S [n, lda]`` (lower triangle)."""
+    """In-place Cholesky of the symmetric positive definite ``S`` (lower triangle given in the
+    leading ``n x n`` part of a ``[chol_padded_n(n), lda >= chol_padded_n(n)]`` buffer)."""
     lib = load_library()
+    if S.shape[0] < chol_padded_n(n) or S.shape[1] < chol_padded_n(n):
+        raise ValueError("chol_factor needs a buffer padded to chol_padded_n(n) rows and columns.")
     dt = dtype_code(S.dtype)
     info = torch.zeros(1, dtype=torch.int32, device=S.device)
     aux = torch.empty(lib.ssa_chol_aux_bytes(n, dt) // S.element_size(), dtype=S.dtype, device=S.device)

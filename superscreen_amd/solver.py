@@ -302,8 +302,10 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
         if method in ("auto", "cholesky"):
             # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
             # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
+            npad = kernels.chol_padded_n(ni)
             S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
-                                        dtype=dtype, row_scale=fd.w, lower_only=True)
+                                        dtype=dtype, row_scale=fd.w, lower_only=True,
+                                        ld=kernels.padded_ld(npad, dtype), alloc_rows=npad)
             chol = kernels.chol_factor(S, ni)
             if chol.info == 0:
                 system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,

@@ -256,9 +256,10 @@ def test_cholesky_factor_solve(K, dtype, tol, n):
     rng = np.random.default_rng(n)
     X = rng.standard_normal((n, n))
     S = (X @ X.T / n + np.eye(n) * 2.0).astype(dtype)
-    ld = K.padded_ld(n, dtype)
-    Sd = torch.zeros((n, ld), dtype=getattr(torch, dtype), device="cuda")
-    Sd[:, :n] = dev(np.tril(S))  # only the lower triangle is given
+    npad = K.chol_padded_n(n)
+    ld = K.padded_ld(npad, dtype)
+    Sd = torch.full((npad, ld), float("nan"), dtype=getattr(torch, dtype), device="cuda")
+    Sd[:n, :n] = dev(np.tril(S))  # only the lower triangle is given; the padding is the library's job
     f = K.chol_factor(Sd, n)
     assert f.info == 0
     L = np.tril(f.L.cpu().numpy()[:, :n].astype(np.float64))
@@ -271,8 +272,8 @@ def test_cholesky_factor_solve(K, dtype, tol, n):
     # not positive definite -> info > 0
     Sbad = S.copy()
     Sbad[n // 2, n // 2] = -1.0
-    Sd2 = torch.zeros((n, ld), dtype=getattr(torch, dtype), device="cuda")
-    Sd2[:, :n] = dev(np.tril(Sbad))
+    Sd2 = torch.zeros((npad, ld), dtype=getattr(torch, dtype), device="cuda")
+    Sd2[:n, :n] = dev(np.tril(Sbad))
     assert K.chol_factor(Sd2, n).info > 0
 
 
@@ -291,8 +292,9 @@ def test_system_assemble_symmetric_scaled(K, disk):
     assert relerr(S_ref, S_ref.T) < 1e-13
     S = K.system_assemble(dev(sites), dev(mesh.weights), qd, dev(Lam), dev(lap.indptr.astype(np.int64)),
                           dev(lap.indices.astype(np.int64)), dev(lap.data), dev(ix), dev(ix), sign=1.0,
-                          dtype="float64", row_scale=dev(mesh.weights), lower_only=True)
-    got = S.cpu().numpy()[:, :len(ix)]
+                          dtype="float64", row_scale=dev(mesh.weights), lower_only=True,
+                          ld=K.padded_ld(K.chol_padded_n(len(ix)), "float64"), alloc_rows=K.chol_padded_n(len(ix)))
+    got = S.cpu().numpy()[:len(ix), :len(ix)]
     mask = np.tril(np.ones_like(S_ref, dtype=bool))
     assert np.max(np.abs(got[mask] - S_ref[mask])) / np.max(np.abs(S_ref)) < 1e-13
     # and the Cholesky route reproduces the LU route: gf = lu_solve(lu_factor(-A), h) = -S^-1 (w h)
