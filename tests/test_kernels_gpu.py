@@ -262,7 +262,7 @@ def test_cholesky_factor_solve(K, dtype, tol, n):
     Sd[:n, :n] = dev(np.tril(S))  # only the lower triangle is given; the padding is the library's job
     f = K.chol_factor(Sd, n)
     assert f.info == 0
-    L = np.tril(f.L.cpu().numpy()[:, :n].astype(np.float64))
+    L = np.tril(f.L.cpu().numpy()[:n, :n].astype(np.float64))
     assert relerr(L, np.linalg.cholesky(S.astype(np.float64))) < tol * 10
     for nrhs in (1, 5):
         b = rng.standard_normal((n, nrhs)).astype(dtype)
