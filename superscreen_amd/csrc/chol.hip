@@ -163,7 +163,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int64_t j0, int m, int jb,
                                                          int32_t *info) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TS = CPW + 1, SS = 32 + 1;
+    constexpr int TS = CPW + 1, SS = 16 + 1;
     T *Ut = reinterpret_cast<T *>(smem_raw);       // [64][TS]: first the block itself, then L11^T
     T *colbuf = Ut + CPW * TS;                      // [2][64]
     T *rdiag = colbuf + 2 * CPW;                    // [64]
@@ -212,40 +212,42 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int6
     }
     __syncthreads();
 
-    // rows below the block: HBM -> (LDS transpose) -> registers -> substitute -> back
+    // rows below the block: HBM -> (LDS transpose, 16 columns at a time: 35 KB of staging keeps the
+    // kernel at 70 KB of LDS so that it can share a CU with a trailing-update workgroup when the
+    // factorization runs panel k+1 beside SYRK k) -> registers -> substitute -> back
     T *st = stage + wave * 64 * SS;
     const int wrow0 = row_base + wave * 64;
     T arow[CPW];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 4; ++h) {
 #pragma unroll 4
-        for (int it = 0; it < 32; ++it) {
-            const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
+        for (int it = 0; it < 16; ++it) {
+            const int rr = 4 * it + (lane >> 4), c = 16 * h + (lane & 15);
             const int pr = wrow0 + rr;
             T val = T(0);
             if (pr < m && pr >= nt && c < jb) val = Ap[static_cast<int64_t>(pr) * lda + c];
-            st[rr * SS + (lane & 31)] = val;
+            st[rr * SS + (lane & 15)] = val;
         }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) arow[32 * h + i] = st[lane * SS + i];
+        for (int i = 0; i < 16; ++i) arow[16 * h + i] = st[lane * SS + i];
     }
     chol_fwd_all<T>(arow, Ut, rdiag, jb, std::make_integer_sequence<int, CPW>{});
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 4; ++h) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) st[lane * SS + i] = arow[32 * h + i];
+        for (int i = 0; i < 16; ++i) st[lane * SS + i] = arow[16 * h + i];
 #pragma unroll 4
-        for (int it = 0; it < 32; ++it) {
-            const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
+        for (int it = 0; it < 16; ++it) {
+            const int rr = 4 * it + (lane >> 4), c = 16 * h + (lane & 15);
             const int pr = wrow0 + rr;
-            if (pr < m && pr >= nt && c < jb) Ap[static_cast<int64_t>(pr) * lda + c] = st[rr * SS + (lane & 31)];
+            if (pr < m && pr >= nt && c < jb) Ap[static_cast<int64_t>(pr) * lda + c] = st[rr * SS + (lane & 15)];
         }
     }
 }
 
 template <typename T>
 constexpr size_t chol_panel_smem() {
-    return sizeof(T) * (CPW * (CPW + 1) + 2 * CPW + CPW + 4 * 64 * 33) + 64;
+    return sizeof(T) * (CPW * (CPW + 1) + 2 * CPW + CPW + 4 * 64 * 17) + 64;
 }
 
 // y[c] = alpha * sum_r M[r][c] x[r] + beta * y[c]  (M is nr x nc row-major): the transposed GEMV of
@@ -309,31 +311,62 @@ int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
     }
     if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
     int rc;
-    for (int64_t k0 = 0; k0 < n; k0 += CNB) {
+    // One outer panel: 64-column sub-panels, each followed by the NT update of the rest of the panel.
+    auto factor_panel = [&](int64_t k0, hipStream_t s) -> int {
         const int64_t kb = (n - k0 < CNB) ? n - k0 : CNB;
         for (int64_t j0 = k0; j0 < k0 + kb; j0 += CPW) {
             const int64_t jb = (k0 + kb - j0 < CPW) ? k0 + kb - j0 : CPW;
             const int64_t m = n - j0;
             hipLaunchKernelGGL((chol_panel_kernel<T>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
-                               dim3(256), chol_panel_smem<T>(), st, A, lda, j0, static_cast<int>(m),
+                               dim3(256), chol_panel_smem<T>(), s, A, lda, j0, static_cast<int>(m),
                                static_cast<int>(jb), info);
             SSA_RETURN_IF_LAUNCH_FAILED();
             const int64_t rest = (k0 + kb) - (j0 + jb);
             const int64_t mm = n - (j0 + jb);
             if (rest > 0 && mm > 0) {
                 const T *P = A + (j0 + jb) * lda + j0;  // rows below the sub-panel, its 64 columns
-                rc = gemm_op_t(0, 1, 0, mm, rest, jb, -1.0, P, lda, P, lda, 1.0,
-                               A + (j0 + jb) * lda + (j0 + jb), lda, st);
-                if (rc != SSA_OK) return rc;
+                const int r2 = gemm_op_t(0, 1, 0, mm, rest, jb, -1.0, P, lda, P, lda, 1.0,
+                                         A + (j0 + jb) * lda + (j0 + jb), lda, s);
+                if (r2 != SSA_OK) return r2;
             }
         }
-        const int64_t right = n - k0 - kb;
-        if (right > 0) {
-            const T *P = A + (k0 + kb) * lda + k0;
-            rc = gemm_op_t(0, 1, 1, right, right, kb, -1.0, P, lda, P, lda, 1.0,
-                           A + (k0 + kb) * lda + (k0 + kb), lda, st);
+        return SSA_OK;
+    };
+    // Look-ahead: the trailing update of panel k is split into the 256-column strip that panel k+1
+    // needs (done first) and the rest; panel k+1 is then factored on a high-priority side stream
+    // WHILE the rest of update k runs on the caller's stream.  The panel kernels are latency bound
+    // and small (70 KB LDS), so they slot in beside the MFMA workgroups.
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_strip = nullptr, ev_panel = nullptr;
+    if (side == nullptr) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_strip, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming) != hipSuccess)
+            return SSA_ERR_HIP;
+    }
+    rc = factor_panel(0, st);
+    if (rc != SSA_OK) return rc;
+    for (int64_t k0 = 0; k0 + CNB < n; k0 += CNB) {
+        const int64_t right = n - k0 - CNB;               // order of the trailing matrix
+        const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
+        const T *P = A + (k0 + CNB) * lda + k0;           // panel k below its diagonal block
+        T *C = A + (k0 + CNB) * lda + (k0 + CNB);
+        rc = gemm_op_t(0, 1, 0, right, nw, CNB, -1.0, P, lda, P, lda, 1.0, C, lda, st);  // strip
+        if (rc != SSA_OK) return rc;
+        if (hipEventRecord(ev_strip, st) != hipSuccess || hipStreamWaitEvent(side, ev_strip, 0) != hipSuccess)
+            return SSA_ERR_HIP;
+        rc = factor_panel(k0 + CNB, side);
+        if (rc != SSA_OK) return rc;
+        if (hipEventRecord(ev_panel, side) != hipSuccess) return SSA_ERR_HIP;
+        if (right > nw) {  // rest of the trailing update: lower tiles of the (right - nw) block
+            const T *P2 = P + nw * lda;
+            rc = gemm_op_t(0, 1, 1, right - nw, right - nw, CNB, -1.0, P2, lda, P2, lda, 1.0,
+                           C + nw * lda + nw, lda, st);
             if (rc != SSA_OK) return rc;
         }
+        if (hipStreamWaitEvent(st, ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
     }
     // aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch)
     const int64_t nblk = ceil_div(n, SNB);
