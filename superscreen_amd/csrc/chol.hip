@@ -159,9 +159,13 @@ __device__ __forceinline__ void chol_fwd_all(T (&a)[CPW], const T *Ut, const T *
     ((Js < jb ? chol_fwd_step<T, Js>(a, Ut, rdiag) : (void)0), ...);
 }
 
-template <typename T>
+// MODE 0: fused (every workgroup factors the diagonal block, then substitutes its rows);
+// MODE 1: diagonal block only (one workgroup; L11 -> A, L11^T and 1/diag -> `scratch`);
+// MODE 2: rows only (L11^T and 1/diag come from `scratch`).  The split form keeps the many row
+// workgroups short, which matters when they have to find room beside a running trailing update.
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int64_t j0, int m, int jb,
-                                                         int32_t *info) {
+                                                         int32_t *info, T *scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TS = CPW + 1, SS = 16 + 1;
     T *Ut = reinterpret_cast<T *>(smem_raw);       // [64][TS]: first the block itself, then L11^T
@@ -173,7 +177,16 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int6
     const int row_base = g * kCholRows;
     const int nt = min(CPW, m);
     T *Ap = A + j0 * lda + j0;
+    // This kernel is a chain of short dependent steps and usually shares its SIMDs with the MFMA
+    // waves of the trailing update (look-ahead): ask the instruction arbiter to serve it first.
+    __builtin_amdgcn_s_setprio(3);
 
+    if (MODE == 2) {
+        for (int e = tid; e < CPW * TS + CPW; e += 256) {
+            if (e < CPW * TS) Ut[e] = scratch[e];
+            else rdiag[e - CPW * TS] = scratch[e];
+        }
+    } else {
     for (int rr = wave; rr < CPW; rr += 4)
         Ut[rr * TS + lane] = (rr < nt && lane < jb) ? Ap[static_cast<int64_t>(rr) * lda + lane] : T(0);
     __syncthreads();
@@ -210,6 +223,13 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int6
             if (r < nt && c <= r && c < jb) Ap[static_cast<int64_t>(r) * lda + c] = v[i];
         }
     }
+    if (MODE == 1) {
+        __syncthreads();
+        for (int e = tid; e < CPW * TS + CPW; e += 256)
+            scratch[e] = (e < CPW * TS) ? Ut[e] : rdiag[e - CPW * TS];
+        return;
+    }
+    }  // MODE != 2
     __syncthreads();
 
     // rows below the block: HBM -> (LDS transpose, 16 columns at a time: 35 KB of staging keeps the
@@ -303,7 +323,7 @@ template <typename T>
 int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_panel_kernel<T>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_panel_kernel<T, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(chol_panel_smem<T>())) != hipSuccess)
             return SSA_ERR_HIP;
@@ -311,15 +331,18 @@ int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
     }
     if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
     int rc;
+    T *scratch = aux + ceil_div(n, SNB) * SNB * SNB + 512 * 512;  // L11^T + 1/diag of the current sub-panel
     // One outer panel: 64-column sub-panels, each followed by the NT update of the rest of the panel.
     auto factor_panel = [&](int64_t k0, hipStream_t s) -> int {
         const int64_t kb = (n - k0 < CNB) ? n - k0 : CNB;
         for (int64_t j0 = k0; j0 < k0 + kb; j0 += CPW) {
             const int64_t jb = (k0 + kb - j0 < CPW) ? k0 + kb - j0 : CPW;
             const int64_t m = n - j0;
-            hipLaunchKernelGGL((chol_panel_kernel<T>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
+            // fused form (MODE 0); the split form (MODE 1 + 2) measured the same under look-ahead,
+            // where the f64 VALU chain is slowed by the co-resident f64 MFMA waves either way
+            hipLaunchKernelGGL((chol_panel_kernel<T, 0>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
                                dim3(256), chol_panel_smem<T>(), s, A, lda, j0, static_cast<int>(m),
-                               static_cast<int>(jb), info);
+                               static_cast<int>(jb), info, scratch);
             SSA_RETURN_IF_LAUNCH_FAILED();
             const int64_t rest = (k0 + kb) - (j0 + jb);
             const int64_t mm = n - (j0 + jb);
@@ -447,7 +470,8 @@ using namespace ssa;
 
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
     const int64_t np = ceil_div(n, CNB) * CNB;
-    return (static_cast<size_t>(ceil_div(np, SNB)) * SNB * SNB + 512 * 512) * (dtype == SSA_F64 ? 8 : 4);
+    return (static_cast<size_t>(ceil_div(np, SNB)) * SNB * SNB + 512 * 512 + 2 * CPW * (CPW + 2)) *
+           (dtype == SSA_F64 ? 8 : 4);
 }
 
 extern "C" int64_t ssa_chol_padded_n(int64_t n) { return ceil_div(n, CNB) * CNB; }
