@@ -183,7 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = {}
     for kind, label in ((0, "ssa::gemm_kernel<double, true> (NN: LU trailing / in-panel updates)"),
-                        (1, "ssa::gemm_op_kernel<double, 0, 1> lower (SYRK: Cholesky trailing update)")):
+                        (1, "ssa::gemm_op_kernel<double, 0, 1, true> (SYRK on the lower tiles: Cholesky trailing update)")):
         ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
         _hip.check(lib.ssa_profile_read(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)),
                    "ssa_profile_read")

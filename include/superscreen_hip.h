@@ -149,12 +149,21 @@ int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *
  *                    info [1] int32 (device): 0, or > 0 if a pivot was not positive (then the
  *                    caller must fall back to ssa_lu_factor on a freshly assembled -A).
  *                    aux: ssa_chol_aux_bytes(n, dtype) (inverses of the diagonal blocks of L).
+ *   ssa_chol_factor_batch: the films of one device (factorize_linear_systems loops over them,
+ *                    solver/solve_film.py:174) factored in ONE interleaved schedule: all MFMA
+ *                    trailing updates round-robin on the caller's stream, every film's panel
+ *                    chain on its own internal side stream, hidden behind the other films'
+ *                    updates.  A, n, lda, info, aux: HOST arrays of `count` entries with the
+ *                    per-matrix arguments of ssa_chol_factor.  Results identical to `count`
+ *                    separate ssa_chol_factor calls.
  *   ssa_chol_solve:  L L^T X = B in place, nrhs >= 1; workspace ssa_chol_solve_workspace_bytes.
  */
 int64_t ssa_chol_padded_n(int64_t n);
 size_t ssa_chol_aux_bytes(int64_t n, int dtype);
 int ssa_chol_factor(void *S, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,
                     void *stream);
+int ssa_chol_factor_batch(int count, void *const *S, const int64_t *n, const int64_t *lda,
+                          int32_t *const *info, void *const *aux, int dtype, void *stream);
 size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
 int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
                    int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, void *stream);

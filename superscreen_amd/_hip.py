@@ -37,6 +37,7 @@ SIGNATURES = {
     "ssa_chol_padded_n": (c_int64, [I64]),
     "ssa_chol_aux_bytes": (c_size_t, [I64, c_int]),
     "ssa_chol_factor": (c_int, [P, I64, I64, P, P, c_int, P]),
+    "ssa_chol_factor_batch": (c_int, [c_int, P, P, P, P, P, c_int, P]),
     "ssa_chol_solve_workspace_bytes": (c_size_t, [I64, I64, c_int]),
     "ssa_chol_solve": (c_int, [P, I64, I64, P, P, I64, I64, c_int, P, c_size_t, P]),
     "ssa_gemm_ex": (c_int, [c_int, c_int, c_int, I64, I64, I64, c_double, P, I64, P, I64, c_double,

@@ -16,6 +16,7 @@
 // K = 256, 64-column sub-panels factored by a register-resident, fully unrolled kernel
 // (diagonal block per workgroup in registers, the rows below forward-substituted one row per
 // thread), in-panel updates by the NT GEMM.
+#include <mutex>
 #include <utility>
 
 #include "common.hpp"
@@ -319,79 +320,74 @@ int gemv_trans(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y
     return SSA_OK;
 }
 
+// One side stream + two events per concurrently factored matrix (look-ahead lanes).
+struct CholLane {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_strip = nullptr, ev_panel = nullptr;
+};
+constexpr int kMaxLanes = 16;
+
+inline int get_lanes(int count, CholLane **out) {
+    static CholLane lanes[kMaxLanes];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
+    for (int i = 0; i < count; ++i) {
+        if (lanes[i].side != nullptr) continue;
+        if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_strip, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess)
+            return SSA_ERR_HIP;
+    }
+    *out = lanes;
+    return SSA_OK;
+}
+
 template <typename T>
-int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_panel_kernel<T, 0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(chol_panel_smem<T>())) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
+struct CholJob {
+    T *A;
+    int64_t n, lda;
+    int32_t *info;
+    T *aux;
+};
+
+// One outer panel of one matrix: 64-column sub-panels, each followed by the NT update of the
+// rest of the panel.  `scratch` = L11^T + 1/diag of the current sub-panel.
+template <typename T>
+int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
+    T *A = J.A;
+    const int64_t n = J.n, lda = J.lda;
+    T *scratch = J.aux + ceil_div(n, SNB) * SNB * SNB + 512 * 512;
+    const int64_t kb = (n - k0 < CNB) ? n - k0 : CNB;
+    for (int64_t j0 = k0; j0 < k0 + kb; j0 += CPW) {
+        const int64_t jb = (k0 + kb - j0 < CPW) ? k0 + kb - j0 : CPW;
+        const int64_t m = n - j0;
+        // fused form (MODE 0); the split form (MODE 1 + 2) measured the same under look-ahead,
+        // where the f64 VALU chain is slowed by the co-resident f64 MFMA waves either way
+        hipLaunchKernelGGL((chol_panel_kernel<T, 0>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
+                           dim3(256), chol_panel_smem<T>(), s, A, lda, j0, static_cast<int>(m),
+                           static_cast<int>(jb), J.info, scratch);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        const int64_t rest = (k0 + kb) - (j0 + jb);
+        const int64_t mm = n - (j0 + jb);
+        if (rest > 0 && mm > 0) {
+            const T *P = A + (j0 + jb) * lda + j0;  // rows below the sub-panel, its 64 columns
+            const int r2 = gemm_op_t(0, 1, 0, mm, rest, jb, -1.0, P, lda, P, lda, 1.0,
+                                     A + (j0 + jb) * lda + (j0 + jb), lda, s);
+            if (r2 != SSA_OK) return r2;
+        }
     }
-    if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
+    return SSA_OK;
+}
+
+// aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch)
+template <typename T>
+int chol_build_inverses(const CholJob<T> &J, hipStream_t st) {
+    const T *A = J.A;
+    T *aux = J.aux;
+    const int64_t n = J.n, lda = J.lda;
     int rc;
-    T *scratch = aux + ceil_div(n, SNB) * SNB * SNB + 512 * 512;  // L11^T + 1/diag of the current sub-panel
-    // One outer panel: 64-column sub-panels, each followed by the NT update of the rest of the panel.
-    auto factor_panel = [&](int64_t k0, hipStream_t s) -> int {
-        const int64_t kb = (n - k0 < CNB) ? n - k0 : CNB;
-        for (int64_t j0 = k0; j0 < k0 + kb; j0 += CPW) {
-            const int64_t jb = (k0 + kb - j0 < CPW) ? k0 + kb - j0 : CPW;
-            const int64_t m = n - j0;
-            // fused form (MODE 0); the split form (MODE 1 + 2) measured the same under look-ahead,
-            // where the f64 VALU chain is slowed by the co-resident f64 MFMA waves either way
-            hipLaunchKernelGGL((chol_panel_kernel<T, 0>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
-                               dim3(256), chol_panel_smem<T>(), s, A, lda, j0, static_cast<int>(m),
-                               static_cast<int>(jb), info, scratch);
-            SSA_RETURN_IF_LAUNCH_FAILED();
-            const int64_t rest = (k0 + kb) - (j0 + jb);
-            const int64_t mm = n - (j0 + jb);
-            if (rest > 0 && mm > 0) {
-                const T *P = A + (j0 + jb) * lda + j0;  // rows below the sub-panel, its 64 columns
-                const int r2 = gemm_op_t(0, 1, 0, mm, rest, jb, -1.0, P, lda, P, lda, 1.0,
-                                         A + (j0 + jb) * lda + (j0 + jb), lda, s);
-                if (r2 != SSA_OK) return r2;
-            }
-        }
-        return SSA_OK;
-    };
-    // Look-ahead: the trailing update of panel k is split into the 256-column strip that panel k+1
-    // needs (done first) and the rest; panel k+1 is then factored on a high-priority side stream
-    // WHILE the rest of update k runs on the caller's stream.  The panel kernels are latency bound
-    // and small (70 KB LDS), so they slot in beside the MFMA workgroups.
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_strip = nullptr, ev_panel = nullptr;
-    if (side == nullptr) {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
-        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_strip, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming) != hipSuccess)
-            return SSA_ERR_HIP;
-    }
-    rc = factor_panel(0, st);
-    if (rc != SSA_OK) return rc;
-    for (int64_t k0 = 0; k0 + CNB < n; k0 += CNB) {
-        const int64_t right = n - k0 - CNB;               // order of the trailing matrix
-        const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
-        const T *P = A + (k0 + CNB) * lda + k0;           // panel k below its diagonal block
-        T *C = A + (k0 + CNB) * lda + (k0 + CNB);
-        rc = gemm_op_t(0, 1, 0, right, nw, CNB, -1.0, P, lda, P, lda, 1.0, C, lda, st);  // strip
-        if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ev_strip, st) != hipSuccess || hipStreamWaitEvent(side, ev_strip, 0) != hipSuccess)
-            return SSA_ERR_HIP;
-        rc = factor_panel(k0 + CNB, side);
-        if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ev_panel, side) != hipSuccess) return SSA_ERR_HIP;
-        if (right > nw) {  // rest of the trailing update: lower tiles of the (right - nw) block
-            const T *P2 = P + nw * lda;
-            rc = gemm_op_t(0, 1, 1, right - nw, right - nw, CNB, -1.0, P2, lda, P2, lda, 1.0,
-                           C + nw * lda + nw, lda, st);
-            if (rc != SSA_OK) return rc;
-        }
-        if (hipStreamWaitEvent(st, ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
-    }
-    // aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch)
     const int64_t nblk = ceil_div(n, SNB);
     if (hipMemsetAsync(aux, 0, static_cast<size_t>(nblk) * SNB * SNB * sizeof(T), st) != hipSuccess)
         return SSA_ERR_HIP;
@@ -409,14 +405,89 @@ int potrf(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
         }
     }
     if (n % 256 != 0) {  // the last, partial leaf
-        const int64_t r0 = n / 256 * 256, J = r0 / SNB, off = r0 - J * SNB;
+        const int64_t r0 = n / 256 * 256, Jb = r0 / SNB, off = r0 - Jb * SNB;
         rc = trtri_batched_t(A + r0 * (lda + 1), lda, 0, static_cast<int>(n - r0),
-                             aux + J * SNB * SNB + off * (SNB + 1), static_cast<int64_t>(SNB), 0, 1, st);
+                             aux + Jb * SNB * SNB + off * (SNB + 1), static_cast<int64_t>(SNB), 0, 1, st);
         if (rc != SSA_OK) return rc;
     }
     for (int64_t k = 0; k < nblk; ++k) {
         const int64_t r0 = k * SNB, sz = (n - r0 < SNB) ? n - r0 : SNB;
         rc = build_block_inverse(A, lda, r0, sz, aux + k * SNB * SNB, static_cast<int64_t>(SNB), tmp, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
+// Factor `count` independent matrices (the films of a device) in one interleaved schedule.
+//
+// Every MFMA trailing update (SYRK) of every matrix goes to the caller's stream, round-robin over
+// the matrices, so the updates never compete with each other for the chip.  The latency-bound
+// panel chain of matrix i runs on its own high-priority side stream: panel k+1 of matrix i is
+// factored while the rest of update k of matrix i AND the updates of the other matrices run.
+// With one matrix this is plain look-ahead (the chain is then the critical path for n ~ 20k);
+// with two or more the chains hide behind the other films' updates.
+//
+// Per matrix and outer step k:   strip   C[:, 0:256]   -= P P[0:256]^T       (caller's stream)
+//                                panel k+1 factored                           (side stream, after strip)
+//                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream)
+template <typename T>
+int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_panel_kernel<T, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(chol_panel_smem<T>())) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
+    CholLane *lanes = nullptr;
+    int rc = get_lanes(count, &lanes);
+    if (rc != SSA_OK) return rc;
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const CholJob<T> &J = jobs[i];
+        CholLane &ln = lanes[i];
+        if (J.n > nmax) nmax = J.n;
+        if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
+        // fork: the side stream starts after everything enqueued so far on the caller's stream
+        if (hipEventRecord(ln.ev_strip, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
+            return SSA_ERR_HIP;
+        rc = chol_factor_panel(J, 0, ln.side);
+        if (rc != SSA_OK) return rc;
+        if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+    }
+    for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
+        for (int i = 0; i < count; ++i) {
+            const CholJob<T> &J = jobs[i];
+            CholLane &ln = lanes[i];
+            if (k0 + CNB >= J.n) continue;
+            const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
+            const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
+            const T *P = J.A + (k0 + CNB) * J.lda + k0;       // panel k below its diagonal block
+            T *C = J.A + (k0 + CNB) * J.lda + (k0 + CNB);
+            if (hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
+            rc = gemm_op_t(0, 1, 0, right, nw, CNB, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, st);  // strip
+            if (rc != SSA_OK) return rc;
+            if (hipEventRecord(ln.ev_strip, st) != hipSuccess ||
+                hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
+                return SSA_ERR_HIP;
+            rc = chol_factor_panel(J, k0 + CNB, ln.side);
+            if (rc != SSA_OK) return rc;
+            if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+            if (right > nw) {  // rest of the trailing update: lower tiles of the (right - nw) block
+                const T *P2 = P + nw * J.lda;
+                rc = gemm_op_t(0, 1, 1, right - nw, right - nw, CNB, -1.0, P2, J.lda, P2, J.lda, 1.0,
+                               C + nw * J.lda + nw, J.lda, st);
+                if (rc != SSA_OK) return rc;
+            }
+        }
+    }
+    for (int i = 0; i < count; ++i) {  // join, then the inverses of the diagonal blocks
+        if (hipStreamWaitEvent(st, lanes[i].ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+    }
+    for (int i = 0; i < count; ++i) {
+        rc = chol_build_inverses(jobs[i], st);
         if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
@@ -487,15 +558,21 @@ __global__ void pad_identity_kernel(T *A, int64_t lda, int64_t n, int64_t np) {
     if (c < np) A[r * lda + c] = (c == r) ? T(1) : T(0);
 }
 template <typename T>
-int potrf_padded(T *A, int64_t n, int64_t lda, int32_t *info, T *aux, hipStream_t st) {
-    const int64_t np = ssa_chol_padded_n(n);
-    if (np > n) {
-        hipLaunchKernelGGL((pad_identity_kernel<T>), dim3(static_cast<unsigned>(ceil_div(np, 256)),
-                                                          static_cast<unsigned>(np - n)),
-                           dim3(256), 0, st, A, lda, n, np);
-        SSA_RETURN_IF_LAUNCH_FAILED();
+int potrf_padded_batch(int count, void *const *A, const int64_t *n, const int64_t *lda, int32_t *const *info,
+                       void *const *aux, hipStream_t st) {
+    CholJob<T> jobs[kMaxLanes];
+    for (int i = 0; i < count; ++i) {
+        const int64_t np = ssa_chol_padded_n(n[i]);
+        T *Ai = static_cast<T *>(A[i]);
+        if (np > n[i]) {
+            hipLaunchKernelGGL((pad_identity_kernel<T>), dim3(static_cast<unsigned>(ceil_div(np, 256)),
+                                                              static_cast<unsigned>(np - n[i])),
+                               dim3(256), 0, st, Ai, lda[i], n[i], np);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+        }
+        jobs[i] = CholJob<T>{Ai, np, lda[i], info[i], static_cast<T *>(aux[i])};
     }
-    return potrf<T>(A, np, lda, info, aux, st);
+    return potrf_batch<T>(jobs, count, st);
 }
 template <typename T>
 int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb,
@@ -517,16 +594,29 @@ int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t
 }  // namespace
 }  // namespace ssa
 
+extern "C" int ssa_chol_factor_batch(int count, void *const *A, const int64_t *n, const int64_t *lda,
+                                     int32_t *const *info, void *const *aux, int dtype, void *stream) {
+    if (count <= 0 || !A || !n || !lda || !info || !aux) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < count; ++i)
+        if (!A[i] || !info[i] || !aux[i] || n[i] <= 0 || lda[i] < ssa_chol_padded_n(n[i]))
+            return SSA_ERR_INVALID_ARGUMENT;
+    // more matrices than look-ahead lanes: groups of kMaxLanes, one after the other
+    for (int first = 0; first < count; first += kMaxLanes) {
+        const int c = (count - first < kMaxLanes) ? count - first : kMaxLanes;
+        const int rc = (dtype == SSA_F64)
+                           ? potrf_padded_batch<double>(c, A + first, n + first, lda + first, info + first,
+                                                        aux + first, as_stream(stream))
+                           : potrf_padded_batch<float>(c, A + first, n + first, lda + first, info + first,
+                                                       aux + first, as_stream(stream));
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
 extern "C" int ssa_chol_factor(void *A, int64_t n, int64_t lda, int32_t *info, void *aux, int dtype,
                                void *stream) {
-    if (!A || !info || !aux || n <= 0 || lda < ssa_chol_padded_n(n)) return SSA_ERR_INVALID_ARGUMENT;
-    if (dtype == SSA_F64)
-        return potrf_padded<double>(static_cast<double *>(A), n, lda, info, static_cast<double *>(aux),
-                                    as_stream(stream));
-    if (dtype == SSA_F32)
-        return potrf_padded<float>(static_cast<float *>(A), n, lda, info, static_cast<float *>(aux),
-                                   as_stream(stream));
-    return SSA_ERR_INVALID_ARGUMENT;
+    return ssa_chol_factor_batch(1, &A, &n, &lda, &info, &aux, dtype, stream);
 }
 
 extern "C" size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype) {

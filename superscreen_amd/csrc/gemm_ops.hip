@@ -223,14 +223,16 @@ __device__ __forceinline__ void tile_edge(int64_t M, int64_t N, int64_t K, T alp
     }
 }
 
-template <typename T, int TA, int TB>
+// LOWER is a template parameter so that the SYRK-shaped launches carry their own symbol in
+// rocprofv3's kernel statistics (profiles/), apart from the skinny in-panel updates.
+template <typename T, int TA, int TB, bool LOWER>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
     const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
-    int64_t ntn, int lower, int aligned) {
+    int64_t ntn, int aligned) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int64_t tm, tn;
-    if (lower) {
+    if constexpr (LOWER) {
         // lower-triangular tile enumeration: id -> (tm, tn <= tm), row by row
         const int64_t id = xcd_contiguous(blockIdx.x, gridDim.x);
         tm = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5);
@@ -258,9 +260,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     }
 }
 
-template <typename T, int TA, int TB>
-int launch_op(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B,
-              int64_t ldb, double beta, T *C, int64_t ldc, int lower, hipStream_t st) {
+template <typename T, int TA, int TB, bool LOWER>
+int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B,
+                int64_t ldb, double beta, T *C, int64_t ldc, hipStream_t st) {
+    constexpr int lower = LOWER ? 1 : 0;
     if (M <= 0 || N <= 0) return SSA_OK;
     if (lower && M != N) return SSA_ERR_INVALID_ARGUMENT;
     const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
@@ -270,22 +273,29 @@ int launch_op(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t
     const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB, LOWER>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(smem)) != hipSuccess)
             return SSA_ERR_HIP;
         attr_set = true;
     }
-    // algorithmic flops of what is actually computed (lower: the tiles on/below the diagonal)
-    const double flops = 2.0 * static_cast<double>(K) * (lower ? 0.5 * static_cast<double>(M) * (M + BM)
+    // algorithmic flops (lower: the M (M + 1) / 2 entries on/below the diagonal)
+    const double flops = 2.0 * static_cast<double>(K) * (lower ? 0.5 * static_cast<double>(M) * (M + 1)
                                                                 : static_cast<double>(M) * N);
     ProfileScope scope(aligned && sizeof(T) == 8 && lower && TA == OP_N && TB == OP_T, kProfileSyrkLower,
                        flops, st);
-    hipLaunchKernelGGL((gemm_op_kernel<T, TA, TB>), dim3(static_cast<unsigned>(nwg)), dim3(kGemmThreads),
-                       smem, st, M, N, K, static_cast<T>(alpha), A, lda, B, ldb, static_cast<T>(beta), C,
-                       ldc, ntm, ntn, lower, aligned);
+    hipLaunchKernelGGL((gemm_op_kernel<T, TA, TB, LOWER>), dim3(static_cast<unsigned>(nwg)),
+                       dim3(kGemmThreads), smem, st, M, N, K, static_cast<T>(alpha), A, lda, B, ldb,
+                       static_cast<T>(beta), C, ldc, ntm, ntn, aligned);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
+}
+
+template <typename T, int TA, int TB>
+int launch_op(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B,
+              int64_t ldb, double beta, T *C, int64_t ldc, int lower, hipStream_t st) {
+    if (lower) return launch_op_l<T, TA, TB, true>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+    return launch_op_l<T, TA, TB, false>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
 }
 
 template <typename T>

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -81,15 +81,21 @@ def system_assemble(xy, w, qdiag, Lambda, lap_indptr, lap_indices, lap_data, row
     return out
 
 
-@dataclass
 class CholFactors:
-    """Device-resident result of :func:`chol_factor`: ``S = L L^T`` (lower triangle of ``L``)."""
+    """Device-resident result of :func:`chol_factor`: ``S = L L^T`` (lower triangle of ``L``).
+    ``info`` (LAPACK ?potrf convention) is fetched from the device on first access, so several
+    factorizations can be enqueued before the host waits for any of them."""
 
-    L: torch.Tensor
-    n: int
-    aux: torch.Tensor
-    info: int
-    dtype: torch.dtype
+    def __init__(self, L: torch.Tensor, n: int, aux: torch.Tensor, info_device: torch.Tensor):
+        self.L, self.n, self.aux, self.info_device = L, n, aux, info_device
+        self.dtype = L.dtype
+        self._info: Optional[int] = None
+
+    @property
+    def info(self) -> int:
+        if self._info is None:
+            self._info = int(self.info_device.item())
+        return self._info
 
     @property
     def lda(self) -> int:
@@ -101,18 +107,37 @@ def chol_padded_n(n: int) -> int:
     return int(load_library().ssa_chol_padded_n(n))
 
 
+def chol_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[CholFactors]:
+    """In-place Cholesky of several symmetric positive definite matrices ``(S, n)`` (the films
+    of a device) in one interleaved schedule (``ssa_chol_factor_batch``)."""
+    import ctypes
+
+    lib = load_library()
+    count = len(systems)
+    if count == 0:
+        return []
+    dt = dtype_code(systems[0][0].dtype)
+    out = []
+    for S, n in systems:
+        if S.shape[0] < chol_padded_n(n) or S.shape[1] < chol_padded_n(n):
+            raise ValueError("chol_factor needs a buffer padded to chol_padded_n(n) rows and columns.")
+        if dtype_code(S.dtype) != dt:
+            raise ValueError("chol_factor_batch: all matrices must have the same dtype.")
+        info = torch.zeros(1, dtype=torch.int32, device=S.device)
+        aux = torch.empty(lib.ssa_chol_aux_bytes(n, dt) // S.element_size(), dtype=S.dtype, device=S.device)
+        out.append(CholFactors(S, n, aux, info))
+    PtrArr, I64Arr = ctypes.c_void_p * count, ctypes.c_int64 * count
+    check(lib.ssa_chol_factor_batch(
+        count, PtrArr(*[f.L.data_ptr() for f in out]), I64Arr(*[f.n for f in out]),
+        I64Arr(*[f.lda for f in out]), PtrArr(*[f.info_device.data_ptr() for f in out]),
+        PtrArr(*[f.aux.data_ptr() for f in out]), dt, current_stream()), "ssa_chol_factor_batch")
+    return out
+
+
 def chol_factor(S: torch.Tensor, n: int) -> CholFactors:
     """In-place Cholesky of the symmetric positive definite ``S`` (lower triangle given in the
     leading ``n x n`` part of a ``[chol_padded_n(n), lda >= chol_padded_n(n)]`` buffer)."""
-    lib = load_library()
-    if S.shape[0] < chol_padded_n(n) or S.shape[1] < chol_padded_n(n):
-        raise ValueError("chol_factor needs a buffer padded to chol_padded_n(n) rows and columns.")
-    dt = dtype_code(S.dtype)
-    info = torch.zeros(1, dtype=torch.int32, device=S.device)
-    aux = torch.empty(lib.ssa_chol_aux_bytes(n, dt) // S.element_size(), dtype=S.dtype, device=S.device)
-    check(lib.ssa_chol_factor(ptr(S), n, S.shape[1], ptr(info), ptr(aux), dt, current_stream()),
-          "ssa_chol_factor")
-    return CholFactors(L=S, n=n, aux=aux, info=int(info.item()), dtype=S.dtype)
+    return chol_factor_batch([(S, n)])[0]
 
 
 def chol_solve(f: CholFactors, B: torch.Tensor) -> torch.Tensor:

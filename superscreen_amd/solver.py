@@ -261,6 +261,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     _hip.require_gpu()
     dtype = device.solve_dtype
     film_systems, hole_systems, film_data = {}, {}, {}
+    pending = []
     for name, info in film_info_dict.items():
         if info.lambda_info.inhomogeneous:
             raise NotImplementedError(
@@ -298,7 +299,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             return factors
 
         host_A = lambda ix_d=ix_d, ni=ni, assemble=assemble: assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy()  # noqa: E731
-        system = None
+        S = None
         if method in ("auto", "cholesky"):
             # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
             # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
@@ -306,7 +307,16 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
                                         dtype=dtype, row_scale=fd.w, lower_only=True,
                                         ld=kernels.padded_ld(npad, dtype), alloc_rows=npad)
-            chol = kernels.chol_factor(S, ni)
+        pending.append((name, interior, ix_d, ni, S, lu_route, host_A, fd))
+    # All films are factored in one interleaved schedule (ssa_chol_factor_batch): the MFMA
+    # trailing updates of the films alternate on the stream, each film's panel chain hides behind
+    # the other films' updates.
+    with_S = [p for p in pending if p[4] is not None]
+    chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S])))
+    for name, interior, ix_d, ni, S, lu_route, host_A, fd in pending:
+        system = None
+        chol = chols.get(name)
+        if chol is not None:
             if chol.info == 0:
                 system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,
                                       neg_w_device=(-fd.w_t[ix_d]).contiguous(),
@@ -315,6 +325,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
                 if method == "cholesky":
                     raise RuntimeError(f"diag(w) A of film {name!r} is not positive definite.")
                 logger.warning(f"Film {name!r}: Cholesky pivot not positive, falling back to LU.")
+                del chols[name]
                 del S, chol
         if system is None:
             factors = lu_route()
