@@ -19,6 +19,7 @@
 #include <mutex>
 #include <utility>
 
+#include "chol_diag.hpp"
 #include "common.hpp"
 
 namespace ssa {
@@ -46,7 +47,6 @@ namespace {
 
 constexpr int CNB = 256;  // outer panel
 constexpr int CPW = 64;   // sub-panel
-constexpr int kCholRows = 256;
 
 inline int gemm_op_t(int oa, int ob, int lower, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
                      int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
@@ -101,174 +101,6 @@ int build_block_inverse(const T *L, int64_t lda, int64_t r0, int64_t sz, T *inv,
     rc = gemm_nn_t(sz - h, h, h, 1.0, L + (r0 + h) * lda + r0, lda, inv, ldi, 0.0, tmp, 512, st);
     if (rc != SSA_OK) return rc;
     return gemm_nn_t(sz - h, h, sz - h, -1.0, inv + h * ldi + h, ldi, tmp, 512, 0.0, inv + h * ldi, ldi, st);
-}
-
-__device__ __forceinline__ double rsqrt_t(double x) { return rsqrt_f64(x); }
-__device__ __forceinline__ float rsqrt_t(float x) {
-    float y = __builtin_amdgcn_rsqf(x);
-    return y * (1.5f - 0.5f * x * y * y);
-}
-
-template <int S>
-__device__ __forceinline__ int cquad_i32(int x) {
-    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
-    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
-}
-
-// One column of the register-tiled 64 x 64 Cholesky: thread (r, q) holds a[r][q + 4 i].
-template <typename T, int J>
-__device__ __forceinline__ void chol_step(T (&v)[16], int r, int q, T *colbuf, bool &bad) {
-    constexpr int I0 = J >> 2, S = J & 3;
-    T *cb = colbuf + (J & 1) * CPW;
-    if (q == S) cb[r] = v[I0];  // unscaled column J (rows above J publish stale values, never read)
-    __syncthreads();
-    const T d = cb[J];
-    bad = bad || !(d > T(0));
-    const T inv = rsqrt_t(d);
-    const T lr = (r >= J) ? cb[r] * inv : T(0);  // l_rJ (= sqrt(d) for r == J)
-    {   // register column I0: c = q + 4 I0;  c == J <=> q == S,  c > J <=> q > S
-        const int c = q + 4 * I0;
-        const T upd = v[I0] - lr * (cb[c] * inv);
-        v[I0] = (q == S) ? ((r >= J) ? lr : v[I0]) : ((q > S && c <= r) ? upd : v[I0]);
-    }
-#pragma unroll
-    for (int i = I0 + 1; i < 16; ++i) {
-        const int c = q + 4 * i;
-        const T upd = v[i] - lr * (cb[c] * inv);
-        v[i] = (c <= r) ? upd : v[i];
-    }
-}
-template <typename T, int... Js>
-__device__ __forceinline__ void chol_all(T (&v)[16], int r, int q, int nsteps, T *colbuf, bool &bad,
-                                         std::integer_sequence<int, Js...>) {
-    ((Js < nsteps ? chol_step<T, Js>(v, r, q, colbuf, bad) : (void)0), ...);
-}
-
-// row x (in registers) <- row x * inv(L11^T):  x_J = (a_J - sum_{k<J} x_k L11[J][k]) / L11[J][J],
-// right-looking; Ut[J][c] = L11[c][J] is read as an LDS broadcast.
-template <typename T, int J>
-__device__ __forceinline__ void chol_fwd_step(T (&a)[CPW], const T *Ut, const T *rdiag) {
-    constexpr int TS = CPW + 1;
-    const T l = a[J] * rdiag[J];
-    a[J] = l;
-#pragma unroll
-    for (int c = J + 1; c < CPW; ++c) a[c] -= l * Ut[J * TS + c];
-}
-template <typename T, int... Js>
-__device__ __forceinline__ void chol_fwd_all(T (&a)[CPW], const T *Ut, const T *rdiag, int jb,
-                                             std::integer_sequence<int, Js...>) {
-    ((Js < jb ? chol_fwd_step<T, Js>(a, Ut, rdiag) : (void)0), ...);
-}
-
-// MODE 0: fused (every workgroup factors the diagonal block, then substitutes its rows);
-// MODE 1: diagonal block only (one workgroup; L11 -> A, L11^T and 1/diag -> `scratch`);
-// MODE 2: rows only (L11^T and 1/diag come from `scratch`).  The split form keeps the many row
-// workgroups short, which matters when they have to find room beside a running trailing update.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void chol_panel_kernel(T *A, int64_t lda, int64_t j0, int m, int jb,
-                                                         int32_t *info, T *scratch) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TS = CPW + 1, SS = 16 + 1;
-    T *Ut = reinterpret_cast<T *>(smem_raw);       // [64][TS]: first the block itself, then L11^T
-    T *colbuf = Ut + CPW * TS;                      // [2][64]
-    T *rdiag = colbuf + 2 * CPW;                    // [64]
-    T *stage = rdiag + CPW;                         // [4 waves][64][SS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
-    const int row_base = g * kCholRows;
-    const int nt = min(CPW, m);
-    T *Ap = A + j0 * lda + j0;
-    // This kernel is a chain of short dependent steps and usually shares its SIMDs with the MFMA
-    // waves of the trailing update (look-ahead): ask the instruction arbiter to serve it first.
-    __builtin_amdgcn_s_setprio(3);
-
-    if (MODE == 2) {
-        for (int e = tid; e < CPW * TS + CPW; e += 256) {
-            if (e < CPW * TS) Ut[e] = scratch[e];
-            else rdiag[e - CPW * TS] = scratch[e];
-        }
-    } else {
-    for (int rr = wave; rr < CPW; rr += 4)
-        Ut[rr * TS + lane] = (rr < nt && lane < jb) ? Ap[static_cast<int64_t>(rr) * lda + lane] : T(0);
-    __syncthreads();
-    const int r = tid >> 2, q = tid & 3;
-    T v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = Ut[r * TS + q + 4 * i];
-    // rows beyond the block (last, partial sub-panel) get a unit diagonal so that the padding
-    // stays positive definite
-    if (r >= nt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (q + 4 * i == r) ? T(1) : T(0);
-    }
-    bool bad = false;
-    chol_all<T>(v, r, q, min(jb, nt), colbuf, bad, std::make_integer_sequence<int, CPW>{});
-    __syncthreads();
-    // Ut[J][c] = L11[c][J] (c >= J), zero elsewhere; reciprocals of the diagonal
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = q + 4 * i;
-        if (c <= r) Ut[c * TS + r] = v[i];
-    }
-    __syncthreads();
-    if (tid < CPW) {
-        const T d = Ut[tid * TS + tid];
-        rdiag[tid] = (d != T(0)) ? T(1) / d : T(1);
-    }
-    if (g == 0) {
-        if (bad && tid == 0 && *info == 0) *info = static_cast<int32_t>(j0 + 1);
-        // L11 (lower triangle) back to A
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = q + 4 * i;
-            if (r < nt && c <= r && c < jb) Ap[static_cast<int64_t>(r) * lda + c] = v[i];
-        }
-    }
-    if (MODE == 1) {
-        __syncthreads();
-        for (int e = tid; e < CPW * TS + CPW; e += 256)
-            scratch[e] = (e < CPW * TS) ? Ut[e] : rdiag[e - CPW * TS];
-        return;
-    }
-    }  // MODE != 2
-    __syncthreads();
-
-    // rows below the block: HBM -> (LDS transpose, 16 columns at a time: 35 KB of staging keeps the
-    // kernel at 70 KB of LDS so that it can share a CU with a trailing-update workgroup when the
-    // factorization runs panel k+1 beside SYRK k) -> registers -> substitute -> back
-    T *st = stage + wave * 64 * SS;
-    const int wrow0 = row_base + wave * 64;
-    T arow[CPW];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int rr = 4 * it + (lane >> 4), c = 16 * h + (lane & 15);
-            const int pr = wrow0 + rr;
-            T val = T(0);
-            if (pr < m && pr >= nt && c < jb) val = Ap[static_cast<int64_t>(pr) * lda + c];
-            st[rr * SS + (lane & 15)] = val;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) arow[16 * h + i] = st[lane * SS + i];
-    }
-    chol_fwd_all<T>(arow, Ut, rdiag, jb, std::make_integer_sequence<int, CPW>{});
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st[lane * SS + i] = arow[16 * h + i];
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int rr = 4 * it + (lane >> 4), c = 16 * h + (lane & 15);
-            const int pr = wrow0 + rr;
-            if (pr < m && pr >= nt && c < jb) Ap[static_cast<int64_t>(pr) * lda + c] = st[rr * SS + (lane & 15)];
-        }
-    }
-}
-
-template <typename T>
-constexpr size_t chol_panel_smem() {
-    return sizeof(T) * (CPW * (CPW + 1) + 2 * CPW + CPW + 4 * 64 * 17) + 64;
 }
 
 // y[c] = alpha * sum_r M[r][c] x[r] + beta * y[c]  (M is nr x nc row-major): the transposed GEMV of
@@ -352,36 +184,32 @@ struct CholJob {
     T *aux;
 };
 
-// One outer panel of one matrix: 64-column sub-panels, each followed by the NT update of the
-// rest of the panel.  `scratch` = L11^T + 1/diag of the current sub-panel.
+// One outer panel of one matrix: the diagonal-block kernel (L11 and W = L11^-1, chol_diag.hpp),
+// then L21 = A21 W^T as two in-place MFMA GEMMs.  W is lower triangular, so columns 128..255 of L21
+// need all 256 columns of A21 (done first) and columns 0..127 only the first 128; every workgroup
+// reads and writes its own 128 rows, which makes the in-place update safe (beta = 0: C is not read).
+// W lands in the solve-phase buffer: it is the inverted 256-leaf of the SNB block inverses.
 template <typename T>
 int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
-    T *A = J.A;
     const int64_t n = J.n, lda = J.lda;
     T *scratch = J.aux + ceil_div(n, SNB) * SNB * SNB + 512 * 512;
-    const int64_t kb = (n - k0 < CNB) ? n - k0 : CNB;
-    for (int64_t j0 = k0; j0 < k0 + kb; j0 += CPW) {
-        const int64_t jb = (k0 + kb - j0 < CPW) ? k0 + kb - j0 : CPW;
-        const int64_t m = n - j0;
-        // fused form (MODE 0); the split form (MODE 1 + 2) measured the same under look-ahead,
-        // where the f64 VALU chain is slowed by the co-resident f64 MFMA waves either way
-        hipLaunchKernelGGL((chol_panel_kernel<T, 0>), dim3(static_cast<unsigned>(ceil_div(m, kCholRows))),
-                           dim3(256), chol_panel_smem<T>(), s, A, lda, j0, static_cast<int>(m),
-                           static_cast<int>(jb), J.info, scratch);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-        const int64_t rest = (k0 + kb) - (j0 + jb);
-        const int64_t mm = n - (j0 + jb);
-        if (rest > 0 && mm > 0) {
-            const T *P = A + (j0 + jb) * lda + j0;  // rows below the sub-panel, its 64 columns
-            const int r2 = gemm_op_t(0, 1, 0, mm, rest, jb, -1.0, P, lda, P, lda, 1.0,
-                                     A + (j0 + jb) * lda + (j0 + jb), lda, s);
-            if (r2 != SSA_OK) return r2;
-        }
+    T *W = J.aux + (k0 / SNB) * SNB * SNB + (k0 % SNB) * (SNB + 1);
+    hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), 0, s, J.A + k0 * (lda + 1), lda, W,
+                       static_cast<int64_t>(SNB), scratch, J.info, static_cast<int>(k0 + 1));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    const int64_t M = n - k0 - CNB;
+    if (M > 0) {
+        T *A21 = J.A + (k0 + CNB) * lda + k0;
+        int rc = gemm_op_t(0, 1, 0, M, 128, 256, 1.0, A21, lda, W + 128 * SNB, SNB, 0.0, A21 + 128, lda, s);
+        if (rc != SSA_OK) return rc;
+        rc = gemm_op_t(0, 1, 0, M, 128, 128, 1.0, A21, lda, W, SNB, 0.0, A21, lda, s);
+        if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
 }
 
-// aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch)
+// aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch):
+// the off-diagonal quadrants, by recursion on the leaves
 template <typename T>
 int chol_build_inverses(const CholJob<T> &J, hipStream_t st) {
     const T *A = J.A;
@@ -389,27 +217,8 @@ int chol_build_inverses(const CholJob<T> &J, hipStream_t st) {
     const int64_t n = J.n, lda = J.lda;
     int rc;
     const int64_t nblk = ceil_div(n, SNB);
-    if (hipMemsetAsync(aux, 0, static_cast<size_t>(nblk) * SNB * SNB * sizeof(T), st) != hipSuccess)
-        return SSA_ERR_HIP;
     T *tmp = aux + nblk * SNB * SNB;
-    // leaves: the 256 x 256 diagonal blocks, batched by their position s inside the SNB block
-    for (int s = 0; s < SNB / 256; ++s) {
-        const int64_t first = static_cast<int64_t>(s) * 256;  // first leaf of this class
-        if (first >= n) break;
-        const int64_t count_full = (n - first >= 256) ? ((n - first - 256) / SNB + 1) : 0;
-        if (count_full > 0) {
-            rc = trtri_batched_t(A + first * (lda + 1), lda, static_cast<int64_t>(SNB) * (lda + 1), 256,
-                                 aux + first * (SNB + 1), static_cast<int64_t>(SNB),
-                                 static_cast<int64_t>(SNB) * SNB, static_cast<int>(count_full), st);
-            if (rc != SSA_OK) return rc;
-        }
-    }
-    if (n % 256 != 0) {  // the last, partial leaf
-        const int64_t r0 = n / 256 * 256, Jb = r0 / SNB, off = r0 - Jb * SNB;
-        rc = trtri_batched_t(A + r0 * (lda + 1), lda, 0, static_cast<int>(n - r0),
-                             aux + Jb * SNB * SNB + off * (SNB + 1), static_cast<int64_t>(SNB), 0, 1, st);
-        if (rc != SSA_OK) return rc;
-    }
+    // the 256 x 256 leaves were written by the diagonal-block kernels during the factorization
     for (int64_t k = 0; k < nblk; ++k) {
         const int64_t r0 = k * SNB, sz = (n - r0 < SNB) ? n - r0 : SNB;
         rc = build_block_inverse(A, lda, r0, sz, aux + k * SNB * SNB, static_cast<int64_t>(SNB), tmp, st);
@@ -432,14 +241,6 @@ int chol_build_inverses(const CholJob<T> &J, hipStream_t st) {
 //                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream)
 template <typename T>
 int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_panel_kernel<T, 0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(chol_panel_smem<T>())) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
-    }
     if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
     CholLane *lanes = nullptr;
     int rc = get_lanes(count, &lanes);
@@ -448,8 +249,12 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     for (int i = 0; i < count; ++i) {
         const CholJob<T> &J = jobs[i];
         CholLane &ln = lanes[i];
+        if (J.n % CNB != 0) return SSA_ERR_INVALID_ARGUMENT;  // callers pad (potrf_padded_batch)
         if (J.n > nmax) nmax = J.n;
-        if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
+        if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess ||
+            hipMemsetAsync(J.aux, 0, static_cast<size_t>(ceil_div(J.n, SNB)) * SNB * SNB * sizeof(T), st) !=
+                hipSuccess)
+            return SSA_ERR_HIP;
         // fork: the side stream starts after everything enqueued so far on the caller's stream
         if (hipEventRecord(ln.ev_strip, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
             return SSA_ERR_HIP;
@@ -541,7 +346,7 @@ using namespace ssa;
 
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
     const int64_t np = ceil_div(n, CNB) * CNB;
-    return (static_cast<size_t>(ceil_div(np, SNB)) * SNB * SNB + 512 * 512 + 2 * CPW * (CPW + 2)) *
+    return (static_cast<size_t>(ceil_div(np, SNB)) * SNB * SNB + 512 * 512 + 4 * CPW * CPW) *
            (dtype == SSA_F64 ? 8 : 4);
 }
 
