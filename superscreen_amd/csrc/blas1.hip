@@ -22,7 +22,9 @@ struct Vec16<float> {
     static constexpr int N = 4;
 };
 
-template <typename T, int ROWS, bool VECTOR>
+// TRI = 1 / 2: M is lower / upper triangular (zero on the other side); a wave then only streams
+// the columns up to / from the diagonal of its rows (whole vectors: the extra elements are zeros).
+template <typename T, int ROWS, bool VECTOR, int TRI = 0>
 __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int64_t nr,
                                                    int64_t nc, int64_t ldm,
                                                    const T *__restrict__ x,
@@ -43,11 +45,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int6
         const int64_t rr = (row0 + r < nr) ? row0 + r : nr - 1;
         rowp[r] = M + rr * ldm;
     }
-    const int64_t nc_vec = VECTOR ? (nc / VN) * VN : 0;
+    const int64_t c_begin = (TRI == 2) ? (row0 / VN) * VN : 0;
+    if (TRI == 1) nc = (row0 + ROWS < nc) ? row0 + ROWS : nc;
+    int64_t nc_vec = VECTOR ? (nc / VN) * VN : c_begin;
+    if (nc_vec < c_begin) nc_vec = c_begin;
     if (VECTOR) {
         using V = typename Vec16<T>::type;
 #pragma unroll 2
-        for (int64_t c = static_cast<int64_t>(lane) * VN; c < nc_vec; c += 64 * VN) {
+        for (int64_t c = c_begin + static_cast<int64_t>(lane) * VN; c < nc_vec; c += 64 * VN) {
             T xv[VN];
 #pragma unroll
             for (int k = 0; k < VN; ++k) {
@@ -103,6 +108,35 @@ int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
+}
+
+// y = alpha * M x + beta * y for a triangular M (tri = 1 lower, 2 upper): chol.hip applies the
+// inverted diagonal blocks with it.
+template <typename T>
+int launch_trmv(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha, double beta,
+                int tri, hipStream_t st) {
+    constexpr int ROWS = 4;
+    if (nr <= 0) return SSA_OK;
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr, 4 * ROWS)));
+    const bool aligned = (reinterpret_cast<uintptr_t>(M) % 16 == 0) && ((ldm * sizeof(T)) % 16 == 0);
+    if (!aligned || (tri != 1 && tri != 2))
+        return launch_gemv<T>(M, nr, nc, ldm, x, nullptr, nullptr, y, alpha, beta, st);
+    if (tri == 1)
+        hipLaunchKernelGGL((gemv_kernel<T, ROWS, true, 1>), grid, dim3(256), 0, st, M, nr, nc, ldm, x, nullptr,
+                           nullptr, y, static_cast<T>(alpha), static_cast<T>(beta));
+    else
+        hipLaunchKernelGGL((gemv_kernel<T, ROWS, true, 2>), grid, dim3(256), 0, st, M, nr, nc, ldm, x, nullptr,
+                           nullptr, y, static_cast<T>(alpha), static_cast<T>(beta));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+int trmv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y, double alpha,
+             double beta, int tri, hipStream_t st) {
+    return launch_trmv<double>(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+int trmv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
+             double beta, int tri, hipStream_t st) {
+    return launch_trmv<float>(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
 }
 
 // Used by lu.hip (single right-hand-side triangular solves).

@@ -12,10 +12,15 @@
 // A non-positive pivot is reported through `info` (LAPACK ?potrf convention) and the host
 // falls back to the LU path (lu.hip).
 //
-// Blocking mirrors lu.hip: 256-column outer panels whose trailing update is one MFMA SYRK with
-// K = 256, 64-column sub-panels factored by a register-resident, fully unrolled kernel
-// (diagonal block per workgroup in registers, the rows below forward-substituted one row per
-// thread), in-panel updates by the NT GEMM.
+// Factorization: 256-column outer panels.  Panel = one diagonal-block kernel (chol_diag.hpp: L11
+// and W = L11^-1) + L21 = A21 W^T as two in-place MFMA GEMMs; trailing update = one MFMA SYRK
+// with K = 256; panel k+1 runs on a side stream beside update k (look-ahead), and the films of a
+// device are factored in one interleaved schedule (potrf_batch).
+//
+// Solve: the factor buffer ends up holding L below and L^T above the diagonal, and `aux` the
+// inverses (and their transposes) of the SNB x SNB diagonal blocks of L, so that both triangular
+// solves are chains of 2 row-major GEMVs per block that stream at HBM speed
+// (x_k = inv_k b_k;  b_rest -= L[rest, k] x_k), with no transposed access and no per-row dependency.
 #include <mutex>
 #include <utility>
 
@@ -38,10 +43,16 @@ int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double 
              double alpha, double beta, hipStream_t st);
 int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
              double alpha, double beta, hipStream_t st);
-int trtri_lower_batched_f64(const double *Ablk, int64_t lda, int64_t a_stride, int kb, double *out,
-                            int64_t ldo, int64_t o_stride, int batch, hipStream_t st);
-int trtri_lower_batched_f32(const float *Ablk, int64_t lda, int64_t a_stride, int kb, float *out,
-                            int64_t ldo, int64_t o_stride, int batch, hipStream_t st);
+int trmv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y, double alpha,
+             double beta, int tri, hipStream_t st);
+int trmv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
+             double beta, int tri, hipStream_t st);
+int gemm_batched_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int batch1,
+                     int batch2, const int64_t *strides, hipStream_t st);
+int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                     const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int batch1,
+                     int batch2, const int64_t *strides, hipStream_t st);
 
 namespace {
 
@@ -74,82 +85,86 @@ inline int gemv_n_t(const float *M, int64_t nr, int64_t nc, int64_t ldm, const f
                     double alpha, double beta, hipStream_t st) {
     return gemv_f32(M, nr, nc, ldm, x, y, alpha, beta, st);
 }
-inline int trtri_batched_t(const double *A, int64_t lda, int64_t as, int kb, double *out, int64_t ldo,
-                           int64_t os, int batch, hipStream_t st) {
-    return trtri_lower_batched_f64(A, lda, as, kb, out, ldo, os, batch, st);
+inline int trmv_t(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
+                  double alpha, double beta, int tri, hipStream_t st) {
+    return trmv_f64(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
 }
-inline int trtri_batched_t(const float *A, int64_t lda, int64_t as, int kb, float *out, int64_t ldo,
-                           int64_t os, int batch, hipStream_t st) {
-    return trtri_lower_batched_f32(A, lda, as, kb, out, ldo, os, batch, st);
+inline int trmv_t(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
+                  double beta, int tri, hipStream_t st) {
+    return trmv_f32(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+inline int gemm_batched_t(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                          const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int b1, int b2,
+                          const int64_t *strides, hipStream_t st) {
+    return gemm_batched_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, st);
+}
+inline int gemm_batched_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                          const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int b1, int b2,
+                          const int64_t *strides, hipStream_t st) {
+    return gemm_batched_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, st);
 }
 
-constexpr int SNB = 1024;  // block size of the triangular solves (pre-inverted diagonal blocks)
+constexpr int64_t SNB = 4096;  // block size of the triangular solves (pre-inverted diagonal blocks)
 
-// inv <- inverse of the lower triangular diagonal block L[r0 : r0 + sz, r0 : r0 + sz], built
-// recursively:  inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]];  leaves (<= 256) by the
-// LDS substitution kernel, the off-diagonal quadrants by two MFMA GEMMs.  `inv` has leading
-// dimension ldi and is zero above the diagonal (the caller memsets it).
+// aux layout (elements):  inv [nblk][SNB][SNB] | invT [nblk][SNB][SNB] | tmp | scratch
+struct AuxLayout {
+    int64_t nblk, nfull, inv, invT, tmp, scratch, total;
+};
+inline AuxLayout aux_layout(int64_t n) {
+    AuxLayout a;
+    a.nblk = ceil_div(n, SNB);
+    a.nfull = n / SNB;
+    a.inv = 0;
+    a.invT = a.nblk * SNB * SNB;
+    a.tmp = 2 * a.nblk * SNB * SNB;
+    a.scratch = a.tmp + (a.nfull > 0 ? a.nfull : 1) * SNB * SNB / 4;
+    a.total = a.scratch + 4 * CPW * CPW;
+    return a;
+}
+
+// inv <- inverse of the lower triangular diagonal block L[r0 : r0 + sz, r0 : r0 + sz] whose 256-leaves
+// are already inverted (chol_diag.hpp), recursively:
+//     inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]
+// One product pair per split; used for the last, partial SNB block (the full ones are batched).
 template <typename T>
 int build_block_inverse(const T *L, int64_t lda, int64_t r0, int64_t sz, T *inv, int64_t ldi, T *tmp,
                         hipStream_t st) {
-    if (sz <= 256) return SSA_OK;  // leaves are inverted by the caller, batched
-    const int64_t h = (sz > 512) ? 512 : 256;
+    if (sz <= 256) return SSA_OK;
+    int64_t h = 256;
+    while (2 * h < sz) h *= 2;
     int rc = build_block_inverse(L, lda, r0, h, inv, ldi, tmp, st);
     if (rc != SSA_OK) return rc;
     rc = build_block_inverse(L, lda, r0 + h, sz - h, inv + h * ldi + h, ldi, tmp, st);
     if (rc != SSA_OK) return rc;
-    rc = gemm_nn_t(sz - h, h, h, 1.0, L + (r0 + h) * lda + r0, lda, inv, ldi, 0.0, tmp, 512, st);
+    rc = gemm_nn_t(sz - h, h, h, 1.0, L + (r0 + h) * lda + r0, lda, inv, ldi, 0.0, tmp, h, st);
     if (rc != SSA_OK) return rc;
-    return gemm_nn_t(sz - h, h, sz - h, -1.0, inv + h * ldi + h, ldi, tmp, 512, 0.0, inv + h * ldi, ldi, st);
+    return gemm_nn_t(sz - h, h, sz - h, -1.0, inv + h * ldi + h, ldi, tmp, h, 0.0, inv + h * ldi, ldi, st);
 }
 
-// y[c] = alpha * sum_r M[r][c] x[r] + beta * y[c]  (M is nr x nc row-major): the transposed GEMV of
-// the backward substitution with L^T.  Workgroup = 128 columns; each wave sums a quarter of the
-// rows with 16-byte loads (lane <-> 2 columns, no cross-lane reduction), the four partial sums
-// meet in LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void gemv_t_kernel(const T *__restrict__ M, int64_t nr, int64_t nc,
-                                                     int64_t ldm, const T *__restrict__ x,
-                                                     T *__restrict__ y, T alpha, T beta) {
-    __shared__ T part[4][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 128 + 2 * lane;
-    T s0 = T(0), s1 = T(0);
-    const int64_t rows_per = (nr + 3) / 4;
-    const int64_t r_begin = wave * rows_per, r_end = (r_begin + rows_per < nr) ? r_begin + rows_per : nr;
-    if (c0 + 1 < nc) {
-#pragma unroll 8
-        for (int64_t r = r_begin; r < r_end; ++r) {
-            const T xv = x[r];
-            const T *p = M + r * ldm + c0;
-            s0 += p[0] * xv;
-            s1 += p[1] * xv;
-        }
-    } else if (c0 < nc) {
-        for (int64_t r = r_begin; r < r_end; ++r) s0 += M[r * ldm + c0] * x[r];
+// dst tile (bj, bi) <- transpose of src tile (bi, bj) for the 64 x 64 tiles on/below the diagonal
+// of a square matrix (blockIdx.x enumerates them row by row, blockIdx.y = matrix of the batch).
+// STRICT: src == dst, only the strictly lower elements move (upper <- lower^T, diagonal kept).
+template <typename T, bool STRICT>
+__global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int64_t lds_, int64_t s_stride,
+                                                              T *dst, int64_t ldd, int64_t d_stride, int64_t n) {
+    __shared__ T tile[64][65];
+    const int64_t id = blockIdx.x;
+    int64_t bi = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5);
+    while (bi * (bi + 1) / 2 > id) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
+    const int64_t bj = id - bi * (bi + 1) / 2;
+    src += blockIdx.y * s_stride;
+    dst += blockIdx.y * d_stride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int rr = w; rr < 64; rr += 4) {
+        const int64_t r = bi * 64 + rr, c = bj * 64 + lane;
+        tile[rr][lane] = (r < n && c < n) ? src[r * lds_ + c] : T(0);
     }
-    part[wave][2 * lane] = s0;
-    part[wave][2 * lane + 1] = s1;
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int64_t c = static_cast<int64_t>(blockIdx.x) * 128 + threadIdx.x;
-        if (c < nc) {
-            const T s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-            T out = alpha * s;
-            if (beta != T(0)) out += beta * y[c];
-            y[c] = out;
-        }
+    for (int rr = w; rr < 64; rr += 4) {
+        const int64_t r = bj * 64 + rr, c = bi * 64 + lane;  // destination element (r, c) = source (c, r)
+        if (r < n && c < n && (!STRICT || c > r)) dst[r * ldd + c] = tile[lane][rr];
     }
-}
-
-template <typename T>
-int gemv_trans(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha, double beta,
-               hipStream_t st) {
-    if (nr <= 0 || nc <= 0) return SSA_OK;
-    hipLaunchKernelGGL((gemv_t_kernel<T>), dim3(static_cast<unsigned>(ceil_div(nc, 128))), dim3(256), 0, st, M,
-                       nr, nc, ldm, x, y, static_cast<T>(alpha), static_cast<T>(beta));
-    SSA_RETURN_IF_LAUNCH_FAILED();
-    return SSA_OK;
 }
 
 // One side stream + two events per concurrently factored matrix (look-ahead lanes).
@@ -192,7 +207,7 @@ struct CholJob {
 template <typename T>
 int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     const int64_t n = J.n, lda = J.lda;
-    T *scratch = J.aux + ceil_div(n, SNB) * SNB * SNB + 512 * 512;
+    T *scratch = J.aux + aux_layout(n).scratch;
     T *W = J.aux + (k0 / SNB) * SNB * SNB + (k0 % SNB) * (SNB + 1);
     hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), 0, s, J.A + k0 * (lda + 1), lda, W,
                        static_cast<int64_t>(SNB), scratch, J.info, static_cast<int>(k0 + 1));
@@ -208,21 +223,50 @@ int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     return SSA_OK;
 }
 
-// aux = inverses of the SNB x SNB diagonal blocks of L for the solve phase (+ GEMM scratch):
-// the off-diagonal quadrants, by recursion on the leaves
+// After the factorization: L^T into the upper triangle of the factor buffer, the off-diagonal
+// quadrants of the SNB block inverses (the 256-leaves were written by the diagonal-block kernels),
+// and the transposed inverses.  One recursion level of ALL full blocks is two batched GEMMs:
+//     tmp_p = L21(p) inv11(p),   inv21(p) = -inv22(p) tmp_p      for every pair p of size 2 h.
 template <typename T>
-int chol_build_inverses(const CholJob<T> &J, hipStream_t st) {
-    const T *A = J.A;
-    T *aux = J.aux;
+int chol_finish(const CholJob<T> &J, hipStream_t st) {
+    T *A = J.A;
     const int64_t n = J.n, lda = J.lda;
+    const AuxLayout al = aux_layout(n);
+    T *inv = J.aux + al.inv, *invT = J.aux + al.invT, *tmp = J.aux + al.tmp;
     int rc;
-    const int64_t nblk = ceil_div(n, SNB);
-    T *tmp = aux + nblk * SNB * SNB;
-    // the 256 x 256 leaves were written by the diagonal-block kernels during the factorization
-    for (int64_t k = 0; k < nblk; ++k) {
-        const int64_t r0 = k * SNB, sz = (n - r0 < SNB) ? n - r0 : SNB;
-        rc = build_block_inverse(A, lda, r0, sz, aux + k * SNB * SNB, static_cast<int64_t>(SNB), tmp, st);
+    {
+        const int64_t nt = ceil_div(n, 64);
+        hipLaunchKernelGGL((transpose_lower_kernel<T, true>), dim3(static_cast<unsigned>(nt * (nt + 1) / 2)),
+                           dim3(256), 0, st, A, lda, int64_t(0), A, lda, int64_t(0), n);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+    }
+    if (al.nfull > 0) {
+        for (int64_t h = 256; h < SNB; h *= 2) {
+            const int ppb = static_cast<int>(SNB / (2 * h));  // pairs per SNB block
+            const int64_t pair_l = 2 * h * (lda + 1), blk_l = SNB * (lda + 1);
+            const int64_t pair_i = 2 * h * (SNB + 1), blk_i = SNB * SNB;
+            const int64_t pair_t = h * h, blk_t = ppb * h * h;
+            const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+            rc = gemm_batched_t(h, h, h, 1.0, A + h * lda, lda, inv, SNB, 0.0, tmp, h, ppb,
+                                static_cast<int>(al.nfull), s1, st);
+            if (rc != SSA_OK) return rc;
+            const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
+            rc = gemm_batched_t(h, h, h, -1.0, inv + h * (SNB + 1), SNB, tmp, h, 0.0, inv + h * SNB, SNB, ppb,
+                                static_cast<int>(al.nfull), s2, st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    if (n % SNB != 0) {  // the last, partial block
+        const int64_t r0 = al.nfull * SNB;
+        rc = build_block_inverse(A, lda, r0, n - r0, inv + al.nfull * SNB * SNB, SNB, tmp, st);
         if (rc != SSA_OK) return rc;
+    }
+    {
+        const int64_t nt = SNB / 64;
+        hipLaunchKernelGGL((transpose_lower_kernel<T, false>),
+                           dim3(static_cast<unsigned>(nt * (nt + 1) / 2), static_cast<unsigned>(al.nblk)), dim3(256),
+                           0, st, inv, SNB, SNB * SNB, invT, SNB, SNB * SNB, SNB);
+        SSA_RETURN_IF_LAUNCH_FAILED();
     }
     return SSA_OK;
 }
@@ -252,8 +296,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (J.n % CNB != 0) return SSA_ERR_INVALID_ARGUMENT;  // callers pad (potrf_padded_batch)
         if (J.n > nmax) nmax = J.n;
         if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess ||
-            hipMemsetAsync(J.aux, 0, static_cast<size_t>(ceil_div(J.n, SNB)) * SNB * SNB * sizeof(T), st) !=
-                hipSuccess)
+            hipMemsetAsync(J.aux, 0, static_cast<size_t>(aux_layout(J.n).tmp) * sizeof(T), st) != hipSuccess)
             return SSA_ERR_HIP;
         // fork: the side stream starts after everything enqueued so far on the caller's stream
         if (hipEventRecord(ln.ev_strip, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
@@ -292,26 +335,29 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (hipStreamWaitEvent(st, lanes[i].ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
     }
     for (int i = 0; i < count; ++i) {
-        rc = chol_build_inverses(jobs[i], st);
+        rc = chol_finish(jobs[i], st);
         if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
 }
 
-// L L^T X = B.  Single right-hand side: GEMV / transposed-GEMV chain over SNB-row blocks;
-// several: the same recurrence on the MFMA GEMMs (NN forward, TN backward).
+// L L^T X = B on the finished factor buffer (L below, L^T above the diagonal).  Per SNB block two
+// launches: apply the inverted diagonal block, then update the rest of the right-hand side with the
+// block column of L (forward) / of L^T (backward).  Single right-hand side: row-major GEMVs;
+// several: the same recurrence on the MFMA GEMM.
 template <typename T>
 int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb, T *X,
           hipStream_t st) {
-    const int64_t nblk = ceil_div(n, SNB);
+    const AuxLayout al = aux_layout(n);
     const int64_t ldx = nrhs;
+    const bool vec = (nrhs == 1 && ldb == 1);
     int rc;
-    for (int64_t k = 0; k < nblk; ++k) {  // forward: L y = b
+    for (int64_t k = 0; k < al.nblk; ++k) {  // forward: L y = b
         const int64_t r0 = k * SNB, kb = (n - r0 < SNB) ? n - r0 : SNB;
         const int64_t below = n - r0 - kb;
-        const T *inv = aux + k * SNB * SNB;
-        if (nrhs == 1 && ldb == 1) {
-            rc = gemv_n_t(inv, kb, kb, SNB, B + r0, X + r0, 1.0, 0.0, st);
+        const T *inv = aux + al.inv + k * SNB * SNB;
+        if (vec) {
+            rc = trmv_t(inv, kb, kb, SNB, B + r0, X + r0, 1.0, 0.0, 1, st);
             if (rc == SSA_OK && below > 0)
                 rc = gemv_n_t(L + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
         } else {
@@ -322,17 +368,17 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
         }
         if (rc != SSA_OK) return rc;
     }
-    for (int64_t k = nblk - 1; k >= 0; --k) {  // backward: L^T x = y   (y lives in X, x goes to B)
+    for (int64_t k = al.nblk - 1; k >= 0; --k) {  // backward: L^T x = y   (y lives in X, x goes to B)
         const int64_t r0 = k * SNB, kb = (n - r0 < SNB) ? n - r0 : SNB;
-        const T *inv = aux + k * SNB * SNB;
-        if (nrhs == 1 && ldb == 1) {
-            rc = gemv_trans(inv, kb, kb, SNB, X + r0, B + r0, 1.0, 0.0, st);
-            if (rc == SSA_OK && r0 > 0)
-                rc = gemv_trans(L + r0 * lda, kb, r0, lda, B + r0, X, -1.0, 1.0, st);
+        const T *invT = aux + al.invT + k * SNB * SNB;
+        const T *U = L + r0;  // rows 0 .. r0-1 of L^T, columns of this block
+        if (vec) {
+            rc = trmv_t(invT, kb, kb, SNB, X + r0, B + r0, 1.0, 0.0, 2, st);
+            if (rc == SSA_OK && r0 > 0) rc = gemv_n_t(U, r0, kb, lda, B + r0, X, -1.0, 1.0, st);
         } else {
-            rc = gemm_op_t(1, 0, 0, kb, nrhs, kb, 1.0, inv, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
+            rc = gemm_nn_t(kb, nrhs, kb, 1.0, invT, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
             if (rc == SSA_OK && r0 > 0)
-                rc = gemm_op_t(1, 0, 0, r0, nrhs, kb, -1.0, L + r0 * lda, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
+                rc = gemm_nn_t(r0, nrhs, kb, -1.0, U, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
         }
         if (rc != SSA_OK) return rc;
     }
@@ -346,8 +392,7 @@ using namespace ssa;
 
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
     const int64_t np = ceil_div(n, CNB) * CNB;
-    return (static_cast<size_t>(ceil_div(np, SNB)) * SNB * SNB + 512 * 512 + 4 * CPW * CPW) *
-           (dtype == SSA_F64 ? 8 : 4);
+    return static_cast<size_t>(aux_layout(np).total) * (dtype == SSA_F64 ? 8 : 4);
 }
 
 extern "C" int64_t ssa_chol_padded_n(int64_t n) { return ceil_div(n, CNB) * CNB; }

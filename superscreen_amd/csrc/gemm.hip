@@ -303,13 +303,21 @@ __device__ __forceinline__ void gemm_tile_edge(int64_t M, int64_t N, int64_t K, 
     }
 }
 
+// Element strides of a two-level batch: matrix (y, z) of the grid starts at X + y * x1 + z * x2.
+struct BatchStrides {
+    int64_t a1, a2, b1, b2, c1, c2;
+};
+
 template <typename T, bool ALIGNED>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
     int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
     const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
-    int64_t ntn) {
+    int64_t ntn, BatchStrides bs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GemmSmem<T> &sm = *reinterpret_cast<GemmSmem<T> *>(smem_raw);
+    A += blockIdx.y * bs.a1 + blockIdx.z * bs.a2;
+    B += blockIdx.y * bs.b1 + blockIdx.z * bs.b2;
+    C += blockIdx.y * bs.c1 + blockIdx.z * bs.c2;
     int64_t tm, tn;
     remap_tile(blockIdx.x, ntm, ntn, tm, tn);
     const int64_t m0 = tm * BM, n0 = tn * BN;
@@ -325,14 +333,18 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
 
 template <typename T>
 int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64_t lda,
-                const void *B, int64_t ldb, double beta, void *C, int64_t ldc, hipStream_t st) {
-    if (M <= 0 || N <= 0) return SSA_OK;
+                const void *B, int64_t ldb, double beta, void *C, int64_t ldc, hipStream_t st,
+                int batch1 = 1, int batch2 = 1, BatchStrides bs = BatchStrides{0, 0, 0, 0, 0, 0}) {
+    if (M <= 0 || N <= 0 || batch1 <= 0 || batch2 <= 0) return SSA_OK;
     const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
     const size_t smem = sizeof(GemmSmem<T>);
     const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
-                         ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
-    const dim3 grid(static_cast<unsigned>(ntm * ntn));
+                         ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0) &&
+                         ((bs.a1 * sizeof(T)) % 16 == 0) && ((bs.a2 * sizeof(T)) % 16 == 0) &&
+                         ((bs.b1 * sizeof(T)) % 16 == 0) && ((bs.b2 * sizeof(T)) % 16 == 0);
+    const dim3 grid(static_cast<unsigned>(ntm * ntn), static_cast<unsigned>(batch1),
+                    static_cast<unsigned>(batch2));
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, true>),
@@ -344,17 +356,17 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, in
             return SSA_ERR_HIP;
         attr_set = true;
     }
-    ProfileScope scope(aligned && sizeof(T) == 8, kProfileGemmNN, 2.0 * M * N * K, st);
+    ProfileScope scope(aligned && sizeof(T) == 8, kProfileGemmNN, 2.0 * M * N * K * batch1 * batch2, st);
     if (aligned) {
         hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(kGemmThreads), smem, st, M, N, K,
                            static_cast<T>(alpha), static_cast<const T *>(A), lda,
                            static_cast<const T *>(B), ldb, static_cast<T>(beta),
-                           static_cast<T *>(C), ldc, ntm, ntn);
+                           static_cast<T *>(C), ldc, ntm, ntn, bs);
     } else {
         hipLaunchKernelGGL((gemm_kernel<T, false>), grid, dim3(kGemmThreads), smem, st, M, N, K,
                            static_cast<T>(alpha), static_cast<const T *>(A), lda,
                            static_cast<const T *>(B), ldb, static_cast<T>(beta),
-                           static_cast<T *>(C), ldc, ntm, ntn);
+                           static_cast<T *>(C), ldc, ntm, ntn, bs);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
@@ -368,6 +380,20 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int
 int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
              const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st) {
     return launch_gemm<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+// Two-level batches of equal-sized products (chol.hip: one recursion level of all block inverses):
+// strides = {a1, a2, b1, b2, c1, c2} in elements.
+int gemm_batched_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int batch1,
+                     int batch2, const int64_t *strides, hipStream_t st) {
+    return launch_gemm<double>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, batch1, batch2,
+                               BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5]});
+}
+int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                     const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int batch1,
+                     int batch2, const int64_t *strides, hipStream_t st) {
+    return launch_gemm<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, batch1, batch2,
+                              BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5]});
 }
 
 }  // namespace ssa
