@@ -209,8 +209,18 @@ int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     const int64_t n = J.n, lda = J.lda;
     T *scratch = J.aux + aux_layout(n).scratch;
     T *W = J.aux + (k0 / SNB) * SNB * SNB + (k0 % SNB) * (SNB + 1);
-    hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), 0, s, J.A + k0 * (lda + 1), lda, W,
-                       static_cast<int64_t>(SNB), scratch, J.info, static_cast<int>(k0 + 1));
+    if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs an explicit opt-in
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(sizeof(cholk::Ge64Smem<T>))) != hipSuccess)
+            return SSA_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), sizeof(cholk::Ge64Smem<T>), s,
+                       J.A + k0 * (lda + 1),
+                       static_cast<int>(lda), W, static_cast<int>(SNB), scratch, J.info, static_cast<int>(k0 + 1));
     SSA_RETURN_IF_LAUNCH_FAILED();
     const int64_t M = n - k0 - CNB;
     if (M > 0) {

@@ -46,25 +46,44 @@ __device__ __forceinline__ float rsqrt_acc(float x) {
 }
 
 // LDS of ge64: column J of D (2 parities x 4 residues x 32 slots, slots 16..31 stay zero for the
-// rotated overrun) and row J of the eliminated identity (2 x 4 x 16).
+// rotated overrun) and row J of the eliminated identity (2 x 4 x 16).  A wave reads 4 distinct
+// addresses per instruction (one per residue q), so the q stride must not be a multiple of the
+// 256-byte bank period: +2 elements of padding (unpadded, the 4-way conflict cost 2x kernel time).
 template <typename T>
 struct Ge64Smem {
-    T cb[2][4][32];
-    T mb[2][4][16];
+    T cb[2][4][32 + 2];
+    T mb[2][4][16 + 2];
+    T lout[64][64 + 1];  // the block on its way in, the finished columns of L on their way out
+    T wout[64][64 + 1];  // W_ss on its way out
 };
 
 // [L, W] of the 64 x 64 block at D (leading dimension ld); L overwrites the lower triangle of D,
 // W (full block, zero above the diagonal) goes to Wout.  All 256 threads.
+__device__ __forceinline__ int opaque(int x) {
+    // Hides the value from loop-invariant code motion: without it the compiler hoists every
+    // per-lane constant of every phase (identity columns, row offsets) to the top of the kernel and
+    // then spills them, because the kernel is capped at 256 registers (see below).
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 template <typename T>
-__device__ __forceinline__ void ge64(T *D, int64_t ld, T *Wout, int64_t ldw, Ge64Smem<T> &sm, bool &bad) {
-    const int t = threadIdx.x, r = t >> 2, q = t & 3;
+__device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T> &sm, bool &bad) {
+    const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
+    const int lane = t & 63, wave = t >> 6;
+    // Global memory is touched only in whole 512-byte rows, before and after the column loop, through
+    // the LDS tiles: partial-line accesses (this thread layout gives 32-byte pieces) and stores
+    // inside the loop both put memory acknowledgements on the critical path, which a trailing
+    // update streaming through the same L2 / HBM stretches to microseconds.
+    for (int rr = wave; rr < 64; rr += 4) sm.lout[rr][lane] = D[rr * ld + lane];
+    for (int e = t; e < 2 * 4 * (32 + 2); e += 256) (&sm.cb[0][0][0])[e] = T(0);
+    __syncthreads();
     T a[16], m[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        a[i] = D[static_cast<int64_t>(r) * ld + q + 4 * i];
+        a[i] = sm.lout[r][q + 4 * i];
         m[i] = (q + 4 * i == r) ? T(1) : T(0);
     }
-    for (int e = t; e < 2 * 4 * 32; e += 256) (&sm.cb[0][0][0])[e] = T(0);
     __syncthreads();
     T myinv = T(0);
 #pragma unroll 1
@@ -91,42 +110,50 @@ __device__ __forceinline__ void ge64(T *D, int64_t ld, T *Wout, int64_t ldw, Ge6
                 const T upd = a[0] - gmul * sm.cb[par][q][I0];
                 a[0] = (q == S) ? ((r >= J) ? lr : a[0]) : ((q > S) ? upd : a[0]);
             }
+#ifndef GE_NO_A
 #pragma unroll
             for (int k = 1; k < 16; ++k) a[k] -= gmul * sm.cb[par][q][I0 + k];
+#endif
+#ifndef GE_NO_M
 #pragma unroll
             for (int i = 0; i < 16; ++i) m[i] -= f * sm.mb[par][q][i];
+#endif
         }
-        const int c = 4 * I0 + q;
-        if (c <= r) D[static_cast<int64_t>(r) * ld + c] = a[0];
+        sm.lout[r][4 * I0 + q] = a[0];
 #pragma unroll
         for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
         a[15] = T(0);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Wout[static_cast<int64_t>(r) * ldw + q + 4 * i] = m[i] * myinv;
+    for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i] * myinv;
+    __syncthreads();
+    for (int rr = wave; rr < 64; rr += 4) {
+        if (lane <= rr) D[rr * ld + lane] = sm.lout[rr][lane];
+        Wout[rr * ldw + lane] = sm.wout[rr][lane];
+    }
 }
 
 // acc[jt] += sign * A_slab * op(B) for one 16-row slab (rows given by Arow, 64 columns = K) and the
 // four 16-column tiles of a 64 x 64 block B.  BT: op(B) = B^T (B[j][k] row-major), else B[k][j].
 template <typename T, bool BT>
-__device__ __forceinline__ void slab_gemm(typename Mfma<T>::acc_t (&acc)[4], const T *Arow, int64_t lda,
-                                          const T *B, int64_t ldb, T sign, int lane) {
+__device__ __forceinline__ void slab_gemm(typename Mfma<T>::acc_t (&acc)[4], const T *Arow, int lda,
+                                          const T *B, int ldb, T sign, int lane) {
     const int i = lane & 15, g = lane >> 4;
     T a[16];
-    const T *ap = Arow + static_cast<int64_t>(i) * lda + 16 * g;
+    const T *ap = Arow + (i * lda + 16 * g);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) a[kk] = sign * ap[kk];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
         T b[16];
         if (BT) {
-            const T *bp = B + static_cast<int64_t>(16 * jt + i) * ldb + 16 * g;
+            const T *bp = B + ((16 * jt + i) * ldb + 16 * g);
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) b[kk] = bp[kk];
         } else {
-            const T *bp = B + static_cast<int64_t>(16 * g) * ldb + 16 * jt + i;
+            const T *bp = B + (16 * g * ldb + 16 * jt + i);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) b[kk] = bp[static_cast<int64_t>(kk) * ldb];
+            for (int kk = 0; kk < 16; ++kk) b[kk] = bp[kk * ldb];
         }
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) acc[jt] = Mfma<T>::run(a[kk], b[kk], acc[jt]);
@@ -141,50 +168,73 @@ __device__ __forceinline__ void slab_zero(typename Mfma<T>::acc_t (&acc)[4]) {
         for (int e = 0; e < 4; ++e) acc[jt][e] = T(0);
 }
 template <typename T>
-__device__ __forceinline__ void slab_load(typename Mfma<T>::acc_t (&acc)[4], const T *Crow, int64_t ldc, int lane) {
+__device__ __forceinline__ void slab_load(typename Mfma<T>::acc_t (&acc)[4], const T *Crow, int ldc, int lane) {
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            acc[jt][e] = Crow[static_cast<int64_t>(Mfma<T>::row(lane, e)) * ldc + 16 * jt + (lane & 15)];
+            acc[jt][e] = Crow[Mfma<T>::row(lane, e) * ldc + 16 * jt + (lane & 15)];
 }
 template <typename T>
-__device__ __forceinline__ void slab_store(const typename Mfma<T>::acc_t (&acc)[4], T *Crow, int64_t ldc, int lane) {
+__device__ __forceinline__ void slab_store(const typename Mfma<T>::acc_t (&acc)[4], T *Crow, int ldc, int lane) {
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            Crow[static_cast<int64_t>(Mfma<T>::row(lane, e)) * ldc + 16 * jt + (lane & 15)] = acc[jt][e];
+            Crow[Mfma<T>::row(lane, e) * ldc + 16 * jt + (lane & 15)] = acc[jt][e];
 }
 
 // D: the 256 x 256 diagonal block (leading dimension lda), W: its inverse factor (ldw), both in
-// global memory; `scratch`: 3 * 64 * 64 elements; `col1`: 1-based column of D[0][0] for `info`.
+// global memory (all offsets inside the blocks are 32-bit: 256 * ld elements must fit, the host
+// checks); `scratch`: 3 * 64 * 64 elements; `col1`: 1-based column of D[0][0] for `info`.
+// __launch_bounds__(256, 2) caps the kernel at 256 registers per lane: the trailing update that
+// runs beside it (look-ahead) keeps two 256-register workgroups on every CU, and a workgroup that
+// needs more than the 256 registers one of them frees is never placed until the whole update has
+// drained (measured: 386 registers -> the kernel "took" as long as the SYRK it was meant to hide
+// behind).
+#ifdef CHOLK_TIMING
+#define CHOLK_STAMP(i) do { if (threadIdx.x == 0) tstamp[i] = wall_clock64(); } while (0)
+#else
+#define CHOLK_STAMP(i) do { } while (0)
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void chol_diag256_kernel(T *D, int64_t lda, T *W, int64_t ldw, T *scratch,
-                                                           int32_t *info, int col1) {
-    __shared__ Ge64Smem<T> sm;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 2) void chol_diag256_kernel(T *D, int lda, T *W, int ldw, T *scratch,
+                                                           int32_t *info, int col1
+#ifdef CHOLK_TIMING
+                                                           , long long *tstamp
+#endif
+) {
+    extern __shared__ __attribute__((aligned(16))) char cholk_smem_raw[];  // sizeof(Ge64Smem<T>), > 64 KB
+    Ge64Smem<T> &sm = *reinterpret_cast<Ge64Smem<T> *>(cholk_smem_raw);
+    const int wave = threadIdx.x >> 6;
     using acc_t = typename Mfma<T>::acc_t;
     // a chain of short dependent steps that shares its SIMDs with the trailing update's MFMA waves
     __builtin_amdgcn_s_setprio(3);
     bool bad = false;
-    auto blk = [&](T *base, int64_t ld, int bi, int bj) { return base + (static_cast<int64_t>(bi) * ld + bj) * SB; };
+    auto blk = [&](T *base, int ld, int bi, int bj) { return base + (bi * ld + bj) * SB; };
 
+    CHOLK_STAMP(0);
+#pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         ge64<T>(blk(D, lda, s, s), lda, blk(W, ldw, s, s), ldw, sm, bad);
         __syncthreads();
+        const int lane = opaque(threadIdx.x) & 63;
+        CHOLK_STAMP(1 + 3 * s);
         // L_is = D_is W_ss^T
+#pragma unroll 1
         for (int task = wave; task < (3 - s) * 4; task += 4) {
             const int i = s + 1 + task / 4, slab = task % 4;
             acc_t acc[4];
             slab_zero<T>(acc);
-            T *rowp = blk(D, lda, i, s) + static_cast<int64_t>(16 * slab) * lda;
+            T *rowp = blk(D, lda, i, s) + 16 * slab * lda;
             slab_gemm<T, true>(acc, rowp, lda, blk(W, ldw, s, s), ldw, T(1), lane);
             slab_store<T>(acc, rowp, lda, lane);
         }
         __syncthreads();
+        CHOLK_STAMP(2 + 3 * s);
         // D_ij -= L_is L_js^T
         const int npairs = (3 - s) * (4 - s) / 2;
+#pragma unroll 1
         for (int task = wave; task < npairs * 4; task += 4) {
             int p = task / 4;
             const int slab = task % 4;
@@ -195,38 +245,46 @@ __global__ __launch_bounds__(256) void chol_diag256_kernel(T *D, int64_t lda, T 
             }
             const int j = s + 1 + p;
             acc_t acc[4];
-            T *crow = blk(D, lda, i, j) + static_cast<int64_t>(16 * slab) * lda;
+            T *crow = blk(D, lda, i, j) + 16 * slab * lda;
             slab_load<T>(acc, crow, lda, lane);
-            slab_gemm<T, true>(acc, blk(D, lda, i, s) + static_cast<int64_t>(16 * slab) * lda, lda,
+            slab_gemm<T, true>(acc, blk(D, lda, i, s) + 16 * slab * lda, lda,
                                blk(D, lda, j, s), lda, T(-1), lane);
             slab_store<T>(acc, crow, lda, lane);
         }
         __syncthreads();
+        CHOLK_STAMP(3 + 3 * s);
     }
     if (bad && threadIdx.x == 0 && *info == 0) *info = col1;
 
     // off-diagonal blocks of W = L^-1, by distance from the diagonal
+#pragma unroll 1
     for (int d = 1; d < 4; ++d) {
         const int npairs = 4 - d;
+        const int lane = opaque(threadIdx.x) & 63;
+#pragma unroll 1
         for (int task = wave; task < npairs * 4; task += 4) {  // S_ij = sum_t L_it W_tj
             const int j = task / 4, i = j + d, slab = task % 4;
             acc_t acc[4];
             slab_zero<T>(acc);
+#pragma unroll 1
             for (int tt = j; tt < i; ++tt)
-                slab_gemm<T, false>(acc, blk(D, lda, i, tt) + static_cast<int64_t>(16 * slab) * lda, lda,
+                slab_gemm<T, false>(acc, blk(D, lda, i, tt) + 16 * slab * lda, lda,
                                     blk(W, ldw, tt, j), ldw, T(1), lane);
             slab_store<T>(acc, scratch + j * SB * SB + 16 * slab * SB, SB, lane);
         }
         __syncthreads();
+        CHOLK_STAMP(11 + 2 * d);
+#pragma unroll 1
         for (int task = wave; task < npairs * 4; task += 4) {  // W_ij = -W_ii S_ij
             const int j = task / 4, i = j + d, slab = task % 4;
             acc_t acc[4];
             slab_zero<T>(acc);
-            slab_gemm<T, false>(acc, blk(W, ldw, i, i) + static_cast<int64_t>(16 * slab) * ldw, ldw,
+            slab_gemm<T, false>(acc, blk(W, ldw, i, i) + 16 * slab * ldw, ldw,
                                 scratch + j * SB * SB, SB, T(-1), lane);
-            slab_store<T>(acc, blk(W, ldw, i, j) + static_cast<int64_t>(16 * slab) * ldw, ldw, lane);
+            slab_store<T>(acc, blk(W, ldw, i, j) + 16 * slab * ldw, ldw, lane);
         }
         __syncthreads();
+        CHOLK_STAMP(12 + 2 * d);
     }
 }
 
