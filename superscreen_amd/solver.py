@@ -462,18 +462,54 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
     return _DeviceFilmResult(g=g, J=J, self_field=sf)
 
 
-def _film_solution(res: _DeviceFilmResult, applied_h: np.ndarray, other_d, conv: float) -> FilmSolution:
-    """Host epilogue of ``solve_film`` (``solver/solve_film.py:566-574``)."""
-    other = None
-    if other_d is not None:
-        other = other_d.cpu().numpy() / conv
-    return FilmSolution(
-        stream=res.g.cpu().numpy(),
-        current_density=res.J.cpu().numpy(),
-        applied_field=applied_h / conv,
-        self_field=res.self_field.cpu().numpy() / conv,
-        field_from_other_films=other,
-    )
+_copy_streams: Dict[int, object] = {}
+
+
+class _StagedPass:
+    """Results of one pass on their way to the host: device-to-host copies run on a side stream
+    into pinned buffers while the main stream already computes the next Jacobi iteration."""
+
+    def __init__(self, results: Dict[str, _DeviceFilmResult], other_d, films: Sequence[str]):
+        import torch
+
+        dev = next(iter(results.values())).g.device
+        stream = _copy_streams.get(dev.index)
+        if stream is None:
+            stream = _copy_streams[dev.index] = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record()  # on the compute stream, after the pass
+        self.host: Dict[str, Dict[str, object]] = {}
+        self._keep = (results, other_d)  # device tensors stay alive until the copies are done
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            for name in films:
+                res = results[name]
+                items = {"g": res.g, "J": res.J, "self_field": res.self_field}
+                if other_d is not None:
+                    items["other"] = other_d[name]
+                out = {}
+                for key, t in items.items():
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    t.record_stream(stream)
+                    out[key] = h
+                self.host[name] = out
+            self.done = torch.cuda.Event()
+            self.done.record(stream)
+
+    def film_solution(self, name: str, applied_h: np.ndarray, conv: float) -> FilmSolution:
+        """Host epilogue of ``solve_film`` (``solver/solve_film.py:566-574``)."""
+        self.done.synchronize()
+        self._keep = None
+        h = self.host[name]
+        other = h["other"].numpy() / conv if "other" in h else None
+        return FilmSolution(
+            stream=h["g"].numpy(),
+            current_density=h["J"].numpy(),
+            applied_field=applied_h / conv,
+            self_field=h["self_field"].numpy() / conv,
+            field_from_other_films=other,
+        )
 
 
 def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] = None,
@@ -554,17 +590,14 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                                                check_inversion)
         return results
 
-    def package(results, other_d):
-        fs = {name: _film_solution(results[name], applied_h[name],
-                                   None if other_d is None else other_d[name], conv)
-              for name in films}
+    def package(staged: _StagedPass):
+        fs = {name: staged.film_solution(name, applied_h[name], conv) for name in films}
         return Solution(device=device, film_solutions=fs, **solution_kwargs)
 
     results = run_pass(None)
-    if return_solutions:
-        solutions.append(package(results, None))
+    pending = _StagedPass(results, None, films) if return_solutions else None
     if len(films) < 2 or iterations < 1:
-        return solutions if return_solutions else None
+        return [package(pending)] if return_solutions else None
 
     for it in range(iterations):
         other_d = {name: torch.zeros(model.film_data[name].n, dtype=model.film_data[name].tdtype,
@@ -582,11 +615,16 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
         prev = results
         results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
         if return_solutions:
-            solutions.append(package(results, other_d))
+            # the previous iterate is unpacked on the host while the GPU works on this one
+            staged = _StagedPass(results, other_d, films)
+            solutions.append(package(pending))
+            pending = staged
         if tolerance is not None:
             change = max(((results[n].g - prev[n].g).abs().max() / results[n].g.abs().max()).item()
                          for n in films)
             logger.debug(f"iteration {it + 1}: relative change {change:.3e}")
             if change < tolerance:
                 break
+    if return_solutions:
+        solutions.append(package(pending))
     return solutions if return_solutions else None
