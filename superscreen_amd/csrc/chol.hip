@@ -49,10 +49,10 @@ int trmv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x
              double beta, int tri, hipStream_t st);
 int gemm_batched_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int batch1,
-                     int batch2, const int64_t *strides, hipStream_t st);
+                     int batch2, const int64_t *strides, int tri, hipStream_t st);
 int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
                      const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int batch1,
-                     int batch2, const int64_t *strides, hipStream_t st);
+                     int batch2, const int64_t *strides, int tri, hipStream_t st);
 
 namespace {
 
@@ -95,13 +95,13 @@ inline int trmv_t(const float *M, int64_t nr, int64_t nc, int64_t ldm, const flo
 }
 inline int gemm_batched_t(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                           const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int b1, int b2,
-                          const int64_t *strides, hipStream_t st) {
-    return gemm_batched_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, st);
+                          const int64_t *strides, int tri, hipStream_t st) {
+    return gemm_batched_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, st);
 }
 inline int gemm_batched_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
                           const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int b1, int b2,
-                          const int64_t *strides, hipStream_t st) {
-    return gemm_batched_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, st);
+                          const int64_t *strides, int tri, hipStream_t st) {
+    return gemm_batched_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, st);
 }
 
 constexpr int64_t SNB = 4096;  // block size of the triangular solves (pre-inverted diagonal blocks)
@@ -117,7 +117,7 @@ inline AuxLayout aux_layout(int64_t n) {
     a.inv = 0;
     a.invT = a.nblk * SNB * SNB;
     a.tmp = 2 * a.nblk * SNB * SNB;
-    a.scratch = a.tmp + (a.nfull > 0 ? a.nfull : 1) * SNB * SNB / 4;
+    a.scratch = a.tmp + a.nblk * (SNB * SNB / 4);
     a.total = a.scratch + 4 * CPW * CPW;
     return a;
 }
@@ -142,19 +142,18 @@ int build_block_inverse(const T *L, int64_t lda, int64_t r0, int64_t sz, T *inv,
 }
 
 // dst tile (bj, bi) <- transpose of src tile (bi, bj) for the 64 x 64 tiles on/below the diagonal
-// of a square matrix (blockIdx.x enumerates them row by row, blockIdx.y = matrix of the batch).
+// of a square matrix: blockIdx.x = bi, blockIdx.y = bj - bj0 (tiles above the diagonal exit at
+// once), blockIdx.z = matrix of the batch.
 // STRICT: src == dst, only the strictly lower elements move (upper <- lower^T, diagonal kept).
 template <typename T, bool STRICT>
 __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int64_t lds_, int64_t s_stride,
-                                                              T *dst, int64_t ldd, int64_t d_stride, int64_t n) {
+                                                              T *dst, int64_t ldd, int64_t d_stride, int64_t n,
+                                                              int64_t bj0) {
     __shared__ T tile[64][65];
-    const int64_t id = blockIdx.x;
-    int64_t bi = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5);
-    while (bi * (bi + 1) / 2 > id) --bi;
-    while ((bi + 1) * (bi + 2) / 2 <= id) ++bi;
-    const int64_t bj = id - bi * (bi + 1) / 2;
-    src += blockIdx.y * s_stride;
-    dst += blockIdx.y * d_stride;
+    const int64_t bi = blockIdx.x, bj = bj0 + blockIdx.y;
+    if (bi < bj) return;
+    src += blockIdx.z * s_stride;
+    dst += blockIdx.z * d_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int rr = w; rr < 64; rr += 4) {
         const int64_t r = bi * 64 + rr, c = bj * 64 + lane;
@@ -233,53 +232,108 @@ int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     return SSA_OK;
 }
 
-// After the factorization: L^T into the upper triangle of the factor buffer, the off-diagonal
-// quadrants of the SNB block inverses (the 256-leaves were written by the diagonal-block kernels),
-// and the transposed inverses.  One recursion level of ALL full blocks is two batched GEMMs:
-//     tmp_p = L21(p) inv11(p),   inv21(p) = -inv22(p) tmp_p      for every pair p of size 2 h.
+// Finishing passes (solve-phase data), each over a range so that most of them can be slipped into
+// the idle slots of the caller's stream during the chain-bound tail of the factorization:
+//   mirror_columns   L^T into the upper triangle for the 64-wide tile columns [c0, c1) of L
+//   inverse_level    one recursion level h of the inverses of the full SNB blocks [j0, j1):
+//                    tmp_p = L21(p) inv11(p)  (first)  /  inv21(p) = -inv22(p) tmp_p  (second)
+//                    for every pair p of size 2 h, as ONE batched GEMM with triangular K ranges
+//   inverse_transposes  invT blocks [j0, j1)
+// (the 256-leaves of the inverses were written by the diagonal-block kernels).
 template <typename T>
-int chol_finish(const CholJob<T> &J, hipStream_t st) {
-    T *A = J.A;
-    const int64_t n = J.n, lda = J.lda;
-    const AuxLayout al = aux_layout(n);
-    T *inv = J.aux + al.inv, *invT = J.aux + al.invT, *tmp = J.aux + al.tmp;
-    int rc;
-    {
-        const int64_t nt = ceil_div(n, 64);
-        hipLaunchKernelGGL((transpose_lower_kernel<T, true>), dim3(static_cast<unsigned>(nt * (nt + 1) / 2)),
-                           dim3(256), 0, st, A, lda, int64_t(0), A, lda, int64_t(0), n);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-    }
-    if (al.nfull > 0) {
-        for (int64_t h = 256; h < SNB; h *= 2) {
-            const int ppb = static_cast<int>(SNB / (2 * h));  // pairs per SNB block
-            const int64_t pair_l = 2 * h * (lda + 1), blk_l = SNB * (lda + 1);
-            const int64_t pair_i = 2 * h * (SNB + 1), blk_i = SNB * SNB;
-            const int64_t pair_t = h * h, blk_t = ppb * h * h;
-            const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
-            rc = gemm_batched_t(h, h, h, 1.0, A + h * lda, lda, inv, SNB, 0.0, tmp, h, ppb,
-                                static_cast<int>(al.nfull), s1, st);
-            if (rc != SSA_OK) return rc;
-            const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
-            rc = gemm_batched_t(h, h, h, -1.0, inv + h * (SNB + 1), SNB, tmp, h, 0.0, inv + h * SNB, SNB, ppb,
-                                static_cast<int>(al.nfull), s2, st);
-            if (rc != SSA_OK) return rc;
-        }
-    }
-    if (n % SNB != 0) {  // the last, partial block
-        const int64_t r0 = al.nfull * SNB;
-        rc = build_block_inverse(A, lda, r0, n - r0, inv + al.nfull * SNB * SNB, SNB, tmp, st);
-        if (rc != SSA_OK) return rc;
-    }
-    {
-        const int64_t nt = SNB / 64;
-        hipLaunchKernelGGL((transpose_lower_kernel<T, false>),
-                           dim3(static_cast<unsigned>(nt * (nt + 1) / 2), static_cast<unsigned>(al.nblk)), dim3(256),
-                           0, st, inv, SNB, SNB * SNB, invT, SNB, SNB * SNB, SNB);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-    }
+int mirror_columns(const CholJob<T> &J, int64_t c0, int64_t c1, hipStream_t st) {
+    if (c1 <= c0) return SSA_OK;
+    const int64_t nt = ceil_div(J.n, 64);
+    hipLaunchKernelGGL((transpose_lower_kernel<T, true>),
+                       dim3(static_cast<unsigned>(nt), static_cast<unsigned>((c1 - c0) / 64)), dim3(256), 0, st, J.A,
+                       J.lda, int64_t(0), J.A, J.lda, int64_t(0), J.n, c0 / 64);
+    SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }
+
+template <typename T>
+int inverse_level(const CholJob<T> &J, int64_t h, bool second, int64_t j0, int64_t j1, hipStream_t st) {
+    if (j1 <= j0) return SSA_OK;
+    const int64_t lda = J.lda;
+    const AuxLayout al = aux_layout(J.n);
+    const int ppb = static_cast<int>(SNB / (2 * h));  // pairs per SNB block
+    const int64_t pair_l = 2 * h * (lda + 1), blk_l = SNB * (lda + 1);
+    const int64_t pair_i = 2 * h * (SNB + 1), blk_i = SNB * SNB;
+    const int64_t pair_t = h * h, blk_t = SNB * SNB / 4;
+    const T *L = J.A + j0 * blk_l;
+    T *inv = J.aux + al.inv + j0 * blk_i, *tmp = J.aux + al.tmp + j0 * blk_t;
+    const int nb = static_cast<int>(j1 - j0);
+    if (!second) {
+        const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+        return gemm_batched_t(h, h, h, 1.0, L + h * lda, lda, inv, SNB, 0.0, tmp, h, ppb, nb, s1, 1, st);
+    }
+    const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
+    return gemm_batched_t(h, h, h, -1.0, inv + h * (SNB + 1), SNB, tmp, h, 0.0, inv + h * SNB, SNB, ppb, nb, s2, 2,
+                          st);
+}
+
+template <typename T>
+int inverse_transposes(const CholJob<T> &J, int64_t j0, int64_t j1, hipStream_t st) {
+    if (j1 <= j0) return SSA_OK;
+    const AuxLayout al = aux_layout(J.n);
+    const int64_t nt = SNB / 64;
+    hipLaunchKernelGGL((transpose_lower_kernel<T, false>),
+                       dim3(static_cast<unsigned>(nt), static_cast<unsigned>(nt), static_cast<unsigned>(j1 - j0)),
+                       dim3(256), 0, st, J.aux + al.inv + j0 * SNB * SNB, SNB, SNB * SNB,
+                       J.aux + al.invT + j0 * SNB * SNB, SNB, SNB * SNB, SNB, int64_t(0));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+// The finishing passes of one matrix as a list of small steps (see above).  Steps [0, n_early) only
+// need the first `early_blocks` SNB blocks of L and are issued one per outer step during the
+// tail; the rest runs after the last panel.
+template <typename T>
+struct FinishPlan {
+    const CholJob<T> *job = nullptr;
+    int64_t early_blocks = 0;  // full SNB blocks finished ahead of time
+    int next = 0, n_early = 0, n_total = 0;
+
+    void init(const CholJob<T> *j, int64_t tail_cols) {
+        job = j;
+        const AuxLayout al = aux_layout(j->n);
+        early_blocks = (j->n > tail_cols) ? (j->n - tail_cols) / SNB : 0;
+        if (early_blocks > al.nfull) early_blocks = al.nfull;
+        int levels = 0;
+        for (int64_t h = 256; h < SNB; h *= 2) ++levels;
+        n_early = (early_blocks > 0) ? 2 * levels + 1 + 4 : 0;
+        n_total = n_early + 2 * levels + 1 + 1 + 1;
+        next = 0;
+    }
+    // columns of L that are final once the first early_blocks blocks are factored
+    int64_t early_cols() const { return early_blocks * SNB; }
+
+    int run_step(int step, hipStream_t st) const {
+        const CholJob<T> &J = *job;
+        const AuxLayout al = aux_layout(J.n);
+        int levels = 0;
+        for (int64_t h = 256; h < SNB; h *= 2) ++levels;
+        auto level_h = [](int l) { return int64_t(256) << l; };
+        if (step < n_early) {
+            if (step < 2 * levels) return inverse_level(J, level_h(step / 2), step % 2 == 1, 0, early_blocks, st);
+            if (step == 2 * levels) return inverse_transposes(J, 0, early_blocks, st);
+            const int q = step - 2 * levels - 1;  // the early columns of L in four pieces
+            const int64_t per = ceil_div(early_cols() / 64, 4) * 64;
+            const int64_t c0 = q * per, c1 = (c0 + per < early_cols()) ? c0 + per : early_cols();
+            return mirror_columns(J, c0, c1, st);
+        }
+        const int t = step - n_early;
+        if (t < 2 * levels) return inverse_level(J, level_h(t / 2), t % 2 == 1, early_blocks, al.nfull, st);
+        if (t == 2 * levels) {  // the last, partial block
+            if (J.n % SNB == 0) return SSA_OK;
+            const int64_t r0 = al.nfull * SNB;
+            return build_block_inverse(J.A, J.lda, r0, J.n - r0, J.aux + al.inv + al.nfull * SNB * SNB, SNB,
+                                       J.aux + al.tmp + al.nfull * (SNB * SNB / 4), st);
+        }
+        if (t == 2 * levels + 1) return inverse_transposes(J, early_blocks, al.nblk, st);
+        return mirror_columns(J, early_cols(), J.n, st);
+    }
+};
 
 // Factor `count` independent matrices (the films of a device) in one interleaved schedule.
 //
@@ -299,10 +353,14 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     CholLane *lanes = nullptr;
     int rc = get_lanes(count, &lanes);
     if (rc != SSA_OK) return rc;
+    // outer steps (per matrix) that are chain bound: the last ~6k columns at this panel speed
+    constexpr int64_t kTailCols = 6144;
+    FinishPlan<T> plans[kMaxLanes];
     int64_t nmax = 0;
     for (int i = 0; i < count; ++i) {
         const CholJob<T> &J = jobs[i];
         CholLane &ln = lanes[i];
+        plans[i].init(&jobs[i], kTailCols);
         if (J.n % CNB != 0) return SSA_ERR_INVALID_ARGUMENT;  // callers pad (potrf_padded_batch)
         if (J.n > nmax) nmax = J.n;
         if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess ||
@@ -339,14 +397,24 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                                C + nw * J.lda + nw, J.lda, st);
                 if (rc != SSA_OK) return rc;
             }
+            // one early finishing step per outer step once its inputs (panels <= k, which this
+            // stream has waited for) are final: fills the slots where the stream waits for the chain
+            FinishPlan<T> &fp = plans[i];
+            if (fp.next < fp.n_early && k0 + CNB >= fp.early_cols()) {
+                rc = fp.run_step(fp.next++, st);
+                if (rc != SSA_OK) return rc;
+            }
         }
     }
     for (int i = 0; i < count; ++i) {  // join, then the inverses of the diagonal blocks
         if (hipStreamWaitEvent(st, lanes[i].ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
     }
     for (int i = 0; i < count; ++i) {
-        rc = chol_finish(jobs[i], st);
-        if (rc != SSA_OK) return rc;
+        FinishPlan<T> &fp = plans[i];
+        while (fp.next < fp.n_total) {
+            rc = fp.run_step(fp.next++, st);
+            if (rc != SSA_OK) return rc;
+        }
     }
     return SSA_OK;
 }

@@ -304,8 +304,12 @@ __device__ __forceinline__ void gemm_tile_edge(int64_t M, int64_t N, int64_t K, 
 }
 
 // Element strides of a two-level batch: matrix (y, z) of the grid starts at X + y * x1 + z * x2.
+// tri = 1: B is lower triangular (K == N): rows k < n0 of B do not reach the tile's columns;
+// tri = 2: A is lower triangular (M == K): columns k >= m0 + BM of A are zero for the tile's rows.
+// The K range of every tile shrinks accordingly (half the flops of a triangular product).
 struct BatchStrides {
     int64_t a1, a2, b1, b2, c1, c2;
+    int tri;
 };
 
 template <typename T, bool ALIGNED>
@@ -321,6 +325,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
     int64_t tm, tn;
     remap_tile(blockIdx.x, ntm, ntn, tm, tn);
     const int64_t m0 = tm * BM, n0 = tn * BN;
+    if (bs.tri == 1) {
+        const int64_t kb = (n0 < K) ? n0 : K;
+        A += kb;
+        B += kb * ldb;
+        K -= kb;
+    } else if (bs.tri == 2) {
+        K = (m0 + BM < K) ? m0 + BM : K;
+    }
     const bool full = ALIGNED && sizeof(T) == 8 && (m0 + BM <= M) && (n0 + BN <= N) &&
                       (K % KC == 0) && (K > 0) && alpha != T(0);
     if (full) {
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
 template <typename T>
 int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, int64_t lda,
                 const void *B, int64_t ldb, double beta, void *C, int64_t ldc, hipStream_t st,
-                int batch1 = 1, int batch2 = 1, BatchStrides bs = BatchStrides{0, 0, 0, 0, 0, 0}) {
+                int batch1 = 1, int batch2 = 1, BatchStrides bs = BatchStrides{0, 0, 0, 0, 0, 0, 0}) {
     if (M <= 0 || N <= 0 || batch1 <= 0 || batch2 <= 0) return SSA_OK;
     const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
     const size_t smem = sizeof(GemmSmem<T>);
@@ -356,7 +368,7 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, in
             return SSA_ERR_HIP;
         attr_set = true;
     }
-    ProfileScope scope(aligned && sizeof(T) == 8, kProfileGemmNN, 2.0 * M * N * K * batch1 * batch2, st);
+    ProfileScope scope(aligned && sizeof(T) == 8 && bs.tri == 0, kProfileGemmNN, 2.0 * M * N * K * batch1 * batch2, st);
     if (aligned) {
         hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(kGemmThreads), smem, st, M, N, K,
                            static_cast<T>(alpha), static_cast<const T *>(A), lda,
@@ -382,18 +394,18 @@ int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int6
     return launch_gemm<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
 }
 // Two-level batches of equal-sized products (chol.hip: one recursion level of all block inverses):
-// strides = {a1, a2, b1, b2, c1, c2} in elements.
+// strides = {a1, a2, b1, b2, c1, c2} in elements; tri: see BatchStrides.
 int gemm_batched_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int batch1,
-                     int batch2, const int64_t *strides, hipStream_t st) {
+                     int batch2, const int64_t *strides, int tri, hipStream_t st) {
     return launch_gemm<double>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, batch1, batch2,
-                               BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5]});
+                               BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], tri});
 }
 int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
                      const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int batch1,
-                     int batch2, const int64_t *strides, hipStream_t st) {
+                     int batch2, const int64_t *strides, int tri, hipStream_t st) {
     return launch_gemm<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, batch1, batch2,
-                              BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5]});
+                              BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], tri});
 }
 
 }  // namespace ssa
