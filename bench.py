@@ -23,9 +23,14 @@ time.
 
 The JSON line also carries
   roofline      -- the dominant kernel: the MFMA trailing update of the factorization
-                   (gemm_op_kernel SYRK for Cholesky, gemm_kernel for LU; MFMA bound):
-                   achieved = sum(flops of the tiles computed) / sum(kernel time), both measured
-                   live with HIP events inside the library (ssa_profile_*) over the timed region
+                   (gemm_op_kernel<double, 0, 1, true>, the lower-tile SYRK of the Cholesky; the NN
+                   gemm_kernel if the LU fallback ran; MFMA bound):
+                   achieved = sum(algorithmic flops, K M (M + 1) per launch) / sum(kernel time),
+                   both measured live with HIP events on the kernel's stream inside the library
+                   (ssa_profile_*) over the timed region; `traffic` = memory-side L2 bytes per
+                   launch from the rocprofv3 PMC passes of this same command
+                   (profiles/r01_v3_syrk_pmc.json, corrections in tools/summarize_pmc.py), next to
+                   the algorithmic bytes per launch (C tiles read + written, panel read once)
   cpu_baseline  -- the CPU oracle (numpy/scipy + OpenMP C ports of the numba kernels) timed on
                    this box's host cores on a bounded sample, rank 0 at N = 1 only.
 """
@@ -45,6 +50,33 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def syrk_algorithmic_bytes(unknowns, elem=8):
+    """Average algorithmic bytes of one trailing-update launch of the Cholesky schedule
+    (chol.hip potrf_batch): per outer step the lower 128 x 128 tiles of the (right - 256) trailing
+    block are read and written once and the 256-column panel below them is read once."""
+    total, launches = 0.0, 0
+    for n in unknowns:
+        npad = -(-n // 256) * 256
+        for k0 in range(0, npad - 256, 256):
+            m = npad - k0 - 512
+            if m <= 0:
+                continue
+            nt = m // 128
+            total += 2.0 * (nt * (nt + 1) // 2) * 128 * 128 * elem + m * 256 * elem
+            launches += 1
+    return total / max(1, launches), launches
+
+
+def pmc_traffic():
+    """Memory-side bytes per SYRK launch from the committed rocprofv3 PMC summary (None if absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_syrk_pmc.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse_args():
@@ -264,7 +296,11 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic() if "gemm_op_kernel" in dom_label else None,
+                "traffic_source": "profiles/r01_v3_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "this command; bytes per launch, fetch x2 per MI355X_MICROARCH.md)",
+                "algorithmic_bytes_per_launch": syrk_algorithmic_bytes(
+                    [int(len(s.indices)) for s in model.film_systems.values()])[0],
                 "launches": int(gemm_n.value),
                 "avg_launch_us": gemm_ms.value * 1e3 / max(1, gemm_n.value),
                 "avg_launch_gflop": gemm_fl.value / max(1, gemm_n.value) / 1e9,

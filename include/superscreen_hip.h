@@ -148,7 +148,9 @@ int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *
  *                    (1/3) n^3 flops, trailing update = MFMA SYRK on the lower tiles only.
  *                    info [1] int32 (device): 0, or > 0 if a pivot was not positive (then the
  *                    caller must fall back to ssa_lu_factor on a freshly assembled -A).
- *                    aux: ssa_chol_aux_bytes(n, dtype) (inverses of the diagonal blocks of L).
+ *                    On return the buffer holds L on/below and L^T above the diagonal (both
+ *                    triangular solves then stream row-major), and aux (ssa_chol_aux_bytes)
+ *                    the inverses of the 4096 x 4096 diagonal blocks of L and their transposes.
  *   ssa_chol_factor_batch: the films of one device (factorize_linear_systems loops over them,
  *                    solver/solve_film.py:174) factored in ONE interleaved schedule: all MFMA
  *                    trailing updates round-robin on the caller's stream, every film's panel

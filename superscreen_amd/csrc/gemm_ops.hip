@@ -233,12 +233,32 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int64_t tm, tn;
     if constexpr (LOWER) {
-        // lower-triangular tile enumeration: id -> (tm, tn <= tm), row by row
+        // Lower-triangular tile enumeration in bands of 8 tile rows, column by column inside a
+        // band: 64 consecutive ids (= what one XCD runs at a time) touch 8 row blocks + 8 column
+        // blocks of the panel (4 MB at K = 256, the size of the XCD's L2) instead of 1 + 64.
+        // Measured with FETCH_SIZE: row-by-row order re-read the panel ~60x through the fabric.
         const int64_t id = xcd_contiguous(blockIdx.x, gridDim.x);
-        tm = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5);
-        while (tm * (tm + 1) / 2 > id) --tm;
-        while ((tm + 1) * (tm + 2) / 2 <= id) ++tm;
-        tn = id - tm * (tm + 1) / 2;
+        constexpr int64_t G = 8;
+        // band b starts at id 8b (8b + 1) / 2
+        int64_t b = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5) / G;
+        while (G * b * (G * b + 1) / 2 > id) --b;
+        while (G * (b + 1) * (G * (b + 1) + 1) / 2 <= id) ++b;
+        const int64_t r0 = G * b;
+        const int64_t R = (ntm - r0 < G) ? ntm - r0 : G;  // tile rows in this band
+        int64_t l = id - r0 * (r0 + 1) / 2;
+        if (l < r0 * R) {  // full columns left of the band's diagonal blocks
+            tn = l / R;
+            tm = r0 + l % R;
+        } else {
+            l -= r0 * R;
+            int64_t j = 0;
+            while (l >= R - j) {  // column r0 + j holds rows r0 + j .. r0 + R - 1
+                l -= R - j;
+                ++j;
+            }
+            tn = r0 + j;
+            tm = r0 + j + l;
+        }
     } else {
         const int64_t wg = xcd_contiguous(blockIdx.x, ntm * ntn);
         constexpr int64_t G = 8;
