@@ -6,10 +6,11 @@
 //
 // Work decomposition: one workgroup (4 waves) owns a strip of TR consecutive rows and
 // sweeps all columns; lane <-> two adjacent columns, so each wave-instruction stores 1 KiB
-// (f64) of one row, fully coalesced.  Row coordinates are wave-uniform and come from LDS as
-// broadcast reads; the row sums needed for the diagonal stay in registers (TR per lane) and
-// are reduced once per strip (wave shuffle + one LDS hop), so the diagonal costs no extra
-// pass over memory.
+// (f64) of one row, fully coalesced.  Row coordinates are wave-uniform and are read with
+// scalar loads (SGPRs: no VGPR cost for the 16 rows of a strip); the row sums needed for the
+// diagonal stay in registers (TR per lane) and are reduced once per strip (wave shuffle + one
+// LDS hop), so the diagonal costs no extra pass over memory.  Optional row scaling and
+// lower-tiles-only output serve the Cholesky route (S = diag(w) A, chol.hip).
 #include "common.hpp"
 
 namespace ssa {

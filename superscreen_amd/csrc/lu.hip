@@ -4,9 +4,14 @@
 //
 //   outer panel NB = 256 columns  -> trailing update C -= L21 * U12 is an MFMA GEMM with
 //                                    K = 256 (compute-bound: 2K/16 = 32 flop per C byte)
-//   sub-panel   PW = 64 columns   -> factored by ONE cooperative persistent kernel
-//                                    (lu_panel_kernel); the rest of the outer panel is then
-//                                    updated by laswp + trsm + a skinny GEMM (L2 resident)
+//   sub-panel   PW = 64 columns   -> factored speculatively without interchanges and verified
+//                                    exactly (lu_panel_spec3_kernel, lu_spec3.hpp); only if
+//                                    the check fails, redone by ONE cooperative persistent
+//                                    kernel (lu_panel_kernel, below); the rest of the outer
+//                                    panel is then updated by laswp + trsm + a skinny GEMM
+//
+// This is the LAPACK-compatible route (method="lu", LinearSystem.lu_piv, fallback when
+// diag(w) A is not positive definite); homogeneous films go through chol.hip by default.
 //
 // lu_panel_kernel: the (m x 64) sub-panel is cut into row slabs of <= 256 rows, one
 // workgroup per slab, each slab living in LDS (column-major, lane <-> row, odd row stride =>
