@@ -303,3 +303,80 @@ def test_system_assemble_symmetric_scaled(K, disk):
     assert f.info == 0
     x = K.chol_solve(f, dev(-mesh.weights[ix] * h)).cpu().numpy()
     assert relerr(x, la.lu_solve(la.lu_factor(-A), h)) < 1e-12
+
+
+@pytest.mark.parametrize("n", [4096, 5000, 9000])
+def test_cholesky_block_solves(K, n):
+    """Orders beyond one 4096-row solve block: level-batched block inverses, L^T mirrored into the
+    upper triangle, triangular GEMV chain (single rhs) and GEMM chain (several)."""
+    rng = np.random.default_rng(n)
+    U = rng.standard_normal((n, 24))
+    S = U @ U.T / 24 + np.diag(2.0 + rng.random(n))
+    npad = K.chol_padded_n(n)
+    Sd = torch.full((npad, K.padded_ld(npad, "float64")), float("nan"), dtype=torch.float64, device="cuda")
+    Sd[:n, :n] = dev(np.tril(S))
+    f = K.chol_factor(Sd, n)
+    assert f.info == 0
+    F = f.L.cpu().numpy()[:n, :n]
+    Lref = np.linalg.cholesky(S)
+    assert relerr(np.tril(F), Lref) < 1e-12
+    assert np.array_equal(np.triu(F, 1), np.tril(F, -1).T)  # the mirror is a copy, not a recomputation
+    for nrhs in (1, 3):
+        b = rng.standard_normal((n, nrhs))
+        x = K.chol_solve(f, dev(b[:, 0].copy()) if nrhs == 1 else dev(b)).cpu().numpy().reshape(n, nrhs)
+        assert relerr(S @ x, b) < 1e-11
+        assert relerr(x, la.cho_solve((Lref, True), b)) < 1e-11
+
+
+def test_cholesky_batch_equals_single(K):
+    """ssa_chol_factor_batch (films interleaved on one schedule) is bit-identical to separate calls."""
+    rng = np.random.default_rng(5)
+    sizes = [1500, 4400, 700, 256]
+    mats = []
+    for n in sizes:
+        U = rng.standard_normal((n, 16))
+        mats.append(np.tril(U @ U.T / 16 + np.diag(1.5 + rng.random(n))))
+
+    def buf(S):
+        n = len(S)
+        npad = K.chol_padded_n(n)
+        t = torch.zeros((npad, K.padded_ld(npad, "float64")), dtype=torch.float64, device="cuda")
+        t[:n, :n] = dev(S)
+        return t
+
+    single = [K.chol_factor(buf(S), len(S)) for S in mats]
+    batch = K.chol_factor_batch([(buf(S), len(S)) for S in mats])
+    for S, a, b in zip(mats, single, batch):
+        n = len(S)
+        assert a.info == 0 and b.info == 0
+        assert torch.equal(a.L[:n, :n], b.L[:n, :n])
+        rhs = dev(rng.standard_normal(n))
+        assert torch.equal(K.chol_solve(a, rhs.clone()), K.chol_solve(b, rhs.clone()))
+    # one indefinite matrix in the batch is reported for that matrix only
+    bad = mats[2].copy()
+    bad[300, 300] = -5.0
+    res = K.chol_factor_batch([(buf(mats[0]), sizes[0]), (buf(bad), sizes[2])])
+    assert res[0].info == 0 and res[1].info > 0
+
+
+def test_cholesky_full_size_residual(K):
+    """BASELINE.json size (n_i = 20 419): S x = b to rounding, by a residual check that needs no
+    O(n^3) host work (S = D + U U^T built on the GPU)."""
+    n = 20419
+    g = torch.Generator(device="cuda").manual_seed(3)
+    U = torch.randn(n, 32, dtype=torch.float64, device="cuda", generator=g)
+    d = 2.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    npad = K.chol_padded_n(n)
+    Sd = torch.zeros((npad, K.padded_ld(npad, "float64")), dtype=torch.float64, device="cuda")
+    Sd[:n, :n] = U @ U.T / 32
+    Sd[:n, :n].diagonal().add_(d)
+    Sfull = Sd[:n, :n].clone()
+    f = K.chol_factor(Sd, n)
+    assert f.info == 0
+    b = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    x = K.chol_solve(f, b.clone())
+    r = (Sfull @ x - b).abs().max().item() / b.abs().max().item()
+    assert r < 1e-12
+    # linearity of the solve
+    x2 = K.chol_solve(f, (2.5 * b).clone())
+    assert (x2 - 2.5 * x).abs().max().item() <= 1e-13 * x.abs().max().item()
