@@ -255,6 +255,9 @@ def main():
         extras["q_assembly_ms"] = tq * 1e3
         extras["q_assembly_frac_of_hbm_peak"] = extras["q_assembly_GBps"] / HBM_PEAK_GBPS
         del Q
+        # what the FP64 matrix pipes sustain on this box (register-only MFMA stream): the practical
+        # ceiling next to the nominal peak the roofline fraction is priced against
+        extras["fp64_mfma_sustained_TFLOPs"] = kernels.mfma_probe(4000)
         # warm (pre-factorized) self-consistent solves
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -301,6 +304,7 @@ def main():
                                   "this command; bytes per launch, fetch x2 per MI355X_MICROARCH.md)",
                 "algorithmic_bytes_per_launch": syrk_algorithmic_bytes(
                     [int(len(s.indices)) for s in model.film_systems.values()])[0],
+                "frac_of_sustained_mfma": achieved / extras["fp64_mfma_sustained_TFLOPs"],
                 "launches": int(gemm_n.value),
                 "avg_launch_us": gemm_ms.value * 1e3 / max(1, gemm_n.value),
                 "avg_launch_gflop": gemm_fl.value / max(1, gemm_n.value) / 1e9,

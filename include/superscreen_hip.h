@@ -287,6 +287,14 @@ int ssa_profile_end(void);
 /* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern (roofline peak). */
 int ssa_fill_probe(void *dst, size_t bytes, void *stream);
 
+/*
+ * FP64 matrix-pipe probe: every wave of a chip-filling grid issues `iters` x 4 independent
+ * v_mfma_f64_16x16x4_f64 from registers (no memory traffic).  *flops_out (host) receives the
+ * flops issued; time the launch to get the MFMA rate the chip sustains (clock under matrix load),
+ * the practical ceiling next to the nominal 78.6 TFLOP/s.  sink: >= 8 bytes of device memory.
+ */
+int ssa_mfma_probe(int iters, void *sink, double *flops_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

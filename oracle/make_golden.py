@@ -274,8 +274,89 @@ def biot_savart_fixture(fname):
     print("wrote", fname)
 
 
+def mutual_fixture(K, kinds, z0s, Lambda, iterations, fname, I_circ=1000.0):
+    """Raw fluxoid parts behind ``Device.mutual_inductance_matrix`` (device/device.py:538-648):
+    for every hole j, a circulating current I_circ (uA) in hole j only, no applied field, the Jacobi
+    loop of ``solve``, then for every hole i the two raw parts of ``polygon_fluxoid``
+    (solution.py:535-559) of a circle around hole i, for every iterate."""
+    from matplotlib.tri import LinearTriInterpolator, Triangulation
+
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = Mesh.from_triangulation(sites, elements)
+    n = len(sites)
+    names = [f"{k}{i}" for i, k in enumerate(kinds)]
+    device_like = SimpleNamespace(terminals={}, meshes={nm: mesh for nm in names})
+    hole_names = [f"hole_{nm}" for nm, kind in zip(names, kinds) if kind == "washer"]
+    film_of = {f"hole_{nm}": nm for nm in names}
+    Kf = synthetic.film_rings(K)
+    r_poly = (Kf // 3 + (Kf - Kf // 3) / 2 + 0.25) * dr
+    poly = synthetic.circle_points(r_poly, 101)
+    tri = Triangulation(sites[:, 0], sites[:, 1], elements)
+    z0 = dict(zip(names, z0s))
+    flux_raw = np.zeros((iterations + 1, len(hole_names), len(hole_names)))
+    intJ_raw = np.zeros_like(flux_raw)
+    for j, src_hole in enumerate(hole_names):
+        infos = {}
+        film_poly = None
+        for nm, kind in zip(names, kinds):
+            film_poly, holes = polygons_for(K, dr, kind == "washer")
+            holes = {f"hole_{nm}": p for p in holes.values()}
+            infos[nm] = make_film_info(nm, f"layer_{nm}", mesh, film_poly, holes, Lambda,
+                                       {h: (I_circ if h == src_hole else 0.0) for h in holes}, "float64")
+        film_systems, hole_systems, _ = factorize_linear_systems(device_like, infos)
+        applied = {nm: np.zeros(n) for nm in names}
+
+        def run(other):
+            return {
+                nm: solve_film(
+                    device=device_like, applied_field=applied[nm], film_info=infos[nm],
+                    film_system=film_systems[nm], hole_systems=hole_systems[nm],
+                    field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX,
+                    field_from_other_films=None if other is None else other[nm],
+                )
+                for nm in names
+            }
+
+        sols = run(None)
+        trace = [sols]
+        for it in range(iterations):
+            other = {nm: np.zeros(n) for nm in names}
+            for src, tgt in itertools.product(names, repeat=2):
+                if src == tgt:
+                    continue
+                other[tgt] += biot_savart_film_to_film(
+                    film1_sites=mesh.sites, film1_z0=z0[src], film1_areas=infos[src].weights,
+                    film1_J=sols[src].current_density, film2_sites=mesh.sites, film2_z0=z0[tgt],
+                )
+            sols = run(other)
+            trace.append(sols)
+        for it, s_all in enumerate(trace):
+            for i, hole in enumerate(hole_names):
+                s = s_all[film_of[hole]]
+                total = s.applied_field + s.self_field
+                if s.field_from_other_films is not None:
+                    total = total + s.field_from_other_films
+                ix = contains(poly, mesh.sites)
+                flux_raw[it, i, j] = np.einsum("i, i ->", total[ix], mesh.vertex_areas[ix])
+                J = s.current_density
+                Jp = np.array([LinearTriInterpolator(tri, J[:, 0])(poly[:, 0], poly[:, 1]).data,
+                               LinearTriInterpolator(tri, J[:, 1])(poly[:, 0], poly[:, 1]).data]).T
+                Jp[~contains(film_poly, poly)] = 0
+                Jp[~np.isfinite(Jp).all(axis=1)] = 0
+                dl = np.diff(poly, axis=0)
+                intJ_raw[it, i, j] = np.trapezoid(Lambda * np.ones(len(poly))[:-1] * np.sum(Jp[:-1] * dl, axis=1))
+    np.savez_compressed(os.path.join(GOLDEN, fname), K=K, kinds=np.array(kinds), z0s=np.asarray(z0s, float),
+                        Lambda=Lambda, iterations=iterations, I_circ_uA=I_circ, names=np.array(names),
+                        hole_names=np.array(hole_names), fluxoid_poly=poly, flux_part_raw=flux_raw,
+                        int_J_raw=intJ_raw, field_conversion=FIELD_CONV)
+    print("wrote", fname, "n =", n, "holes", hole_names)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
+    if "--only-mutual" in sys.argv:
+        mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
+        sys.exit(0)
     single_film_fixture(10, False, [0.0, 0.1, 1.0], [0.0], "disk_K10.npz", full_Q=True)
     single_film_fixture(26, False, [0.1], [0.0], "disk_K26.npz", full_Q=False)
     single_film_fixture(17, True, [0.1, 1.0], [0.0, 1.0], "washer_K17.npz", full_Q=False)
@@ -283,3 +364,4 @@ if __name__ == "__main__":
     stack_fixture(8, ("disk", "washer", "disk"), (0.0, 0.5, 1.0), 0.1, 3, "stack3_K8.npz",
                   circ=2.0, field_mT=0.5)
     biot_savart_fixture("biot_savart.npz")
+    mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")

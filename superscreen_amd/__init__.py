@@ -16,6 +16,7 @@ _LAZY = {
     "convert_field": "units", "field_conversion_factor": "units",
     "Solution": "solution", "FilmSolution": "solution", "Fluxoid": "solution",
     "Vortex": "solution",
+    "find_fluxoid_solution": "fluxoid", "make_fluxoid_polygons": "fluxoid",
 }
 
 

@@ -63,6 +63,7 @@ SIGNATURES = {
                                 c_size_t, P]),
     "ssa_gemm": (c_int, [I64, I64, I64, c_double, P, I64, P, I64, c_double, P, I64, c_int, P]),
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),
+    "ssa_mfma_probe": (c_int, [c_int, P, P, P]),
     "ssa_profile_begin": (c_int, []),
     "ssa_profile_end": (c_int, []),
 }

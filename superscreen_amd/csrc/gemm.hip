@@ -412,6 +412,30 @@ int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float 
 
 using namespace ssa;
 
+namespace ssa {
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double *sink, int iters) {
+    f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = threadIdx.x * 1e-3, b = 1.0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.678) sink[0] = 1.0;  // never true: keeps the loop alive
+}
+}  // namespace ssa
+
+extern "C" int ssa_mfma_probe(int iters, void *sink, double *flops_out, void *stream) {
+    if (iters <= 0 || !sink) return SSA_ERR_INVALID_ARGUMENT;
+    constexpr int kGrid = 2048;  // 8 workgroups of 4 waves per CU
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(kGrid), dim3(256), 0, as_stream(stream),
+                       static_cast<double *>(sink), iters);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    if (flops_out) *flops_out = static_cast<double>(kGrid) * 4.0 * iters * 4.0 * 2.0 * 16 * 16 * 4;
+    return SSA_OK;
+}
+
 extern "C" int ssa_profile_begin(void) {
     g_prof.used = 0;
     g_prof.enabled = true;

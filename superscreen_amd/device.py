@@ -11,11 +11,13 @@ solve_dtype="float32")`` with ``films / holes / layers / meshes / terminals``,
 
 Out of scope: geometry authoring (boolean ops, buffering, resampling --
 needs shapely), meshing with meshpy/Triangle (``Device.make_mesh`` here meshes only what the
-synthetic mesher supports, or takes explicit triangulations), plotting, HDF5, transforms,
-``mutual_inductance_matrix`` (listed as "next" in section 8f).
+synthetic mesher supports, or takes explicit triangulations), plotting, HDF5, transforms.
+``mutual_inductance_matrix`` (``device/device.py:538-648``, row 1 of "next" in section 8f) is
+implemented: it only loops ``solve(model=...)``.
 """
 from __future__ import annotations
 
+import logging
 import numbers
 from copy import deepcopy
 from typing import Dict, List, Optional, Sequence, Tuple, Union
@@ -24,6 +26,9 @@ import numpy as np
 
 from .geometry import close_curve
 from .parameter import Parameter
+
+
+logger = logging.getLogger(__name__)
 
 
 class Layer:
@@ -312,6 +317,64 @@ class Device:
         if missing:
             raise ValueError(f"No triangulation given for films {sorted(missing)!r}.")
         self.meshes = {name: Mesh.from_triangulation(*triangulations[name]) for name in self.films}
+
+    def mutual_inductance_matrix(self, hole_polygon_mapping: Optional[Dict[str, np.ndarray]] = None,
+                                 units: str = "pH", all_iterations: bool = False, progress_bar: bool = False,
+                                 **solve_kwargs):
+        """``M[i, j] = fluxoid(polygon S_i around hole i) / I_j`` for a current ``I_j`` circulating
+        around hole ``j`` (``device/device.py:538-648``): one factorization, one warm
+        ``solve(model=...)`` per hole.  Returns a :class:`~superscreen_amd.units.Quantity` holding
+        the ``(n_holes, n_holes)`` matrix, or a list of them (one per iterate) if ``all_iterations``."""
+        from .fluxoid import make_fluxoid_polygons
+        from .solver import factorize_model, solve
+        from .units import PHI_0, Quantity, parse_units
+
+        holes = self.holes
+        hole_names = list(holes)
+        if hole_polygon_mapping is None:
+            hole_polygon_mapping = make_fluxoid_polygons(self)
+        n_holes = len(hole_polygon_mapping)
+        for hole_name, polygon in hole_polygon_mapping.items():
+            if hole_name not in holes:
+                raise ValueError(f"Hole '{hole_name}' does not exist in the device.")
+            if not Polygon(points=polygon).contains_points(holes[hole_name].points).all():
+                raise ValueError(f"Hole '{hole_name}' is not completely contained within the given polygon.")
+        solve_kwargs = dict(solve_kwargs)
+        iterations = solve_kwargs.get("iterations", 1)
+        solve_kwargs["progress_bar"] = False
+        solve_kwargs.pop("current_units", None)
+        I_circ_A = 1e-3  # 1 mA; the magnitude is not important (device.py:597)
+        if all_iterations:
+            n_iter = 1 if len(self.layers) == 1 else iterations + 1
+            solution_slice = slice(None)
+        else:
+            n_iter = 1
+            solution_slice = slice(-1, None)
+        mutual = np.zeros((n_iter, n_holes, n_holes))
+        films_by_hole = {hole.name: film for film, hs in self.holes_by_film().items() for hole in hs}
+        to_units = PHI_0 / I_circ_A / parse_units(units).scale  # (Phi_0 / I) -> `units`
+        if parse_units(units).dims != parse_units("H").dims:
+            raise ValueError(f"{units!r} is not a unit of inductance.")
+        model = None
+        for j, hole_name in enumerate(hole_names):
+            logger.info(f"Evaluating {self.name!r} mutual inductance matrix column "
+                        f"({j + 1}/{len(hole_names)}), source = {hole_name!r}.")
+            if model is None:
+                model = factorize_model(device=self, current_units="mA", circulating_currents={hole_name: "1 mA"})
+                I_circ_val = model.circulating_currents[hole_name]
+            else:
+                model.set_circulating_currents({hole_name: I_circ_val})
+            solutions = solve(model=model, **solve_kwargs)[solution_slice]
+            for n, solution in enumerate(solutions):
+                for i, name in enumerate(hole_names):
+                    fluxoid = solution.polygon_fluxoid(hole_polygon_mapping[name], film=films_by_hole[name],
+                                                       units="Phi_0", with_units=False)
+                    mutual[n, i, j] = sum(fluxoid) * to_units
+        result = [Quantity(m, units) for m in mutual]
+        if not all_iterations:
+            assert len(result) == 1
+            return result[0]
+        return result
 
     def __repr__(self) -> str:
         return (f"Device({self.name!r}, layers={list(self.layers)!r}, films={list(self.films)!r}, "

@@ -330,6 +330,20 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
     return C
 
 
+def mfma_probe(iters: int = 2000) -> float:
+    """Sustained FP64 MFMA rate of this GPU in TFLOP/s (register-only instruction stream)."""
+    lib = load_library()
+    sink = torch.zeros(1, dtype=torch.float64, device="cuda")
+    flops = ctypes.c_double(0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check(lib.ssa_mfma_probe(iters, ptr(sink), ctypes.byref(flops), current_stream()), "ssa_mfma_probe")  # warm-up
+    e0.record()
+    check(lib.ssa_mfma_probe(iters, ptr(sink), ctypes.byref(flops), current_stream()), "ssa_mfma_probe")
+    e1.record()
+    torch.cuda.synchronize()
+    return flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def fill_probe(buf: torch.Tensor) -> None:
     lib = load_library()
     check(lib.ssa_fill_probe(ptr(buf), buf.numel() * buf.element_size(), current_stream()),

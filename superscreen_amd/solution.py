@@ -184,13 +184,12 @@ class Solution:
                      interp_method: str = "linear", units: Optional[str] = "Phi_0",
                      with_units: bool = True) -> Fluxoid:
         """Fluxoid of a polygon enclosing a hole (``solution.py:565-609``).  Without ``points`` the
-        reference buffers the hole with shapely (``fluxoid.py:13-52``); that is out of scope, so
-        ``points`` is required here."""
-        if points is None:
-            raise NotImplementedError(
-                "make_fluxoid_polygons needs shapely (out of scope): pass the enclosing polygon."
-            )
+        polygon comes from :func:`superscreen_amd.fluxoid.make_fluxoid_polygons`."""
         device = self.device
+        if points is None:
+            from .fluxoid import make_fluxoid_polygons
+
+            points = make_fluxoid_polygons(device, holes=hole_name)[hole_name]
         hole = device.holes[hole_name]
         if not Polygon(points=points).contains_points(hole.points).all():
             raise ValueError(f"Hole {hole.name} is not completely enclosed by the given polygon.")

@@ -146,3 +146,44 @@ def test_no_cpu_fallback_without_gpu():
         sc.solve(device, applied_field=sc.ConstantField(1))
     with pytest.raises(HipLibraryError):
         _ = device.meshes["disk0"].operators.Q
+
+
+def test_fluxoid_polygons_without_shapely():
+    """make_fluxoid_polygons (fluxoid.py:13-52): the hole outline offset halfway to the nearest
+    other outline of its layer, mitre joins."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+    from superscreen_amd.fluxoid import _offset_mitre, _outline_distance
+
+    device = synthetic.make_stack_device(12, ("washer", "disk", "washer"), z_spacing=0.4)
+    polys = sc.make_fluxoid_polygons(device)
+    assert set(polys) == {"hole0", "hole2"}
+    for name, pts in polys.items():
+        hole = device.holes[name]
+        film = [f for f in device.films.values() if f.layer == hole.layer][0]
+        assert np.allclose(pts[0], pts[-1])
+        assert sc.Polygon(points=pts).contains_points(hole.points).all()   # encloses the hole
+        assert film.contains_points(pts).all()                              # stays inside the film
+        r = np.linalg.norm(pts, axis=1)
+        r_hole, r_film = np.linalg.norm(hole.points, axis=1).max(), np.linalg.norm(film.points, axis=1).max()
+        assert abs(r.mean() - 0.5 * (r_hole + r_film)) < 2e-3 * r_film  # halfway (up to chord sagitta)
+    # exact cases: a square offset by 1 with mitre joins is the bigger square
+    sq = np.array([[0, 0], [2, 0], [2, 2], [0, 2], [0, 0]], float)
+    assert np.allclose(_offset_mitre(sq, 1.0), np.array([[-1, -1], [3, -1], [3, 3], [-1, 3], [-1, -1]], float))
+    assert abs(_outline_distance(sq, sq + np.array([5.0, 0.0])) - 3.0) < 1e-14
+    one = sc.make_fluxoid_polygons(device, holes="hole0", interp_points=51)
+    assert one["hole0"].shape == (51, 2)
+    with pytest.raises(NotImplementedError):
+        sc.make_fluxoid_polygons(device, join_style="round")
+
+
+def test_mutual_inductance_argument_checks():
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(8, ("washer",))
+    tiny = synthetic.circle_points(0.1, 33)
+    with pytest.raises(ValueError, match="does not exist"):
+        device.mutual_inductance_matrix(hole_polygon_mapping={"nope": tiny})
+    with pytest.raises(ValueError, match="not completely contained"):
+        device.mutual_inductance_matrix(hole_polygon_mapping={"hole0": tiny})

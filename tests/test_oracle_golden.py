@@ -125,3 +125,24 @@ def test_jacobi_trace_and_fluxoid(golden, name):
                                           contains(poly, film.mesh.sites), contains(film_poly, poly))
     assert abs(flux - float(d["flux_part_raw"])) < 1e-10 * abs(float(d["flux_part_raw"]))
     assert abs(int_J - float(d["int_J_raw"])) < 1e-10 * abs(float(d["int_J_raw"]))
+
+
+def test_mutual_inductance_raw_parts(golden):
+    """The raw fluxoid parts behind Device.mutual_inductance_matrix (device/device.py:538-648),
+    recorded from the reference for a circulating current in one hole at a time."""
+    d = golden("mutual_K12.npz")
+    films, film_poly = _stack(d)
+    poly = d["fluxoid_poly"]
+    hole_names = [str(h) for h in d["hole_names"]]
+    film_of = {f"hole_{f.name}": f for f in films}
+    for j, src in enumerate(hole_names):
+        circ = {h: (float(d["I_circ_uA"]) if h == src else 0.0) for h in hole_names}
+        trace = orc.solve(films, 0.0, iterations=int(d["iterations"]), circulating_currents=circ,
+                          field_conversion=float(d["field_conversion"]))
+        for it, sols in enumerate(trace):
+            for i, hole in enumerate(hole_names):
+                film = film_of[hole]
+                flux, int_J = orc.polygon_fluxoid_raw(film, sols[film.name], poly,
+                                                      contains(poly, film.mesh.sites), contains(film_poly, poly))
+                assert abs(flux - d["flux_part_raw"][it, i, j]) <= 1e-10 * abs(d["flux_part_raw"][:, :, j]).max()
+                assert abs(int_J - d["int_J_raw"][it, i, j]) <= 1e-10 * abs(d["int_J_raw"][:, :, j]).max()

@@ -229,3 +229,56 @@ def test_coupling_plan_matches_single_stream_path(sc):
                                 accumulate=True, src_begin=b, src_end=e)
     for nm in films:
         assert relerr(part[nm].cpu().numpy(), full[nm].cpu().numpy()) < 1e-13
+
+
+def test_mutual_inductance_matrix_vs_reference(golden):
+    """Device.mutual_inductance_matrix (device/device.py:538-648) against the raw fluxoid parts the
+    reference produces for one circulating current at a time (tests/golden/mutual_K12.npz)."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+    from superscreen_amd.units import MU_0
+
+    d = golden("mutual_K12.npz")
+    device = synthetic.make_stack_device(int(d["K"]), tuple(str(k) for k in d["kinds"]),
+                                         z_spacing=float(d["z0s"][1]), Lambda=float(d["Lambda"]))
+    poly = d["fluxoid_poly"]
+    mapping = {"hole0": poly, "hole1": poly}
+    iterations = int(d["iterations"])
+    # reference raw parts: flux [mT um^2], Lambda J dl [uA um]; fluxoid / I_circ -> H -> pH
+    I_A = float(d["I_circ_uA"]) * 1e-6
+    M_ref = (d["flux_part_raw"] * 1e-3 * 1e-12 + MU_0 * d["int_J_raw"] * 1e-6 * 1e-6) / I_A / 1e-12
+    Ms = device.mutual_inductance_matrix(hole_polygon_mapping=mapping, units="pH", all_iterations=True,
+                                         iterations=iterations)
+    assert len(Ms) == iterations + 1
+    for it, M in enumerate(Ms):
+        assert np.max(np.abs(np.asarray(M.magnitude) - M_ref[it])) < 1e-9 * np.max(np.abs(M_ref[it]))
+    M_last = device.mutual_inductance_matrix(hole_polygon_mapping=mapping, units="pH", iterations=iterations)
+    assert np.array_equal(np.asarray(M_last.magnitude), np.asarray(Ms[-1].magnitude))
+    # other units: Phi_0 / A
+    M2 = device.mutual_inductance_matrix(hole_polygon_mapping=mapping, units="Phi_0 / A", iterations=iterations)
+    assert np.allclose(np.asarray(M2.magnitude), np.asarray(M_last.to("Phi_0 / A").magnitude), rtol=1e-12)
+    # physics: self inductances positive, coupling symmetric to discretisation accuracy
+    m = np.asarray(M_last.magnitude)
+    assert m[0, 0] > 0 and m[1, 1] > 0 and abs(m[0, 1] - m[1, 0]) < 0.05 * abs(m[0, 1])
+
+
+def test_find_fluxoid_solution():
+    """find_fluxoid_solution (fluxoid.py:55-119): the returned solution has the requested fluxoids."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(12, ("washer", "washer"), z_spacing=0.4)
+    model = sc.factorize_model(device=device, current_units="uA")
+    polys = sc.make_fluxoid_polygons(device)
+    target = {"hole0": 1.0, "hole1": -2.0}
+    kw = dict(applied_field=sc.ConstantField(0.05), field_units="mT", iterations=40)
+    sol = sc.find_fluxoid_solution(model, fluxoids=target, **kw)
+    for name, want in target.items():
+        got = float(sum(sol.hole_fluxoid(name, points=polys[name], with_units=False)))
+        assert abs(got - want) < 1e-6
+    assert all(v == 0 for v in model.circulating_currents.values())  # the model is restored
+    # default target: zero fluxoid in every hole (Meissner state of the rings)
+    sol0 = sc.find_fluxoid_solution(model, **kw)
+    for name in target:
+        assert abs(float(sum(sol0.hole_fluxoid(name, with_units=False)))) < 1e-6
+    assert sol0.circulating_currents["hole0"] != 0
