@@ -255,9 +255,22 @@ def main():
         extras["q_assembly_ms"] = tq * 1e3
         extras["q_assembly_frac_of_hbm_peak"] = extras["q_assembly_GBps"] / HBM_PEAK_GBPS
         del Q
-        # what the FP64 matrix pipes sustain on this box (register-only MFMA stream): the practical
-        # ceiling next to the nominal peak the roofline fraction is priced against
-        extras["fp64_mfma_sustained_TFLOPs"] = kernels.mfma_probe(4000)
+        # what a register-only v_mfma_f64 stream reaches on this box right now (no memory, no LDS):
+        # the matrix pipes are clock / power limited well below the nominal 78.6 TFLOP/s the roofline
+        # fraction is priced against (46-62 TFLOP/s observed, depending on the thermal state)
+        extras["fp64_mfma_register_only_TFLOPs"] = kernels.mfma_probe(4000)
+        # field map above the device: 512 x 512 image, all-pairs Biot-Savart of one film
+        gx = torch.linspace(-6.0, 6.0, 512, dtype=torch.float64, device="cuda")
+        ev = torch.stack([gx.repeat_interleave(512), gx.repeat(512), torch.full((512 * 512,), 1.0, dtype=torch.float64,
+                                                                                device="cuda")], dim=1).contiguous()
+        Jd = torch.from_numpy(sols[-1].film_solutions["washer0"].current_density).cuda()
+        kernels.sheet_field(fd.xy, fd.w, Jd, 0.0, ev, 1e-7, True)
+        e0.record()
+        kernels.sheet_field(fd.xy, fd.w, Jd, 0.0, ev, 1e-7, True)
+        e1.record()
+        torch.cuda.synchronize()
+        extras["field_map_512x512_vector_ms"] = e0.elapsed_time(e1)
+        extras["field_map_Tpairs_per_s"] = 512 * 512 * n / (e0.elapsed_time(e1) * 1e-3) / 1e12
         # warm (pre-factorized) self-consistent solves
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -304,7 +317,6 @@ def main():
                                   "this command; bytes per launch, fetch x2 per MI355X_MICROARCH.md)",
                 "algorithmic_bytes_per_launch": syrk_algorithmic_bytes(
                     [int(len(s.indices)) for s in model.film_systems.values()])[0],
-                "frac_of_sustained_mfma": achieved / extras["fp64_mfma_sustained_TFLOPs"],
                 "launches": int(gemm_n.value),
                 "avg_launch_us": gemm_ms.value * 1e3 / max(1, gemm_n.value),
                 "avg_launch_gflop": gemm_fl.value / max(1, gemm_n.value) / 1e9,

@@ -170,6 +170,23 @@ size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
 int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
                    int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Replaces the numba kernels _biot_savart_2d_z / _biot_savart_2d_vector
+ * (sources/current.py:13-57, :60-110) behind biot_savart_2d (:113-199) and
+ * Solution.screening_field_at_position / field_at_position (solution.py:611-831):
+ * field of the sheet current of one film at arbitrary points,
+ *   pref_k = a_k |r - r_k|^-3,  r - r_k = (dx, dy, dz),  r_k = (x_k, y_k, z0)
+ *   vector == 0:  out[i]   = prefactor * sum_k pref_k (Jx_k dy - Jy_k dx)
+ *   vector != 0:  out[i,:] = prefactor * sum_k pref_k (Jy_k dz, -Jx_k dz, Jx_k dy - Jy_k dx)
+ * src_xy [ns,2], src_areas [ns], src_J [ns,2], eval_xyz [np,3], out [np] or [np,3]: float64, in the
+ * caller's length / current units; prefactor = (mu_0 / 4 pi) * (A/m per current_unit/length_unit)
+ * gives tesla.  Deterministic two-stage reduction; workspace ssa_sheet_field_workspace_bytes.
+ */
+size_t ssa_sheet_field_workspace_bytes(int64_t np, int vector);
+int ssa_sheet_field(const double *src_xy, const double *src_areas, const double *src_J, int64_t ns,
+                    double z0, const double *eval_xyz, int64_t np, double prefactor, int vector,
+                    double *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------- */
 /* (3) Per-film vector kernels of solve_film                                           */
 /* ---------------------------------------------------------------------------------- */

@@ -274,6 +274,31 @@ def biot_savart_fixture(fname):
     print("wrote", fname)
 
 
+def sheet_field_fixture(fname):
+    """The numba kernels behind ``biot_savart_2d`` (sources/current.py:13-110), driven exactly as
+    the wrapper does (:166-198): everything converted to metres and A/m first."""
+    from superscreen.sources.current import _biot_savart_2d_vector, _biot_savart_2d_z  # the reference
+
+    rng = np.random.default_rng(7)
+    sites, elements, _ = synthetic.ring_disk_mesh(7)
+    mesh = Mesh.from_triangulation(sites, elements)
+    J = rng.standard_normal((len(sites), 2))            # uA / um
+    areas = mesh.vertex_areas                            # um^2
+    z0 = 0.3                                             # um
+    ev = np.concatenate([
+        np.column_stack([rng.uniform(-7, 7, 30), rng.uniform(-7, 7, 30), rng.uniform(0.5, 3.0, 30)]),
+        np.column_stack([rng.uniform(6, 9, 6), rng.uniform(-2, 2, 6), np.full(6, z0)]),   # in plane, outside
+        np.column_stack([rng.uniform(-4, 4, 6), rng.uniform(-4, 4, 6), rng.uniform(-2.0, -0.2, 6)]),
+    ])
+    to_m, to_A_per_m = 1e-6, 1.0                         # um -> m ; uA/um -> A/m
+    pos_SI = np.concatenate([sites * to_m, (z0 * to_m) * np.ones((len(sites), 1))], axis=1)
+    Bz = _biot_savart_2d_z(ev * to_m, pos_SI, J * to_A_per_m, areas * to_m**2)
+    Bv = _biot_savart_2d_vector(ev * to_m, pos_SI, J * to_A_per_m, areas * to_m**2)
+    np.savez_compressed(os.path.join(GOLDEN, fname), sites=sites, elements=elements, J=J, areas=areas, z0=z0,
+                        eval_xyz=ev, Bz_tesla=Bz, B_tesla=Bv)
+    print("wrote", fname)
+
+
 def mutual_fixture(K, kinds, z0s, Lambda, iterations, fname, I_circ=1000.0):
     """Raw fluxoid parts behind ``Device.mutual_inductance_matrix`` (device/device.py:538-648):
     for every hole j, a circulating current I_circ (uA) in hole j only, no applied field, the Jacobi
@@ -357,6 +382,9 @@ if __name__ == "__main__":
     if "--only-mutual" in sys.argv:
         mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
         sys.exit(0)
+    if "--only-sheet-field" in sys.argv:
+        sheet_field_fixture("sheet_field.npz")
+        sys.exit(0)
     single_film_fixture(10, False, [0.0, 0.1, 1.0], [0.0], "disk_K10.npz", full_Q=True)
     single_film_fixture(26, False, [0.1], [0.0], "disk_K26.npz", full_Q=False)
     single_film_fixture(17, True, [0.1, 1.0], [0.0, 1.0], "washer_K17.npz", full_Q=False)
@@ -365,3 +393,4 @@ if __name__ == "__main__":
                   circ=2.0, field_mT=0.5)
     biot_savart_fixture("biot_savart.npz")
     mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
+    sheet_field_fixture("sheet_field.npz")

@@ -60,6 +60,76 @@ __global__ __launch_bounds__(kPairThreads) void biot_savart_partial_kernel(
     if (i < nt) partial[static_cast<int64_t>(blockIdx.y) * nt + i] = acc;
 }
 
+// Field of a current sheet at arbitrary points in space (sources/current.py:13-110, the numba
+// kernels _biot_savart_2d_z / _biot_savart_2d_vector behind Solution.field_at_position): same
+// skeleton, per-point dz, NC = 1 (z component) or 3 (vector) accumulators per evaluation point.
+//   Bx += pref Jy dz,   By -= pref Jx dz,   Bz += pref (Jx dy - Jy dx),   pref = a_k r^-3
+// (the unit prefactor mu_0 / 4 pi * [A/m per current unit / length unit] is applied by the combine).
+template <int NC>
+__global__ __launch_bounds__(kPairThreads) void sheet_field_partial_kernel(
+    const double *__restrict__ src_xy, const double *__restrict__ src_areas, const double *__restrict__ src_J,
+    int64_t ns, int64_t slice_len, double z0, const double *__restrict__ eval_xyz, int64_t np,
+    double *__restrict__ partial) {
+    __shared__ Source s_src[kPairThreads];
+    const int tid = threadIdx.x;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
+    const int64_t j_end = (j_begin + slice_len < ns) ? j_begin + slice_len : ns;
+    const int64_t ic = (i < np) ? i : np - 1;
+    const double xi = eval_xyz[3 * ic], yi = eval_xyz[3 * ic + 1], dz = eval_xyz[3 * ic + 2] - z0;
+    const double dz2 = dz * dz;
+    double az = 0.0, sa = 0.0, sb = 0.0;  // Bz, sum pref a_k Jx, sum pref a_k Jy
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        const int64_t j = t0 + tid;
+        Source s;
+        if (j < j_end) {
+            const double a = src_areas[j];
+            s.x = src_xy[2 * j];
+            s.y = src_xy[2 * j + 1];
+            s.a = a * src_J[2 * j];
+            s.b = a * src_J[2 * j + 1];
+        } else {
+            s.x = 0.0; s.y = 0.0; s.a = 0.0; s.b = 0.0;
+        }
+        __syncthreads();
+        s_src[tid] = s;
+        __syncthreads();
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const Source q = s_src[k];
+            const double dx = xi - q.x, dy = yi - q.y;
+            const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
+            const double y = rsqrt_f64(r2);
+            const double y3 = y * (y * y);
+            az = __builtin_fma(__builtin_fma(q.a, dy, -(q.b * dx)), y3, az);
+            if (NC == 3) {
+                sa = __builtin_fma(q.a, y3, sa);
+                sb = __builtin_fma(q.b, y3, sb);
+            }
+        }
+    }
+    if (i < np) {
+        double *dst = partial + (static_cast<int64_t>(blockIdx.y) * np + i) * NC;
+        if (NC == 3) {
+            dst[0] = sb * dz;   // Jy dz
+            dst[1] = -sa * dz;  // -Jx dz
+            dst[2] = az;
+        } else {
+            dst[0] = az;
+        }
+    }
+}
+
+__global__ void sheet_field_combine_kernel(const double *__restrict__ partial, int slices, int64_t count,
+                                           double prefactor, double *__restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int k = 0; k < slices; ++k) s += partial[static_cast<int64_t>(k) * count + i];
+    out[i] = prefactor * s;
+}
+
 // out[i] = alpha * ( qdiag_i w_i g_i - sum_{j != i} q_ij w_j g_j )   (partials: the sum only)
 template <typename T>
 __global__ __launch_bounds__(kPairThreads) void self_field_partial_kernel(
@@ -181,6 +251,37 @@ extern "C" int ssa_biot_savart(const double *src_xy, const void *src_areas, cons
         hipLaunchKernelGGL((combine_partials_kernel<float>), cgrid, dim3(256), 0, st, partial,
                            slices, nt, static_cast<float *>(out), accumulate);
     }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" size_t ssa_sheet_field_workspace_bytes(int64_t np, int vector) {
+    return static_cast<size_t>(kMaxSlices) * static_cast<size_t>(np) * (vector ? 3 : 1) * sizeof(double) + 256;
+}
+
+extern "C" int ssa_sheet_field(const double *src_xy, const double *src_areas, const double *src_J, int64_t ns,
+                               double z0, const double *eval_xyz, int64_t np, double prefactor, int vector,
+                               double *out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!src_xy || !src_areas || !src_J || !eval_xyz || !out || ns <= 0 || np <= 0)
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_sheet_field_workspace_bytes(np, vector))
+        return SSA_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = as_stream(stream);
+    double *partial = static_cast<double *>(workspace);
+    int slices = pick_slices(np, ns);
+    const int64_t slice_len = ceil_div(ceil_div(ns, slices), kPairThreads) * kPairThreads;
+    slices = static_cast<int>(ceil_div(ns, slice_len));
+    const dim3 grid(static_cast<unsigned>(ceil_div(np, kPairThreads)), slices);
+    const int nc = vector ? 3 : 1;
+    if (vector)
+        hipLaunchKernelGGL((sheet_field_partial_kernel<3>), grid, dim3(kPairThreads), 0, st, src_xy, src_areas,
+                           src_J, ns, slice_len, z0, eval_xyz, np, partial);
+    else
+        hipLaunchKernelGGL((sheet_field_partial_kernel<1>), grid, dim3(kPairThreads), 0, st, src_xy, src_areas,
+                           src_J, ns, slice_len, z0, eval_xyz, np, partial);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(sheet_field_combine_kernel, dim3(static_cast<unsigned>(ceil_div(np * nc, 256))), dim3(256), 0,
+                       st, partial, slices, np * nc, prefactor, out);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }

@@ -330,6 +330,21 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
     return C
 
 
+def sheet_field(src_xy: torch.Tensor, src_areas: torch.Tensor, src_J: torch.Tensor, z0: float,
+                eval_xyz: torch.Tensor, prefactor: float, vector: bool) -> torch.Tensor:
+    """Field of a film's sheet current at arbitrary points (``sources/current.py:13-110``);
+    all inputs float64 device tensors; returns ``[np]`` or ``[np, 3]``."""
+    lib = load_library()
+    np_, ns = eval_xyz.shape[0], src_xy.shape[0]
+    out = torch.empty((np_, 3) if vector else (np_,), dtype=torch.float64, device=eval_xyz.device)
+    nbytes = lib.ssa_sheet_field_workspace_bytes(np_, int(vector))
+    ws = _ws(nbytes, eval_xyz.device)
+    check(lib.ssa_sheet_field(ptr(src_xy), ptr(src_areas), ptr(src_J), ns, float(z0), ptr(eval_xyz), np_,
+                              float(prefactor), int(vector), ptr(out), ptr(ws), nbytes, current_stream()),
+          "ssa_sheet_field")
+    return out
+
+
 def mfma_probe(iters: int = 2000) -> float:
     """Sustained FP64 MFMA rate of this GPU in TFLOP/s (register-only instruction stream)."""
     lib = load_library()

@@ -20,6 +20,13 @@ from .units import MU_0, Quantity, convert_field, parse_units
 from .version import __version__
 
 
+def _sum_quantities(values):
+    total = values[0]
+    for v in values[1:]:
+        total = total + v
+    return total
+
+
 class Fluxoid(NamedTuple):
     """Flux part and supercurrent part of the fluxoid of a closed region (``solution.py:39-59``)."""
 
@@ -142,6 +149,122 @@ class Solution:
         J[~np.isfinite(J).all(axis=1)] = 0
         q = Quantity(J, default_units).to(units)
         return q if with_units else q.magnitude
+
+    def interp_field(self, positions: np.ndarray, *, film: str, dataset: str = "field", method: str = "linear",
+                     units: Optional[str] = None, with_units: bool = False):
+        """Interpolates the z component of a field inside a film (``solution.py:364-428``)."""
+        import matplotlib.tri as mtri
+
+        valid = ("field", "self_field", "applied_field", "field_from_other_films")
+        if dataset not in valid:
+            raise ValueError(f"Invalid dataset: {dataset!r}. Expected one of {valid!r}")
+        if units is None:
+            units = self.field_units
+        mesh = self.device.meshes[film]
+        fs = self.film_solutions[film]
+        if dataset == "field":
+            field = fs.total_field
+        elif dataset == "self_field":
+            field = fs.self_field
+        elif dataset == "applied_field":
+            field = fs.applied_field
+        else:
+            field = fs.field_from_other_films
+            if field is None:
+                field = np.zeros(len(mesh.sites))
+        interp = {"linear": mtri.LinearTriInterpolator, "cubic": mtri.CubicTriInterpolator}[method]
+        positions = np.atleast_2d(positions)
+        Hz = interp(mesh.triangulation, field)(positions[:, 0], positions[:, 1]).data
+        return convert_field(Hz, units, old_units=self.field_units, with_units=with_units)
+
+    @staticmethod
+    def _split_positions(positions, zs, dtype):
+        """``(m, 2)`` + ``zs`` or ``(m, 3)`` -> ``(m, 2)``, ``(m,)`` (``solution.py:657-673``)."""
+        positions = np.atleast_2d(positions)
+        if positions.shape[1] == 3:
+            if zs is not None:
+                raise ValueError("If positions has shape (m, 3) then zs cannot be specified.")
+            zs = positions[:, 2]
+            positions = positions[:, :2]
+        else:
+            zs = np.squeeze(zs)
+            if zs.ndim == 0:
+                zs = zs.item() * np.ones(positions.shape[0], dtype=dtype)
+        if not isinstance(zs, np.ndarray):
+            raise ValueError(f"Expected zs to be an ndarray, but got {type(zs)}.")
+        return positions, zs
+
+    def screening_field_at_position(self, positions: np.ndarray, *, zs=None, vector: bool = False,
+                                    interp_method: str = "linear", units: Optional[str] = None,
+                                    with_units: bool = True, return_sum: bool = True):
+        """Field of the currents in the device anywhere in space, without the applied field
+        (``solution.py:611-723``): inside a film's plane the solved ``self_field`` is interpolated,
+        everywhere else the film's sheet current is summed with Biot-Savart (GPU, ``ssa_sheet_field``)."""
+        from .sources import biot_savart_2d
+
+        device = self.device
+        dtype = device.solve_dtype
+        units = units or self.field_units
+        positions, zs = self._split_positions(positions, zs, dtype)
+        fields = {}
+        for name, film in device.films.items():
+            layer = device.layers[film.layer]
+            field_from_film = np.zeros((len(positions), 3) if vector else len(positions), dtype=dtype)
+            in_film = np.zeros(len(positions), dtype=bool)
+            if np.all(zs == layer.z0):
+                in_film[film.contains_points(positions)] = True
+                field_in_film = self.interp_field(positions[in_film], film=film.name, dataset="self_field",
+                                                  method=interp_method, units="tesla", with_units=False)
+                field_in_film = np.atleast_1d(field_in_film)
+                if vector:
+                    zeros = np.zeros_like(field_in_film)
+                    field_in_film = np.array([zeros, zeros, field_in_film]).T
+                field_from_film[in_film] = field_in_film
+            out = ~in_film
+            if out.any():
+                field_from_film[out] = biot_savart_2d(
+                    positions[out, 0], positions[out, 1], zs[out], positions=device.meshes[name].sites,
+                    areas=device.meshes[name].vertex_areas,
+                    current_densities=self.film_solutions[name].current_density, z0=layer.z0,
+                    length_units=device.length_units, current_units=self.current_units, vector=vector)
+            fields[name] = convert_field(field_from_film, units, old_units="tesla", with_units=with_units)
+        if return_sum:
+            return sum(fields.values()) if not with_units else _sum_quantities(list(fields.values()))
+        return fields
+
+    def field_at_position(self, positions: np.ndarray, *, zs=None, interp_method: str = "linear",
+                          units: Optional[str] = None, with_units: bool = True, return_sum: bool = True):
+        """Total z field (applied + screening) anywhere in space (``solution.py:725-831``)."""
+        device = self.device
+        dtype = device.solve_dtype
+        units = units or self.field_units
+        positions, zs = self._split_positions(positions, zs, dtype)
+        fields = self.screening_field_at_position(positions, zs=zs, vector=False, interp_method=interp_method,
+                                                  units=self.field_units, with_units=False, return_sum=False)
+        films_by_layer = device.polygons_by_layer("film")
+        Hz_applied = np.zeros(len(positions), dtype=dtype)
+        in_film = np.zeros(len(positions), dtype=bool)
+        for name, layer in device.layers.items():
+            if np.all(zs == layer.z0):
+                for film in films_by_layer[name]:
+                    ix = film.contains_points(positions)
+                    in_film[ix] = True
+                    Hz_applied[ix] = self.interp_field(positions[ix], film=film.name, dataset="applied_field",
+                                                       method=interp_method, units=self.field_units)
+                    Hz_applied[ix] += self.interp_field(positions[ix], film=film.name,
+                                                        dataset="field_from_other_films", method=interp_method,
+                                                        units=self.field_units)
+                break
+        mask = ~in_film
+        if mask.any():
+            Hz_applied[mask] = np.squeeze(self.applied_field_func(positions[mask, 0], positions[mask, 1],
+                                                                  zs[mask, np.newaxis]))
+        fields["applied_field"] = np.atleast_1d(Hz_applied).squeeze()
+        for key, value in fields.items():
+            fields[key] = convert_field(value, units, old_units=self.field_units, with_units=with_units)
+        if return_sum:
+            return sum(fields.values()) if not with_units else _sum_quantities(list(fields.values()))
+        return fields
 
     def polygon_fluxoid(self, polygon_coords, *, film: str, interp_method: str = "linear",
                         units: Optional[str] = "Phi_0", with_units: bool = True) -> Fluxoid:

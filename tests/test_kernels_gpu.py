@@ -380,3 +380,32 @@ def test_cholesky_full_size_residual(K):
     # linearity of the solve
     x2 = K.chol_solve(f, (2.5 * b).clone())
     assert (x2 - 2.5 * x).abs().max().item() <= 1e-13 * x.abs().max().item()
+
+
+def test_sheet_field_golden(K, golden):
+    """ssa_sheet_field against the reference's _biot_savart_2d_z / _biot_savart_2d_vector."""
+    from scipy.constants import mu_0 as MU_0  # sources/current.py:5
+
+    d = golden("sheet_field.npz")
+    pref = MU_0 / (4 * np.pi) * 1.0  # uA/um == A/m
+    args = (dev(d["sites"]), dev(d["areas"]), dev(d["J"]), float(d["z0"]), dev(d["eval_xyz"]), pref)
+    assert relerr(K.sheet_field(*args, True).cpu().numpy(), d["B_tesla"]) < 1e-12
+    assert relerr(K.sheet_field(*args, False).cpu().numpy(), d["Bz_tesla"]) < 1e-12
+
+
+def test_sheet_field_ragged_and_large(K):
+    """Ragged sizes (1 point, 257 points, source counts off the 256 tile) and an image-sized case
+    against the vectorised oracle; linearity in J."""
+    rng = np.random.default_rng(11)
+    for ns, npts in ((1, 1), (255, 257), (1000, 3), (2049, 1025)):
+        src = rng.uniform(-5, 5, (ns, 2))
+        J = rng.standard_normal((ns, 2))
+        a = rng.uniform(0.5, 1.5, ns)
+        ev = np.column_stack([rng.uniform(-6, 6, npts), rng.uniform(-6, 6, npts), rng.uniform(0.3, 2.0, npts)])
+        ref = orc.biot_savart_2d(ev[:, 0], ev[:, 1], ev[:, 2], positions=src, current_densities=J, z0=-0.1,
+                                 areas=a, vector=True)
+        from scipy.constants import mu_0 as MU_0
+        got = K.sheet_field(dev(src), dev(a), dev(J), -0.1, dev(ev), MU_0 / (4 * np.pi), True).cpu().numpy()
+        assert relerr(got, ref) < 1e-12
+        got2 = K.sheet_field(dev(src), dev(a), dev(2.0 * J), -0.1, dev(ev), MU_0 / (4 * np.pi), True).cpu().numpy()
+        assert relerr(got2, 2.0 * got) < 1e-15

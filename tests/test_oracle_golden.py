@@ -146,3 +146,14 @@ def test_mutual_inductance_raw_parts(golden):
                                                       contains(poly, film.mesh.sites), contains(film_poly, poly))
                 assert abs(flux - d["flux_part_raw"][it, i, j]) <= 1e-10 * abs(d["flux_part_raw"][:, :, j]).max()
                 assert abs(int_J - d["int_J_raw"][it, i, j]) <= 1e-10 * abs(d["int_J_raw"][:, :, j]).max()
+
+
+def test_sheet_field(golden):
+    """sources/current.py:13-110 (numba kernels of biot_savart_2d) recorded from the reference."""
+    d = golden("sheet_field.npz")
+    ev = d["eval_xyz"]
+    kw = dict(positions=d["sites"], current_densities=d["J"], z0=float(d["z0"]), areas=d["areas"])
+    B = orc.biot_savart_2d(ev[:, 0], ev[:, 1], ev[:, 2], vector=True, **kw)
+    Bz = orc.biot_savart_2d(ev[:, 0], ev[:, 1], ev[:, 2], vector=False, **kw)
+    assert relerr(B, d["B_tesla"]) < RTOL
+    assert relerr(Bz, d["Bz_tesla"]) < RTOL
