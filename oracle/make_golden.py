@@ -73,10 +73,16 @@ def contains(poly_points, pts):
 
 
 def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ, dtype):
-    """Index logic of ``make_film_info`` (solver/utils.py:261-304) for a constant Lambda."""
+    """Index logic of ``make_film_info`` (solver/utils.py:261-304); ``Lambda_value``: a constant or
+    the per-site array (then the dense gradient is attached as :293-297 does)."""
     dtype = np.dtype(dtype)
     n = len(mesh.sites)
     Lambda = (Lambda_value * np.ones(n)).astype(dtype)[:, np.newaxis]
+    lam_info = LambdaInfo(film=name, Lambda=Lambda)
+    grad = None
+    if lam_info.inhomogeneous:
+        grad = np.array([mesh.operators.gradient_x.toarray().astype(dtype, copy=False),
+                         mesh.operators.gradient_y.toarray().astype(dtype, copy=False)])
     hole_indices = {h: np.where(contains(p, mesh.sites))[0] for h, p in hole_polys.items()}
     in_hole = np.zeros(n, dtype=bool)
     if hole_indices:
@@ -85,7 +91,7 @@ def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ,
     return FilmInfo(
         name=name,
         layer=layer,
-        lambda_info=LambdaInfo(film=name, Lambda=Lambda),
+        lambda_info=lam_info,
         vortices=[],
         interior_indices=interior,
         boundary_indices=mesh.boundary_indices,
@@ -95,7 +101,7 @@ def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ,
         weights=mesh.operators.weights.astype(dtype, copy=False),
         kernel=mesh.operators.Q.astype(dtype, copy=False),
         laplacian=mesh.operators.laplacian.toarray().astype(dtype, copy=False),
-        gradient=None,
+        gradient=grad,
         terminal_currents=None,
     )
 
@@ -274,6 +280,62 @@ def biot_savart_fixture(fname):
     print("wrote", fname)
 
 
+def vortex_fixture(K, washer, fname):
+    """``solve_film`` with trapped vortices (solver/solve_film.py:541-554)."""
+    from superscreen.solution import Vortex  # the reference's dataclass
+
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = Mesh.from_triangulation(sites, elements)
+    film_poly, holes = polygons_for(K, dr, washer)
+    n = len(sites)
+    device_like = SimpleNamespace(terminals={}, meshes={"film": mesh})
+    vortices = [Vortex(x=3.1, y=-0.7, film="film", nPhi0=1), Vortex(x=-2.4, y=2.2, film="film", nPhi0=-2)]
+    out = dict(K=K, washer=washer, vortex_xy=np.array([[v.x, v.y] for v in vortices]),
+               vortex_nPhi0=np.array([v.nPhi0 for v in vortices], float), field_conversion=FIELD_CONV,
+               vortex_flux=VORTEX_FLUX)
+    for tag, field_mT, circ in (("a", 0.0, 0.0), ("b", 0.7, 1.5)):
+        info = make_film_info("film", "layer", mesh, film_poly, holes, 0.25, {"hole": circ}, "float64")
+        info.vortices = tuple(vortices)
+        film_systems, hole_systems, _ = factorize_linear_systems(device_like, {"film": info})
+        sol = solve_film(device=device_like, applied_field=(field_mT * FIELD_CONV) * np.ones(n), film_info=info,
+                         film_system=film_systems["film"], hole_systems=hole_systems["film"],
+                         field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX)
+        out[f"field_mT_{tag}"], out[f"circ_{tag}"] = field_mT, circ
+        out[f"g_{tag}"], out[f"J_{tag}"], out[f"self_field_{tag}"] = sol.stream, sol.current_density, sol.self_field
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "n =", n)
+
+
+def lambda_xy(x, y):
+    """The Lambda(x, y) of the inhomogeneous fixture (um)."""
+    return 0.2 * (1.0 + 0.5 * x / 5.0 + 0.3 * (y / 5.0) ** 2)
+
+
+def inhomogeneous_fixture(K, washer, fname):
+    """A film with Lambda(x, y): the grad(Lambda) term of solver/solve_film.py:181-185."""
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = Mesh.from_triangulation(sites, elements)
+    film_poly, holes = polygons_for(K, dr, washer)
+    n = len(sites)
+    device_like = SimpleNamespace(terminals={}, meshes={"film": mesh})
+    Lam = lambda_xy(sites[:, 0], sites[:, 1])
+    info = make_film_info("film", "layer", mesh, film_poly, holes, Lam, {"hole": 0.8}, "float64")
+    assert info.lambda_info.inhomogeneous
+    film_systems, hole_systems, _ = factorize_linear_systems(device_like, {"film": info})
+    fs = film_systems["film"]
+    sol = solve_film(device=device_like, applied_field=(0.9 * FIELD_CONV) * np.ones(n), film_info=info,
+                     film_system=fs, hole_systems=hole_systems["film"], field_conversion=FIELD_CONV,
+                     vortex_flux=VORTEX_FLUX)
+    rows = sample_rows(len(fs.indices))
+    out = dict(K=K, washer=washer, Lambda=Lam, field_mT=0.9, circ=0.8, field_conversion=FIELD_CONV,
+               A_rows_idx=rows, A_rows=fs.A[rows].copy(), A_diag=np.diag(fs.A).copy(),
+               g=sol.stream, J=sol.current_density, self_field=sol.self_field)
+    if washer:
+        out["A_hole_rows"] = hole_systems["film"]["hole"].A[sample_rows(n)].copy()
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "n =", n)
+
+
 def sheet_field_fixture(fname):
     """The numba kernels behind ``biot_savart_2d`` (sources/current.py:13-110), driven exactly as
     the wrapper does (:166-198): everything converted to metres and A/m first."""
@@ -382,6 +444,13 @@ if __name__ == "__main__":
     if "--only-mutual" in sys.argv:
         mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
         sys.exit(0)
+    if "--only-vortex" in sys.argv:
+        vortex_fixture(13, False, "vortex_disk_K13.npz")
+        vortex_fixture(13, True, "vortex_washer_K13.npz")
+        sys.exit(0)
+    if "--only-inhomogeneous" in sys.argv:
+        inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")
+        sys.exit(0)
     if "--only-sheet-field" in sys.argv:
         sheet_field_fixture("sheet_field.npz")
         sys.exit(0)
@@ -394,3 +463,6 @@ if __name__ == "__main__":
     biot_savart_fixture("biot_savart.npz")
     mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
     sheet_field_fixture("sheet_field.npz")
+    vortex_fixture(13, False, "vortex_disk_K13.npz")
+    vortex_fixture(13, True, "vortex_washer_K13.npz")
+    inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")

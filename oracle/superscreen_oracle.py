@@ -323,9 +323,23 @@ def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.nda
     film = OracleFilm(name=name, mesh=mesh, z0=float(z0), Lambda=Lambda,
                       film_indices=interior, hole_indices=hole_indices, dtype=dtype,
                       weights=weights, Q=Q)
+    # inhomogeneous Lambda: LambdaInfo's criterion (solver/utils.py:46-49) and the extra term
+    # grad_Lambda_term = einsum("ijk, ijk -> jk", grad @ Lambda, grad)   (solve_film.py:181-185)
+    inhomogeneous = np.ptp(Lambda) / max(np.min(np.abs(Lambda)), np.finfo(float).eps) > 1e-6
+    term = None
+    if inhomogeneous:
+        gx = mesh.gradient_x.toarray().astype(dtype, copy=False)
+        gy = mesh.gradient_y.toarray().astype(dtype, copy=False)
+        term = (gx @ Lambda)[:, None] * gx + (gy @ Lambda)[:, None] * gy
     for h, ix in hole_indices.items():
-        film.A_holes[h] = build_system_1d(Q, weights, Lambda, lap, ix).astype(dtype, copy=False)
-    film.A = build_system_2d(Q, weights, Lambda, lap, interior).astype(dtype, copy=False)
+        A_h = build_system_1d(Q, weights, Lambda, lap, ix)
+        if term is not None:
+            A_h = A_h - term[:, ix]  # :289-293
+        film.A_holes[h] = A_h.astype(dtype, copy=False)
+    A = build_system_2d(Q, weights, Lambda, lap, interior)
+    if term is not None:
+        A = A - term[np.ix_(interior, interior)]  # :300-305
+    film.A = A.astype(dtype, copy=False)
     if factorize:
         film.lu_piv = la.lu_factor(-film.A)
     return film
@@ -351,8 +365,11 @@ class OracleFilmSolution:
 
 def solve_film(film: OracleFilm, applied_field: np.ndarray, *, field_conversion: float,
                circulating_currents: Optional[Dict[str, float]] = None,
-               field_from_other_films: Optional[np.ndarray] = None) -> OracleFilmSolution:
-    """solver/solve_film.py:440-574, main branch (no terminals, no vortices)."""
+               field_from_other_films: Optional[np.ndarray] = None,
+               vortices: Sequence[Tuple[float, float, float]] = (),
+               vortex_flux: Optional[float] = None) -> OracleFilmSolution:
+    """solver/solve_film.py:440-574 without terminals.  ``vortices``: ``(x, y, nPhi0)`` triples
+    located in this film (:541-554)."""
     circulating_currents = circulating_currents or {}
     Hz = applied_field
     if field_from_other_films is not None:
@@ -366,6 +383,15 @@ def solve_film(film: OracleFilm, applied_field: np.ndarray, *, field_conversion:
     h = Hz[ix] - Ha_eff[ix]
     gf = la.lu_solve(film.lu_piv, h)  # :530  => g = -A^-1 h
     g[ix] += gf
+    K = None
+    for (vx, vy, nPhi0) in vortices:  # :541-554
+        if K is None:
+            K = -la.lu_solve(film.lu_piv, np.eye(film.A.shape[0]))  # = inv(A)
+        pts = film.mesh.sites
+        j_film = np.argmin(la.norm(pts[ix] - (vx, vy), axis=1))
+        j_device = np.argmin(la.norm(pts - (vx, vy), axis=1))
+        vf = vortex_flux_uA_um() if vortex_flux is None else vortex_flux
+        g[ix] += vf * nPhi0 * K[:, j_film] / film.weights[j_device]  # Eq. 28 in [Brandt]
     J = np.array([film.mesh.gradient_y @ g, -(film.mesh.gradient_x @ g)]).T  # :556
     screening = film.Q @ (film.weights * g)  # :565
     other = None

@@ -37,8 +37,8 @@ class Fluxoid(NamedTuple):
 @dataclass
 class Vortex:
     """A vortex pinned at ``(x, y)`` in ``film`` carrying ``nPhi0`` flux quanta
-    (``solution.py:62-92``).  Accepted by the API; the vortex branch of ``solve_film`` is not
-    on the BASELINE path yet."""
+    (``solution.py:62-92``); handled by the vortex branch of ``solve_film``
+    (``solver/solve_film.py:541-554``) as one extra right-hand side per vortex."""
 
     x: float
     y: float

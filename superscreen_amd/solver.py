@@ -19,8 +19,10 @@ Memory (per film, n vertices, n_i unknowns, s = sizeof(solve dtype)): LU n_i^2 s
 n = 50k in f64), hole systems n * k_h * s, optional stored Q n^2 s; the reference additionally
 keeps A, a float64 Q and a DENSE Laplacian (solver/utils.py:290-292), about 5 n^2 words.
 
-Not implemented (raise NotImplementedError): terminal currents,
-vortices, the grad(Lambda) term of inhomogeneous films, HDF5 persistence.
+Not implemented (raise NotImplementedError): terminal currents, HDF5
+persistence.  Vortices (solve_film.py:541-554) are one extra right-hand side per vortex through the
+existing factorization; a film with Lambda(x, y) (grad(Lambda) term, :181-185) goes through the LU
+route because diag(w) A is then no longer symmetric.
 """
 from __future__ import annotations
 
@@ -263,15 +265,29 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     film_systems, hole_systems, film_data = {}, {}, {}
     pending = []
     for name, info in film_info_dict.items():
-        if info.lambda_info.inhomogeneous:
-            raise NotImplementedError(
-                "Inhomogeneous Lambda (grad(Lambda) term, solve_film.py:181-185) is not on the "
-                "accelerated path yet."
-            )
         mesh = device.meshes[name]
         fd = FilmDeviceData(info, mesh, dtype, store_Q)
         film_data[name] = fd
         dev = fd.device
+        inhomogeneous = info.lambda_info.inhomogeneous
+        grad_Lambda_term = 0.0
+        if inhomogeneous:
+            # A = Q w - Lambda[cols] Del2 - grad_Lambda_term with (solve_film.py:181-185)
+            #   grad_Lambda_term[j, k] = sum_d (grad_d @ Lambda)[j] grad_d[j, k]   (sparse, like grad).
+            # Both sparse pieces go to the assembly kernel as ONE CSR in the Laplacian's slot, with
+            # a unit Lambda:  A = Q w - 1 * (Del2 scaled per column + grad_Lambda_term).
+            import scipy.sparse as sp
+
+            ops = mesh.operators
+            Lam = info.lambda_info.Lambda[:, 0].astype(np.float64)
+            gx, gy = ops.gradient_x.tocsr(), ops.gradient_y.tocsr()
+            grad_Lambda_term = (sp.diags(gx @ Lam) @ gx + sp.diags(gy @ Lam) @ gy).tocsr()
+            corr = (ops.laplacian.tocsr().multiply(Lam[np.newaxis, :]) + grad_Lambda_term).tocsr()
+            corr.sort_indices()
+            fd.lap = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                           for a in (corr.indptr.astype(np.int64), corr.indices.astype(np.int64),
+                                     corr.data.astype(np.float64)))
+            fd.Lambda = torch.ones(fd.n, dtype=torch.float64, device=dev)
 
         def assemble(rows, cols, sign, fd=fd):
             return kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, rows, cols,
@@ -282,7 +298,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             ix_d = torch.from_numpy(indices.astype(np.int64)).to(dev)
             A_h = assemble(None, ix_d, 1.0)  # [n, ld]
             hole_systems[name][hole_name] = LinearSystem(
-                indices=indices, A_device=A_h, indices_device=ix_d,
+                indices=indices, A_device=A_h, indices_device=ix_d, grad_Lambda_term=grad_Lambda_term,
                 _assemble=lambda A_h=A_h, k=len(indices): A_h[:, :k].cpu().numpy(),
             )
         interior = info.interior_indices
@@ -300,25 +316,28 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
 
         host_A = lambda ix_d=ix_d, ni=ni, assemble=assemble: assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy()  # noqa: E731
         S = None
-        if method in ("auto", "cholesky"):
+        if inhomogeneous and method == "cholesky":
+            raise ValueError(f"Film {name!r}: Lambda(x, y) makes diag(w) A non-symmetric; use method='auto' or 'lu'.")
+        if method in ("auto", "cholesky") and not inhomogeneous:
             # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
             # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
             npad = kernels.chol_padded_n(ni)
             S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
                                         dtype=dtype, row_scale=fd.w, lower_only=True,
                                         ld=kernels.padded_ld(npad, dtype), alloc_rows=npad)
-        pending.append((name, interior, ix_d, ni, S, lu_route, host_A, fd))
+        pending.append((name, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term))
     # All films are factored in one interleaved schedule (ssa_chol_factor_batch): the MFMA
     # trailing updates of the films alternate on the stream, each film's panel chain hides behind
     # the other films' updates.
     with_S = [p for p in pending if p[4] is not None]
     chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S])))
-    for name, interior, ix_d, ni, S, lu_route, host_A, fd in pending:
+    for name, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term in pending:
         system = None
         chol = chols.get(name)
         if chol is not None:
             if chol.info == 0:
                 system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,
+                                      grad_Lambda_term=grad_Lambda_term,
                                       neg_w_device=(-fd.w_t[ix_d]).contiguous(),
                                       _lu_factorize=lu_route, _assemble=host_A)
             else:
@@ -330,6 +349,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
         if system is None:
             factors = lu_route()
             system = LinearSystem(indices=interior, factors=factors, indices_device=ix_d,
+                                  grad_Lambda_term=grad_Lambda_term,
                                   rhs_indices_device=ix_d[factors.perm].contiguous(), _assemble=host_A)
         film_systems[name] = system
     return film_systems, hole_systems, {}, film_data
@@ -364,9 +384,39 @@ class FactorizedModel:
             info.circulating_currents = {h: c for h, c in currents.items() if h in info.hole_indices}
 
     def set_vortices(self, vortices: Sequence[Vortex]) -> None:
-        if vortices:
-            raise NotImplementedError("Vortices are not on the accelerated path yet.")
-        self.vortices = []
+        """``solver/solve.py:204-217`` (the model's ``vortices`` becomes ``{film: tuple}`` there too)."""
+        for info in self.film_info.values():
+            info.vortices = []
+        for vortex in vortices:
+            self.film_info[vortex.film].vortices.append(vortex)
+        self.vortices = {}
+        for name, info in self.film_info.items():
+            info.vortices = tuple(info.vortices)
+            self.vortices[name] = info.vortices
+
+    def vortex_column(self, film: str, j_film: int):
+        """Column ``j_film`` of ``K = inv(A)`` of a film (``solve_film.py:541-544`` builds the whole
+        inverse; one extra right-hand side through the existing factorization is enough), cached."""
+        import torch
+
+        from . import kernels
+
+        cache = self.__dict__.setdefault("_vortex_columns", {})
+        key = (film, int(j_film))
+        if key not in cache:
+            system = self.film_systems[film]
+            fd = self.film_data[film]
+            ni = len(system.indices)
+            e = torch.zeros(ni, dtype=fd.tdtype, device=fd.device)
+            if system.chol is not None:
+                # A = diag(1/w) S  ->  inv(A) e_j = w_j inv(S) e_j ;  neg_w holds -w[ix]
+                e[j_film] = -system.neg_w_device[j_film]
+                cache[key] = kernels.chol_solve(system.chol, e)
+            else:
+                # lu_piv factors -A:  inv(A) e_j = -lu_solve(lu_piv, e_j)
+                e[j_film] = 1.0
+                cache[key] = -kernels.lu_solve(system.factors, e)
+        return cache[key]
 
     def copy(self) -> "FactorizedModel":
         """Shallow copy (``solver/solve.py:219-220``)."""
@@ -403,8 +453,6 @@ def factorize_model(*, device: Device, current_units: str,
     film_info = make_film_info(device=device, vortices=vortices,
                                circulating_currents=circulating_currents,
                                terminal_currents=terminal_currents)
-    if vortices:
-        raise NotImplementedError("Vortices are not on the accelerated path yet.")
     film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
         device, film_info, store_Q=(self_field == "dense"), method=method)
     return FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
@@ -423,7 +471,7 @@ class _DeviceFilmResult:
 
 
 def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
-                       check_inversion: bool) -> _DeviceFilmResult:
+                       check_inversion: bool, vortex_flux_value: float = 0.0) -> _DeviceFilmResult:
     """Device part of ``solve_film`` (``solver/solve_film.py:486-565``)."""
     import torch
 
@@ -454,6 +502,17 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
             err = (hsim - h_nat).abs().max().item()
             logger.warning(f"Unable to solve for stream function in {name!r}), maximum error {err:.3e}.")
     kernels.scatter_add(g, system.indices_device, gf)
+    if info.vortices:  # solve_film.py:541-554, Eq. 28 in [Brandt]
+        mesh = model.device.meshes[name]
+        points = mesh.sites
+        weights = mesh.operators.weights
+        for vortex in info.vortices:
+            xy = (vortex.x, vortex.y)
+            j_film = int(np.argmin(np.linalg.norm(points[system.indices] - xy, axis=1)))
+            j_device = int(np.argmin(np.linalg.norm(points - xy, axis=1)))
+            scale = vortex_flux_value * vortex.nPhi0 / float(weights[j_device])
+            g_vortex = kernels.scale(model.vortex_column(name, j_film), scale)
+            kernels.scatter_add(g, system.indices_device, g_vortex)
     J = kernels.current_density(*fd.grad, g)
     if model.self_field_mode == "dense":
         sf = kernels.gemv(fd.Q, fd.n, fd.n, g, xscale=fd.w_t)
@@ -572,7 +631,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
             raise ValueError(f"Expected applied_field to return a 1D vector, got a {Hz.shape[1]}D vector.")
         applied_h[film] = Hz
         applied_d[film] = torch.from_numpy(np.ascontiguousarray(Hz)).to(model.film_data[film].device)
-    _ = vortex_flux(current_units, device.length_units)  # solve.py:441-442 (vortex branch unused)
+    vflux = vortex_flux(current_units, device.length_units)  # solve.py:441-442
 
     solution_kwargs = dict(applied_field_func=applied_field, field_units=field_units,
                            current_units=current_units,
@@ -587,7 +646,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
         for name in films:
             results[name] = _solve_film_device(model, name, applied_d[name],
                                                None if other_d is None else other_d[name],
-                                               check_inversion)
+                                               check_inversion, vflux)
         return results
 
     def package(staged: _StagedPass):

@@ -157,3 +157,56 @@ def test_sheet_field(golden):
     Bz = orc.biot_savart_2d(ev[:, 0], ev[:, 1], ev[:, 2], vector=False, **kw)
     assert relerr(B, d["B_tesla"]) < RTOL
     assert relerr(Bz, d["Bz_tesla"]) < RTOL
+
+
+@pytest.mark.parametrize("name", ["vortex_disk_K13.npz", "vortex_washer_K13.npz"])
+def test_vortices(golden, name):
+    """solve_film with trapped vortices (solver/solve_film.py:541-554) recorded from the reference."""
+    import importlib.util, os
+    d = golden(name)
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_syn", os.path.join(here, "superscreen_amd", "synthetic.py"))
+    syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(syn)
+    K = int(d["K"])
+    sites, elements, dr = syn.ring_disk_mesh(K)
+    mesh = orc.make_mesh(sites, elements)
+    Kf = syn.film_rings(K)
+    film_poly = syn.circle_points((Kf + 0.5) * dr)
+    holes = {"hole": contains(syn.circle_points((Kf // 3 + 0.5) * dr, 201), sites)} if bool(d["washer"]) else {}
+    film = orc.make_film("film", mesh, z0=0.0, Lambda=0.25, in_film=contains(film_poly, sites), holes_mask=holes)
+    vortices = [(x, y, n) for (x, y), n in zip(d["vortex_xy"], d["vortex_nPhi0"])]
+    conv = float(d["field_conversion"])
+    for tag in ("a", "b"):
+        sol = orc.solve_film(film, float(d[f"field_mT_{tag}"]) * conv * np.ones(len(sites)), field_conversion=conv,
+                             circulating_currents={"hole": float(d[f"circ_{tag}"])}, vortices=vortices,
+                             vortex_flux=float(d["vortex_flux"]))
+        assert relerr(sol.stream, d[f"g_{tag}"]) < RTOL
+        assert relerr(sol.current_density, d[f"J_{tag}"]) < RTOL
+        assert relerr(sol.self_field, d[f"self_field_{tag}"]) < RTOL
+
+
+def test_inhomogeneous_lambda(golden):
+    """Lambda(x, y): grad(Lambda) term of solver/solve_film.py:181-185, recorded from the reference."""
+    import importlib.util, os
+    d = golden("inhomogeneous_washer_K11.npz")
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_syn", os.path.join(here, "superscreen_amd", "synthetic.py"))
+    syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(syn)
+    K = int(d["K"])
+    sites, elements, dr = syn.ring_disk_mesh(K)
+    mesh = orc.make_mesh(sites, elements)
+    Kf = syn.film_rings(K)
+    film_poly = syn.circle_points((Kf + 0.5) * dr)
+    holes = {"hole": contains(syn.circle_points((Kf // 3 + 0.5) * dr, 201), sites)}
+    film = orc.make_film("film", mesh, z0=0.0, Lambda=d["Lambda"], in_film=contains(film_poly, sites),
+                         holes_mask=holes)
+    assert relerr(film.A[d["A_rows_idx"]], d["A_rows"]) < RTOL
+    assert relerr(np.diag(film.A), d["A_diag"]) < RTOL
+    conv = float(d["field_conversion"])
+    sol = orc.solve_film(film, float(d["field_mT"]) * conv * np.ones(len(sites)), field_conversion=conv,
+                         circulating_currents={"hole": float(d["circ"])})
+    assert relerr(sol.stream, d["g"]) < RTOL
+    assert relerr(sol.current_density, d["J"]) < RTOL
+    assert relerr(sol.self_field, d["self_field"]) < RTOL

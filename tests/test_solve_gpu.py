@@ -340,3 +340,67 @@ def test_field_at_position_and_sheet_sources(golden):
     assert relerr(B2[:, 2], B) < 1e-3   # Delaunay areas differ slightly from the mesh's at the rim
     assert B.shape == (5,) and B2.shape == (5, 3) and callable(f)
     assert MU_0 > 0
+
+
+@pytest.mark.parametrize("name", ["vortex_disk_K13.npz", "vortex_washer_K13.npz"])
+@pytest.mark.parametrize("method", ["auto", "lu"])
+def test_vortices_vs_reference(golden, name, method):
+    """Trapped vortices (solver/solve_film.py:541-554): one extra right-hand side per vortex instead
+    of the full inverse the reference forms; both factorization routes."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    d = golden(name)
+    device = synthetic.make_stack_device(int(d["K"]), ("washer" if bool(d["washer"]) else "disk",), Lambda=0.25)
+    film = list(device.films)[0]
+    vortices = [sc.Vortex(x=float(x), y=float(y), film=film, nPhi0=float(n))
+                for (x, y), n in zip(d["vortex_xy"], d["vortex_nPhi0"])]
+    for tag in ("a", "b"):
+        circ = {"hole0": float(d[f"circ_{tag}"])} if bool(d["washer"]) else None
+        model = sc.factorize_model(device=device, current_units="uA", circulating_currents=circ,
+                                   vortices=vortices, method=method)
+        sol = sc.solve(model=model, applied_field=sc.ConstantField(float(d[f"field_mT_{tag}"])),
+                       field_units="mT")[-1].film_solutions[film]
+        assert relerr(sol.stream, d[f"g_{tag}"]) < 1e-9
+        assert relerr(sol.current_density, d[f"J_{tag}"]) < 1e-9
+        assert relerr(sol.self_field, d[f"self_field_{tag}"]) < 1e-9
+    # set_vortices on an existing model: no re-factorization; removing them restores the Meissner answer
+    model.set_vortices([])
+    plain = sc.solve(model=model, applied_field=sc.ConstantField(0.7), field_units="mT")[-1].film_solutions[film]
+    model.set_vortices(vortices)
+    again = sc.solve(model=model, applied_field=sc.ConstantField(0.7), field_units="mT")[-1].film_solutions[film]
+    assert relerr(again.stream, d["g_b"]) < 1e-9
+    assert relerr(plain.stream, again.stream) > 1e-3
+    with pytest.raises(ValueError):
+        sc.factorize_model(device=device, current_units="uA", vortices=[sc.Vortex(x=40.0, y=0.0, film=film)])
+
+
+def test_inhomogeneous_lambda_vs_reference(golden):
+    """Layer.Lambda as a Parameter of (x, y): the grad(Lambda) term (solver/solve_film.py:181-185) is
+    folded into the sparse part of the assembly kernel; diag(w) A is no longer symmetric, so the
+    film goes through the LU route."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    d = golden("inhomogeneous_washer_K11.npz")
+
+    def lam(x, y):
+        return 0.2 * (1.0 + 0.5 * x / 5.0 + 0.3 * (y / 5.0) ** 2)
+
+    device = synthetic.make_stack_device(int(d["K"]), ("washer",))
+    device.layers["layer0"].Lambda = sc.Parameter(lam)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": float(d["circ"])})
+    system = model.film_systems["washer0"]
+    assert system.chol is None and system.factors is not None          # LU route
+    assert relerr(system.A[d["A_rows_idx"]], d["A_rows"]) < 1e-12
+    hs = model.hole_systems["washer0"]["hole0"]
+    n = len(device.meshes["washer0"].sites)
+    rows = np.unique(np.linspace(0, n - 1, 8).astype(np.int64))
+    assert relerr(hs.A[rows], d["A_hole_rows"]) < 1e-12
+    sol = sc.solve(model=model, applied_field=sc.ConstantField(float(d["field_mT"])),
+                   field_units="mT")[-1].film_solutions["washer0"]
+    assert relerr(sol.stream, d["g"]) < 1e-9
+    assert relerr(sol.current_density, d["J"]) < 1e-9
+    assert relerr(sol.self_field, d["self_field"]) < 1e-9
+    with pytest.raises(ValueError):
+        sc.factorize_model(device=device, current_units="uA", method="cholesky")
