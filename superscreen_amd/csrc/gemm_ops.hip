@@ -132,6 +132,91 @@ __device__ __forceinline__ void tile_full_f64(int64_t K, double alpha, const dou
                 Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
 }
 
+// ---- FULL path, f32, NT (both operands K-MAJOR) -----------------------------------------------
+// Byte for byte the f64 pipeline: a row segment of 32 floats is the same 128 bytes as 16 doubles,
+// so the operands are staged through the SAME LDS-DMA / swizzle code on 8-byte views of the
+// matrices (leading dimension and K counted in float pairs).  Every 8-byte LDS read then carries
+// two consecutive k of one row and feeds two v_mfma_f32_16x16x4_f32 (the k permutation this
+// implies is the same for A and B, so the product is unchanged).  Same time per byte as f64,
+// i.e. twice the rate per element.
+__device__ __forceinline__ void tile_full_f32_nt(int64_t K, float alpha, const float *__restrict__ A,
+                                                 int64_t lda, const float *__restrict__ B, int64_t ldb,
+                                                 float beta, float *__restrict__ C, int64_t ldc, int64_t m0,
+                                                 int64_t n0, char *smem_raw) {
+    using MF = Mfma<float>;
+    using acc_t = MF::acc_t;
+    OpSmemF64 &sm = *reinterpret_cast<OpSmemF64 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int swz = 2 * ((li >> 1) & 7);
+
+    OperandF64<true> opa, opb;
+    opa.init(reinterpret_cast<const double *>(A), lda / 2, m0, lane, wave);
+    opb.init(reinterpret_cast<const double *>(B), ldb / 2, n0, lane, wave);
+    opa.issue(0, sm.a[0], wave);
+    opb.issue(0, sm.b[0], wave);
+
+    acc_t acc[4][4];
+    float *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
+    if (beta != 0.0f) {
+        const float scale = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int64_t nk = (K / 2) / KC;  // stages of 16 float pairs
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = static_cast<int>(kt & 1);
+        if (kt + 1 < nk) {
+            opa.issue((kt + 1) * KC, sm.a[cur ^ 1], wave);
+            opb.issue((kt + 1) * KC, sm.b[cur ^ 1], wave);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            float2 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = OperandF64<true>::frag(sm.a[cur], wm, i, ks, li, lk, swz);
+                fa[i] = __builtin_bit_cast(float2, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double v = OperandF64<true>::frag(sm.b[cur], wn, j, ks, li, lk, swz);
+                fb[j] = __builtin_bit_cast(float2, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = MF::run(fa[i].x, fb[j].x, acc[i][j]);
+                    acc[i][j] = MF::run(fa[i].y, fb[j].y, acc[i][j]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+}
+
 // ---- EDGE path: any type, any shape, guarded element-wise staging --------------------------
 template <typename T>
 struct EdgeSmem {
@@ -270,11 +355,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
         tn = (wg % per_group) / gsize;
     }
     const int64_t m0 = tm * BM, n0 = tn * BN;
-    const bool full = aligned && sizeof(T) == 8 && (m0 + BM <= M) && (n0 + BN <= N) &&
-                      (K % KC == 0) && (K > 0) && alpha != T(0);
+    constexpr bool kHasFull = (sizeof(T) == 8) || (TA == OP_N && TB == OP_T);  // f32: NT only
+    constexpr int64_t kStageK = (sizeof(T) == 8) ? KC : 2 * KC;
+    const bool full = kHasFull && aligned && (m0 + BM <= M) && (n0 + BN <= N) && (K % kStageK == 0) &&
+                      (K > 0) && alpha != T(0);
     if (full) {
         if constexpr (sizeof(T) == 8)
             tile_full_f64<TA, TB>(K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
+        else if constexpr (TA == OP_N && TB == OP_T)
+            tile_full_f32_nt(K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
     } else {
         tile_edge<T, TA, TB>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
     }
