@@ -155,13 +155,25 @@ __global__ __launch_bounds__(kPairThreads) void self_field_partial_kernel(
         s_x[tid] = sx; s_y[tid] = sy; s_c[tid] = sc;
         __syncthreads();
         const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+        // only the source tile that overlaps this workgroup's own targets can contain j == i
+        const int64_t i_first = static_cast<int64_t>(blockIdx.x) * kPairThreads;
+        if (t0 < i_first + kPairThreads && t0 + cnt > i_first) {
 #pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-            const double dx = xi - s_x[k], dy = yi - s_y[k];
-            const double r2 = __builtin_fma(dx, dx, dy * dy);
-            const double y = rsqrt_f64(r2);
-            const double t = (t0 + k == i) ? 0.0 : (s_c[k] * y) * (y * y);
-            acc += t;
+            for (int k = 0; k < cnt; ++k) {
+                const double dx = xi - s_x[k], dy = yi - s_y[k];
+                const double r2 = __builtin_fma(dx, dx, dy * dy);
+                const double y = rsqrt_f64(r2);
+                const double t = (t0 + k == i) ? 0.0 : (s_c[k] * y) * (y * y);
+                acc += t;
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < cnt; ++k) {
+                const double dx = xi - s_x[k], dy = yi - s_y[k];
+                const double r2 = __builtin_fma(dx, dx, dy * dy);
+                const double y = rsqrt_f64(r2);
+                acc = __builtin_fma(s_c[k] * y, y * y, acc);
+            }
         }
     }
     if (i < n) partial[static_cast<int64_t>(blockIdx.y) * n + i] = acc;
