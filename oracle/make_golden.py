@@ -72,7 +72,8 @@ def contains(poly_points, pts):
     return Path(poly_points, closed=True).contains_points(np.atleast_2d(pts))
 
 
-def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ, dtype):
+def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ, dtype,
+                   boundary=None, terminal_currents=None):
     """Index logic of ``make_film_info`` (solver/utils.py:261-304); ``Lambda_value``: a constant or
     the per-site array (then the dense gradient is attached as :293-297 does)."""
     dtype = np.dtype(dtype)
@@ -87,14 +88,15 @@ def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ,
     in_hole = np.zeros(n, dtype=bool)
     if hole_indices:
         in_hole[np.concatenate(list(hole_indices.values()))] = True
-    interior = np.setdiff1d(np.where(contains(film_poly, mesh.sites))[0], mesh.boundary_indices)
+    boundary_indices = mesh.boundary_indices if boundary is None else boundary
+    interior = np.setdiff1d(np.where(contains(film_poly, mesh.sites))[0], boundary_indices)
     return FilmInfo(
         name=name,
         layer=layer,
         lambda_info=lam_info,
         vortices=[],
         interior_indices=interior,
-        boundary_indices=mesh.boundary_indices,
+        boundary_indices=boundary_indices,
         hole_indices=hole_indices,
         in_hole=in_hole,
         circulating_currents={h: c for h, c in circ.items() if h in hole_indices},
@@ -102,7 +104,7 @@ def make_film_info(name, layer, mesh, film_poly, hole_polys, Lambda_value, circ,
         kernel=mesh.operators.Q.astype(dtype, copy=False),
         laplacian=mesh.operators.laplacian.toarray().astype(dtype, copy=False),
         gradient=grad,
-        terminal_currents=None,
+        terminal_currents=terminal_currents,
     )
 
 
@@ -306,6 +308,70 @@ def vortex_fixture(K, washer, fname):
     print("wrote", fname, "n =", n)
 
 
+class TerminalStub:
+    """What the reference's terminal code needs from a terminal Polygon: ``name`` and
+    ``contains_points(points, index=...)`` (matplotlib Path, device/polygon.py:138-162)."""
+
+    def __init__(self, name, points):
+        self.name, self.points = name, points
+
+    def contains_points(self, pts, index=False, radius=0):
+        mask = contains(self.points, pts)
+        return np.where(mask)[0] if index else mask
+
+
+def terminal_fixture(nx, ny, hole_radius, fname):
+    """Transport currents (solver/solve_film.py:308-437, 505-524, 557-562): a strip with a source
+    and a drain terminal.  The ordered boundary (device/device.py:473-500 needs shapely) comes from
+    this repository's chaining of the boundary edges; everything downstream is the reference."""
+    from superscreen.solver.solve_film import solve_for_terminal_current_stream  # the reference
+
+    spec = importlib.util.spec_from_file_location("_fem", os.path.join(ROOT, "superscreen_amd", "fem.py"))
+    fem_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fem_mod)
+    spec = importlib.util.spec_from_file_location("_geo", os.path.join(ROOT, "superscreen_amd", "geometry.py"))
+    geo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(geo)
+
+    length, width, Lam = 10.0, 4.0, 0.3
+    sites, elements = synthetic.strip_mesh(nx, ny, length, width)
+    mesh = Mesh.from_triangulation(sites, elements)
+    n = len(sites)
+    eps = 1e-3 * min(length / nx, width / ny)
+    dx = length / nx
+    film_poly = geo.box(length + 2 * eps, width + 2 * eps, points=401)
+    terms = [TerminalStub("source", geo.box(dx, width + 4 * eps, points=41, center=(-length / 2, 0.0))),
+             TerminalStub("drain", geo.box(dx, width + 4 * eps, points=41, center=(length / 2, 0.0)))]
+    holes = {"hole": synthetic.circle_points(hole_radius, 101)} if hole_radius > 0 else {}
+    # Device.boundary_vertices (device/device.py:486-500) on the chained boundary loop
+    indices = fem_mod.boundary_vertices(sites, elements)
+    for t in terms:
+        t_ix = t.contains_points(sites[indices], index=True)
+        discont = np.diff(t_ix) != 1
+        if np.any(discont):
+            indices = np.roll(indices, -(np.where(discont)[0][0] + 1))
+            break
+    device_like = SimpleNamespace(terminals={"film": terms}, meshes={"film": mesh})
+    out = dict(nx=nx, ny=ny, hole_radius=hole_radius, Lambda=Lam, boundary_indices=indices,
+               field_conversion=FIELD_CONV)
+    for tag, current, field_mT, circ in (("a", 5.0, 0.0, 0.0), ("b", -2.5, 0.4, 1.2)):
+        tc = {"source": current, "drain": -current}
+        info = make_film_info("film", "layer", mesh, film_poly, holes, Lam, {"hole": circ}, "float64",
+                              boundary=indices, terminal_currents=tc)
+        film_systems, hole_systems, terminal_systems = factorize_linear_systems(device_like, {"film": info})
+        g_tr = solve_for_terminal_current_stream(device_like, info, terminal_systems["film"], tc)
+        sol = solve_film(device=device_like, applied_field=(field_mT * FIELD_CONV) * np.ones(n), film_info=info,
+                         film_system=film_systems["film"], hole_systems=hole_systems["film"],
+                         field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX,
+                         terminal_systems=terminal_systems["film"])
+        out[f"current_{tag}"], out[f"field_mT_{tag}"], out[f"circ_{tag}"] = current, field_mT, circ
+        out[f"g_transport_{tag}"] = g_tr
+        out[f"g_{tag}"], out[f"J_{tag}"], out[f"self_field_{tag}"] = sol.stream, sol.current_density, sol.self_field
+        out[f"film_indices_{tag}"] = film_systems["film"].indices
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "n =", n)
+
+
 def lambda_xy(x, y):
     """The Lambda(x, y) of the inhomogeneous fixture (um)."""
     return 0.2 * (1.0 + 0.5 * x / 5.0 + 0.3 * (y / 5.0) ** 2)
@@ -448,6 +514,10 @@ if __name__ == "__main__":
         vortex_fixture(13, False, "vortex_disk_K13.npz")
         vortex_fixture(13, True, "vortex_washer_K13.npz")
         sys.exit(0)
+    if "--only-terminals" in sys.argv:
+        terminal_fixture(24, 10, 0.0, "terminals_strip.npz")
+        terminal_fixture(24, 10, 0.9, "terminals_strip_hole.npz")
+        sys.exit(0)
     if "--only-inhomogeneous" in sys.argv:
         inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")
         sys.exit(0)
@@ -466,3 +536,5 @@ if __name__ == "__main__":
     vortex_fixture(13, False, "vortex_disk_K13.npz")
     vortex_fixture(13, True, "vortex_washer_K13.npz")
     inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")
+    terminal_fixture(24, 10, 0.0, "terminals_strip.npz")
+    terminal_fixture(24, 10, 0.9, "terminals_strip_hole.npz")

@@ -296,11 +296,19 @@ class OracleFilm:
     A: np.ndarray = None
     lu_piv: Tuple[np.ndarray, np.ndarray] = None
     A_holes: Dict[str, np.ndarray] = field(default_factory=dict)
+    # films with terminals (solver/solve_film.py:220-263)
+    boundary_indices: Optional[np.ndarray] = None            # ordered counter-clockwise
+    terminal_masks: Optional[Dict[str, np.ndarray]] = None   # {terminal: contains(boundary points)}
+    A_boundary: Optional[np.ndarray] = None
+    fwb_indices: Optional[np.ndarray] = None                 # film without boundary (holes included)
+    fwb_lu_piv: Optional[Tuple[np.ndarray, np.ndarray]] = None
 
 
 def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.ndarray,
               holes_mask: Optional[Dict[str, np.ndarray]] = None,
-              dtype="float64", factorize: bool = True) -> OracleFilm:
+              dtype="float64", factorize: bool = True,
+              boundary_indices: Optional[np.ndarray] = None,
+              terminal_masks: Optional[Dict[str, np.ndarray]] = None) -> OracleFilm:
     """``make_film_info`` index logic (solver/utils.py:271-304) followed by
     ``factorize_linear_systems`` (solver/solve_film.py:209-218, 269-281).
 
@@ -314,7 +322,10 @@ def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.nda
         raise ValueError(f"Negative Lambda in film {name!r}.")  # solver/utils.py:57-58
     holes_mask = holes_mask or {}
     hole_indices = {h: np.where(m)[0] for h, m in holes_mask.items()}
-    interior = np.setdiff1d(np.where(in_film)[0], mesh.boundary_indices)
+    has_terminals = terminal_masks is not None
+    boundary = mesh.boundary_indices if boundary_indices is None else np.asarray(boundary_indices)
+    interior_all = np.setdiff1d(np.where(in_film)[0], boundary)  # solver/utils.py:300-303
+    interior = interior_all
     if hole_indices:
         interior = np.setdiff1d(interior, np.concatenate(list(hole_indices.values())))
     weights = mesh.weights.astype(dtype, copy=False)
@@ -342,6 +353,15 @@ def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.nda
     film.A = A.astype(dtype, copy=False)
     if factorize:
         film.lu_piv = la.lu_factor(-film.A)
+    if has_terminals:  # solve_film.py:220-263 (homogeneous Lambda)
+        film.boundary_indices = boundary
+        film.terminal_masks = terminal_masks
+        film.A_boundary = build_system_1d(Q, weights, Lambda, lap, boundary).astype(dtype, copy=False)
+        film.fwb_indices = interior_all
+        if hole_indices:
+            film.fwb_lu_piv = la.lu_factor(-build_system_2d(Q, weights, Lambda, lap, interior_all))
+        else:
+            film.fwb_lu_piv = film.lu_piv
     return film
 
 
@@ -363,11 +383,107 @@ class OracleFilmSolution:
         return out
 
 
+def boundary_vertices(points: np.ndarray, triangles: np.ndarray) -> np.ndarray:
+    """device/utils.py:205-226 without shapely: the directed boundary edges of the (CCW) triangles
+    chained into the outer loop, from its lowest vertex index (see superscreen_amd.fem)."""
+    tri = np.asarray(triangles, dtype=np.int64)
+    directed = {}
+    twins = set()
+    for t in tri:
+        p = points[t]
+        if (p[1, 0] - p[0, 0]) * (p[2, 1] - p[0, 1]) - (p[2, 0] - p[0, 0]) * (p[1, 1] - p[0, 1]) < 0:
+            t = t[[0, 2, 1]]
+        for k in range(3):
+            twins.add((int(t[(k + 1) % 3]), int(t[k])))
+            directed[(int(t[k]), int(t[(k + 1) % 3]))] = True
+    nxt = {a: b for (a, b) in directed if (a, b) not in twins}
+    start = min(nxt)
+    loop = [start]
+    while nxt[loop[-1]] != start:
+        loop.append(nxt[loop[-1]])
+    return np.asarray(loop, dtype=np.int64)
+
+
+def roll_boundary_outside_terminals(indices: np.ndarray, terminal_contains) -> np.ndarray:
+    """device/device.py:491-500: roll the loop so that it does not wrap around inside a terminal.
+    ``terminal_contains``: list of callables ``f(boundary_positions_order) -> index array``."""
+    for contains_ix in terminal_contains:
+        t_ix = contains_ix(indices)
+        discont = np.diff(t_ix) != 1
+        if np.any(discont):
+            return np.roll(indices, -(np.where(discont)[0][0] + 1))
+    return indices
+
+
+def _path_vectors(path: np.ndarray):
+    """geometry.py:12-29: edge lengths and unit normals (dy, -dx) / |d| of a path."""
+    dr = np.diff(path, axis=0)
+    lengths = la.norm(dr, axis=1)
+    return lengths, np.column_stack([dr[:, 1], -dr[:, 0]]) / lengths[:, None]
+
+
+def stream_from_terminal_current(points: np.ndarray, current: float) -> np.ndarray:
+    """solver/utils.py:440-488: g = cumulative trapezoid of (z x J) . dl for a current density
+    that is uniform along and perpendicular to the terminal, normalised to ``current``."""
+    from scipy import integrate
+
+    lengths, normals = _path_vectors(points)
+    J = current * normals / np.sum(lengths)
+    zxJ = np.column_stack([-J[:, 1], J[:, 0]])
+    g = integrate.cumulative_trapezoid(np.sum(zxJ * np.diff(points, axis=0), axis=1), initial=0)
+    return g * current / g[-1]
+
+
+def terminal_current_stream(film: OracleFilm, terminal_currents: Dict[str, float]) -> np.ndarray:
+    """solve_for_terminal_current_stream (solver/solve_film.py:308-390)."""
+    pts = film.mesh.sites
+    n = len(pts)
+    if not any(terminal_currents.values()):
+        return np.zeros(n)
+    b = film.boundary_indices
+    g = np.zeros(n)
+    for tname, mask in film.terminal_masks.items():
+        ixb = np.sort(np.where(mask)[0])
+        remaining = b[ixb[-1]:]
+        ixt = b[ixb]
+        stream = stream_from_terminal_current(pts[ixt], -terminal_currents[tname])
+        g[ixt[:-1]] += stream
+        g[remaining] += stream[-1]
+    g = g - np.max(g) + np.ptp(g) / 2
+    Ha = -(film.A_boundary @ g[b])
+    g[film.fwb_indices] = la.lu_solve(film.fwb_lu_piv, -Ha[film.fwb_indices])
+    if not film.hole_indices:
+        return g
+    Ha = np.zeros(n)
+    for h, ix in film.hole_indices.items():
+        g[ix] = np.average(g[ix], weights=film.weights[ix])
+        Ha += -(film.A_holes[h] @ g[ix])
+    Ha += -(film.A_boundary @ g[b])
+    g[film.film_indices] = la.lu_solve(film.lu_piv, -Ha[film.film_indices])
+    return g
+
+
+def boundary_effective_field(sites, centers, lengths, normals, stream) -> np.ndarray:
+    """_get_boundary_effective_field (solver/solve_film.py:393-412)."""
+    dr = sites[:, None, :] - centers[None, :, :]
+    r3 = la.norm(dr, axis=2) ** 3
+    return np.sum(stream[None, :] / r3 * np.sum(dr * -normals[None, :, :], axis=2) * lengths[None, :], axis=1) / (4 * np.pi)
+
+
+def biot_savart_within_film(sites, centroids, areas, J_tri) -> np.ndarray:
+    """_biot_savart_within_film (solver/solve_film.py:415-437)."""
+    dx = sites[:, 0, None] - centroids[None, :, 0]
+    dy = sites[:, 1, None] - centroids[None, :, 1]
+    pref = areas[None, :] * (dx * dx + dy * dy) ** (-1.5)
+    return (np.sum(pref * J_tri[None, :, 0] * dy, axis=1) - np.sum(pref * J_tri[None, :, 1] * dx, axis=1)) / (4 * np.pi)
+
+
 def solve_film(film: OracleFilm, applied_field: np.ndarray, *, field_conversion: float,
                circulating_currents: Optional[Dict[str, float]] = None,
                field_from_other_films: Optional[np.ndarray] = None,
                vortices: Sequence[Tuple[float, float, float]] = (),
-               vortex_flux: Optional[float] = None) -> OracleFilmSolution:
+               vortex_flux: Optional[float] = None,
+               terminal_currents: Optional[Dict[str, float]] = None) -> OracleFilmSolution:
     """solver/solve_film.py:440-574 without terminals.  ``vortices``: ``(x, y, nPhi0)`` triples
     located in this film (:541-554)."""
     circulating_currents = circulating_currents or {}
@@ -379,6 +495,16 @@ def solve_film(film: OracleFilm, applied_field: np.ndarray, *, field_conversion:
     for hname, ix in film.hole_indices.items():  # :498-503 (also when I_circ == 0)
         g[ix] += circulating_currents.get(hname, 0)
         Ha_eff += -(film.A_holes[hname] @ g[ix])
+    has_terminals = film.terminal_masks is not None
+    if has_terminals:  # :505-524
+        g_tr = terminal_current_stream(film, terminal_currents or {})
+        g = g + g_tr
+        bs = film.mesh.sites[film.boundary_indices]
+        stream = g_tr[film.boundary_indices]
+        centers = 0.5 * (bs + np.roll(bs, -1, axis=0))
+        stream = 0.5 * (stream + np.roll(stream, -1, axis=0))
+        lengths, normals = _path_vectors(np.concatenate([bs, bs[:1]]))
+        Ha_eff = Ha_eff + boundary_effective_field(film.mesh.sites, centers, lengths, normals, stream)
     ix = film.film_indices
     h = Hz[ix] - Ha_eff[ix]
     gf = la.lu_solve(film.lu_piv, h)  # :530  => g = -A^-1 h
@@ -393,7 +519,12 @@ def solve_film(film: OracleFilm, applied_field: np.ndarray, *, field_conversion:
         vf = vortex_flux_uA_um() if vortex_flux is None else vortex_flux
         g[ix] += vf * nPhi0 * K[:, j_film] / film.weights[j_device]  # Eq. 28 in [Brandt]
     J = np.array([film.mesh.gradient_y @ g, -(film.mesh.gradient_x @ g)]).T  # :556
-    screening = film.Q @ (film.weights * g)  # :565
+    if has_terminals:  # :557-562
+        m = film.mesh
+        J_tri = np.array([m.gradient_tri_y @ g, -(m.gradient_tri_x @ g)]).T
+        screening = biot_savart_within_film(m.sites, m.sites[m.elements].sum(axis=1) / 3, m.triangle_areas, J_tri)
+    else:
+        screening = film.Q @ (film.weights * g)  # :565
     other = None
     if field_from_other_films is not None:
         other = field_from_other_films / field_conversion

@@ -197,6 +197,10 @@ class Device:
             holes = list(holes.values())
         self.holes: Dict[str, Polygon] = {hole.name: hole for hole in holes}
         self.terminals: Dict[str, List[Polygon]] = terminals or {}
+        for film, terms in self.terminals.items():  # device/device.py:82-84
+            for terminal in terms:
+                if film in self.films:
+                    terminal.layer = self.films[film].layer
         if not set(self.terminals).issubset(self.films):
             raise ValueError(
                 f"terminals.keys() must be a subset of films.keys() ({list(self.films)!r})."
@@ -317,6 +321,27 @@ class Device:
         if missing:
             raise ValueError(f"No triangulation given for films {sorted(missing)!r}.")
         self.meshes = {name: Mesh.from_triangulation(*triangulations[name]) for name in self.films}
+
+    def boundary_vertices(self, film: str) -> Optional[np.ndarray]:
+        """Boundary vertex indices of a film's mesh, ordered counter-clockwise and rolled so that
+        the sequence does not wrap around inside a terminal (``device/device.py:473-500``)."""
+        from . import fem
+
+        if self.meshes is None:
+            return None
+        mesh = self.meshes[film]
+        points = mesh.sites
+        indices = fem.boundary_vertices(points, mesh.elements)
+        if film not in self.terminals:
+            return indices
+        for terminal in self.terminals[film]:
+            terminal_indices = terminal.contains_points(points[indices], index=True)
+            discont = np.diff(terminal_indices) != 1
+            if np.any(discont):
+                i_discont = np.where(discont)[0][0]
+                indices = np.roll(indices, -(i_discont + 1))
+                break
+        return indices
 
     def mutual_inductance_matrix(self, hole_polygon_mapping: Optional[Dict[str, np.ndarray]] = None,
                                  units: str = "pH", all_iterations: bool = False, progress_bar: bool = False,

@@ -48,6 +48,36 @@ def boundary_indices(triangles: np.ndarray) -> np.ndarray:
     return np.unique(np.concatenate([once // n, once % n]))
 
 
+def boundary_vertices(points: np.ndarray, triangles: np.ndarray) -> np.ndarray:
+    """Boundary vertex indices ordered counter-clockwise (``device/utils.py:205-226``).
+
+    The reference polygonises the boundary edges with shapely; here the directed edges of the
+    (counter-clockwise) triangles that have no twin are chained into the outer loop, starting at
+    its lowest vertex index.  (The reference's start vertex is whatever shapely returns; the
+    callers only rely on the cyclic order, ``Device.boundary_vertices`` re-rolls the loop so that
+    it does not wrap inside a terminal.)"""
+    tri = np.asarray(triangles, dtype=np.int64)
+    p = points[tri]
+    area2 = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 2, 0] - p[:, 0, 0]) * (p[:, 1, 1] - p[:, 0, 1])
+    tri = np.where(area2[:, None] < 0, tri[:, [0, 2, 1]], tri)
+    a = np.concatenate([tri[:, 0], tri[:, 1], tri[:, 2]])
+    b = np.concatenate([tri[:, 1], tri[:, 2], tri[:, 0]])
+    n = int(tri.max()) + 1
+    twins = set((b * n + a).tolist())
+    nxt = {int(u): int(v) for u, v in zip(a, b) if int(u) * n + int(v) not in twins}
+    if not nxt:
+        return np.zeros(0, dtype=np.int64)
+    start = min(nxt)
+    loop = [start]
+    while nxt[loop[-1]] != start:
+        loop.append(nxt[loop[-1]])
+        if len(loop) > len(nxt):
+            raise ValueError("The mesh boundary is not a single closed loop.")
+    if len(loop) != len(nxt):
+        raise ValueError("The mesh boundary is not a single closed loop.")
+    return np.asarray(loop, dtype=np.int64)
+
+
 def _angle(u: np.ndarray, v: np.ndarray) -> np.ndarray:
     """Angle between 2-D vectors; the reference takes ``arccos`` of the normalised dot product
     (``fem.py:188-224, 393-399``) -- same convention here so results agree to rounding."""

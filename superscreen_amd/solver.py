@@ -19,8 +19,9 @@ Memory (per film, n vertices, n_i unknowns, s = sizeof(solve dtype)): LU n_i^2 s
 n = 50k in f64), hole systems n * k_h * s, optional stored Q n^2 s; the reference additionally
 keeps A, a float64 Q and a DENSE Laplacian (solver/utils.py:290-292), about 5 n^2 words.
 
-Not implemented (raise NotImplementedError): terminal currents, HDF5
-persistence.  Vortices (solve_film.py:541-554) are one extra right-hand side per vortex through the
+Not implemented (raise NotImplementedError): HDF5 persistence.  Transport currents through terminals
+(solve_film.py:308-437, 505-524, 557-562) reuse the film factorization where the reference factors
+the same matrix again, and run their all-pairs sums through ``ssa_sheet_field``.  Vortices (solve_film.py:541-554) are one extra right-hand side per vortex through the
 existing factorization; a film with Lambda(x, y) (grad(Lambda) term, :181-185) goes through the LU
 route because diag(w) A is then no longer symmetric.
 """
@@ -39,6 +40,7 @@ import scipy.sparse as sp
 from . import fem
 from .device import Device
 from .parameter import Constant
+from .geometry import close_curve, path_vectors
 from .solution import FilmSolution, Solution, Vortex
 from .sources import ConstantField
 from .units import current_to_float, field_conversion_factor, vortex_flux
@@ -151,8 +153,9 @@ def make_film_info(*, device: Device, vortices: Sequence[Vortex],
         lambda_info = LambdaInfo(film=name, Lambda=Lambda, london_lambda=london_lambda,
                                  thickness=layer.thickness)
         if name in device.terminals:
-            raise NotImplementedError("Terminal currents are not on the accelerated path yet.")
-        boundary = mesh.boundary_indices
+            boundary = device.boundary_vertices(name)  # ordered, solver/utils.py:298-299
+        else:
+            boundary = mesh.boundary_indices
         interior = np.setdiff1d(_sites_in_polygon(mesh, film), boundary)
         film_info[name] = FilmInfo(
             name=name, layer=layer.name, lambda_info=lambda_info,
@@ -206,6 +209,29 @@ class FilmDeviceData:
         # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
         # unless the dense Q is wanted for the self-field GEMV.
         self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, geo["C"], dtype, want_Q=store_Q)
+        self._geo = geo
+
+    def triangle_data(self, mesh):
+        """Per-triangle operators of films with terminals (centroids, areas, triangle gradient CSR
+        with a shared pattern), uploaded on first use and cached with the mesh geometry."""
+        import torch
+
+        geo = self._geo
+        if "tri" not in geo:
+            ops = mesh.operators
+            dev = self.device
+
+            def put(a, dt=np.float64):
+                return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+
+            ptr_, idx_, vx, vy = fem.shared_pattern(ops.gradient_tri_x, ops.gradient_tri_y)
+            centroids = mesh.sites[mesh.elements].mean(axis=1)
+            geo["tri"] = dict(
+                grad=(put(ptr_, np.int64), put(idx_, np.int64), put(vx), put(vy)),
+                centroids=put(centroids), areas=put(mesh.triangle_areas),
+                sites3=put(np.column_stack([mesh.sites, np.zeros(len(mesh.sites))])),
+            )
+        return geo["tri"]
 
 
 @dataclass
@@ -245,6 +271,20 @@ class LinearSystem:
         return f.lu[:, :f.n].cpu().numpy(), f.ipiv.cpu().numpy()
 
 
+@dataclass
+class TerminalSystems:
+    """The linear systems behind the transport-current stream function of one film
+    (``solver/solve_film.py:80-148``).  ``film_without_boundary_or_holes`` has the same unknowns as
+    the film's own system and IS that object here (the reference factors the matrix twice); without
+    holes ``film_without_boundary`` is the same object too."""
+
+    film: str
+    boundary: LinearSystem
+    holes: Dict[str, LinearSystem]
+    film_without_boundary: Optional[LinearSystem] = None
+    film_without_boundary_or_holes: Optional[LinearSystem] = None
+
+
 def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo], *,
                              store_Q: bool = False, method: str = "auto"):
     """``factorize_linear_systems`` (``solver/solve_film.py:151-282``) on the GPU.
@@ -262,7 +302,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
 
     _hip.require_gpu()
     dtype = device.solve_dtype
-    film_systems, hole_systems, film_data = {}, {}, {}
+    film_systems, hole_systems, film_data, terminal_systems = {}, {}, {}, {}
     pending = []
     for name, info in film_info_dict.items():
         mesh = device.meshes[name]
@@ -301,39 +341,60 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
                 indices=indices, A_device=A_h, indices_device=ix_d, grad_Lambda_term=grad_Lambda_term,
                 _assemble=lambda A_h=A_h, k=len(indices): A_h[:, :k].cpu().numpy(),
             )
-        interior = info.interior_indices
-        if info.hole_indices:  # solve_film.py:269-272
-            interior = np.setdiff1d(interior, np.concatenate(list(info.hole_indices.values())))
-        ix_d = torch.from_numpy(interior.astype(np.int64)).to(dev)
-        ni = len(interior)
-        def lu_route(ix_d=ix_d, ni=ni, assemble=assemble, name=name):
-            minusA = assemble(ix_d, ix_d, -1.0)      # -A, written once, factored in place
-            factors = kernels.lu_factor(minusA, ni)  # solve_film.py:279
-            if factors.info > 0:
-                logger.warning(f"LU of film {name!r}: exactly singular U[{factors.info - 1}, "
-                               f"{factors.info - 1}] (LAPACK info = {factors.info}).")
-            return factors
+        targets = [("film", info.interior_indices)]
+        if name in device.terminals:  # solve_film.py:220-263
+            bix = np.asarray(info.boundary_indices, dtype=np.int64)
+            bix_d = torch.from_numpy(bix).to(dev)
+            A_b = assemble(None, bix_d, 1.0)
+            terminal_systems[name] = TerminalSystems(
+                film=name,
+                boundary=LinearSystem(indices=bix, A_device=A_b, indices_device=bix_d,
+                                      grad_Lambda_term=grad_Lambda_term,
+                                      _assemble=lambda A_b=A_b, k=len(bix): A_b[:, :k].cpu().numpy()),
+                holes=hole_systems[name])
+            if info.hole_indices:
+                targets.append(("film_without_boundary", info.interior_indices))
+        for role, interior in targets:
+            if role == "film":
+                if info.hole_indices:  # solve_film.py:269-272
+                    interior = np.setdiff1d(interior, np.concatenate(list(info.hole_indices.values())))
+                if name in device.terminals:
+                    interior = np.setdiff1d(interior, info.boundary_indices)  # :273-274
+            ix_d = torch.from_numpy(interior.astype(np.int64)).to(dev)
+            ni = len(interior)
 
-        host_A = lambda ix_d=ix_d, ni=ni, assemble=assemble: assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy()  # noqa: E731
-        S = None
-        if inhomogeneous and method == "cholesky":
-            raise ValueError(f"Film {name!r}: Lambda(x, y) makes diag(w) A non-symmetric; use method='auto' or 'lu'.")
-        if method in ("auto", "cholesky") and not inhomogeneous:
-            # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
-            # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
-            npad = kernels.chol_padded_n(ni)
-            S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
-                                        dtype=dtype, row_scale=fd.w, lower_only=True,
-                                        ld=kernels.padded_ld(npad, dtype), alloc_rows=npad)
-        pending.append((name, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term))
+            def lu_route(ix_d=ix_d, ni=ni, assemble=assemble, name=name):
+                minusA = assemble(ix_d, ix_d, -1.0)      # -A, written once, factored in place
+                factors = kernels.lu_factor(minusA, ni)  # solve_film.py:279
+                if factors.info > 0:
+                    logger.warning(f"LU of film {name!r}: exactly singular U[{factors.info - 1}, "
+                                   f"{factors.info - 1}] (LAPACK info = {factors.info}).")
+                return factors
+
+            def host_A(ix_d=ix_d, ni=ni, assemble=assemble):
+                return assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy()
+
+            S = None
+            if inhomogeneous and method == "cholesky":
+                raise ValueError(f"Film {name!r}: Lambda(x, y) makes diag(w) A non-symmetric; "
+                                 "use method='auto' or 'lu'.")
+            if method in ("auto", "cholesky") and not inhomogeneous:
+                # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
+                # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
+                npad = kernels.chol_padded_n(ni)
+                S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
+                                            dtype=dtype, row_scale=fd.w, lower_only=True,
+                                            ld=kernels.padded_ld(npad, dtype), alloc_rows=npad)
+            pending.append(((name, role), interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term))
     # All films are factored in one interleaved schedule (ssa_chol_factor_batch): the MFMA
     # trailing updates of the films alternate on the stream, each film's panel chain hides behind
     # the other films' updates.
     with_S = [p for p in pending if p[4] is not None]
     chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S])))
-    for name, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term in pending:
+    for key, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term in pending:
+        name, role = key
         system = None
-        chol = chols.get(name)
+        chol = chols.get(key)
         if chol is not None:
             if chol.info == 0:
                 system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,
@@ -344,15 +405,22 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
                 if method == "cholesky":
                     raise RuntimeError(f"diag(w) A of film {name!r} is not positive definite.")
                 logger.warning(f"Film {name!r}: Cholesky pivot not positive, falling back to LU.")
-                del chols[name]
+                del chols[key]
                 del S, chol
         if system is None:
             factors = lu_route()
             system = LinearSystem(indices=interior, factors=factors, indices_device=ix_d,
                                   grad_Lambda_term=grad_Lambda_term,
                                   rhs_indices_device=ix_d[factors.perm].contiguous(), _assemble=host_A)
-        film_systems[name] = system
-    return film_systems, hole_systems, {}, film_data
+        if role == "film":
+            film_systems[name] = system
+            if name in terminal_systems:
+                terminal_systems[name].film_without_boundary_or_holes = system
+                if terminal_systems[name].film_without_boundary is None and not film_info_dict[name].hole_indices:
+                    terminal_systems[name].film_without_boundary = system
+        else:
+            terminal_systems[name].film_without_boundary = system
+    return film_systems, hole_systems, terminal_systems, film_data
 
 
 @dataclass
@@ -445,8 +513,6 @@ def factorize_model(*, device: Device, current_units: str,
     for film_name, currents in terminal_currents.items():
         if sum(currents.values()):
             raise ValueError(f"Terminal currents in film {film_name!r} are not conserved.")
-    if any(terminal_currents.values()):
-        raise NotImplementedError("Terminal currents are not on the accelerated path yet.")
     vortices = list(vortices or [])
     if not device.meshes:
         raise ValueError("The device does not have a mesh. Call device.make_mesh() to generate it.")
@@ -470,6 +536,123 @@ class _DeviceFilmResult:
     self_field: object  # [n] solve dtype, raw (not yet divided by field_conversion)
 
 
+def _system_solve(system: LinearSystem, h):
+    """``lu_solve(system.lu_piv, h)`` for a right-hand side in natural order (device vector):
+    through the Cholesky factor of ``diag(w) A`` if the system has one, else through the LU."""
+    from . import kernels
+
+    if system.chol is not None:
+        return kernels.chol_solve(system.chol, kernels.row_scale(h, system.neg_w_device))
+    return kernels.lu_solve(system.factors, h)
+
+
+def stream_from_current_density(points: np.ndarray, J: np.ndarray) -> np.ndarray:
+    """``solver/utils.py:440-463``: ``g(r) = g(r0) + int (z x J) . dl`` along ``points``."""
+    from scipy import integrate
+
+    zhat_cross_J = J[:, [1, 0]].copy()
+    zhat_cross_J[:, 0] *= -1
+    dl = np.diff(points, axis=0)
+    integrand = np.sum(zhat_cross_J * dl, axis=1)
+    return integrate.cumulative_trapezoid(integrand, initial=0)
+
+
+def stream_from_terminal_current(points: np.ndarray, current: float) -> np.ndarray:
+    """``solver/utils.py:466-488``: stream function along a terminal that sources ``current``
+    uniformly and perpendicular to itself."""
+    edge_lengths, unit_normals = path_vectors(points)
+    J = current * unit_normals / np.sum(edge_lengths)
+    g = stream_from_current_density(points, J)
+    return g * current / g[-1]
+
+
+def _terminal_transport(model: "FactorizedModel", name: str):
+    """Device vectors ``(g_transport, Ha_transport)`` of a film with terminals
+    (``solve_for_terminal_current_stream``, ``solve_film.py:308-390``, and the boundary effective
+    field, ``:507-524``); they depend on the terminal currents only, so they are computed once per
+    model and reused by every pass.  Boundary bookkeeping is host work on O(sqrt n) vertices; the
+    gemvs, the two triangular solves and the all-pairs boundary field run on the GPU."""
+    import torch
+
+    from . import kernels
+
+    cache = model.__dict__.setdefault("_transport", {})
+    info = model.film_info[name]
+    currents = dict(info.terminal_currents or {})
+    key = (name, tuple(sorted(currents.items())))
+    if key in cache:
+        return cache[key]
+    fd = model.film_data[name]
+    device = model.device
+    mesh = device.meshes[name]
+    points = mesh.sites
+    weights = mesh.operators.weights
+    n = len(points)
+    ts = model.terminal_systems[name]
+    zeros = torch.zeros(n, dtype=fd.tdtype, device=fd.device)
+    if not any(currents.values()):
+        cache[key] = (zeros, zeros.clone())
+        return cache[key]
+
+    def put(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(fd.device).to(fd.tdtype)
+
+    def minus_A_times(system: LinearSystem, g_d, out):
+        kernels.gemv(system.A_device, n, len(system.indices), g_d, xidx=system.indices_device, y=out,
+                     alpha=-1.0, beta=1.0)
+
+    boundary_indices = ts.boundary.indices
+    boundary_points = points[boundary_indices]
+    # 1. stream function on the boundary (:342-353)
+    g = np.zeros(n)
+    for terminal in device.terminals[name]:
+        current = currents[terminal.name]
+        ix_boundary = np.sort(terminal.contains_points(boundary_points, index=True))
+        remaining_boundary = boundary_indices[ix_boundary[-1]:]
+        ix_terminal = boundary_indices[ix_boundary]
+        stream = stream_from_terminal_current(points[ix_terminal], -current)
+        g[ix_terminal[:-1]] += stream
+        g[remaining_boundary] += stream[-1]
+    g = g - np.max(g) + np.ptp(g) / 2
+    ha = torch.zeros(n, dtype=fd.tdtype, device=fd.device)
+    minus_A_times(ts.boundary, put(g), ha)
+    # 2. interior, holes ignored (:358-364)
+    fwb = ts.film_without_boundary
+    h = kernels.film_rhs(zeros, None, ha, fwb.indices_device)          # = -Ha_eff[indices]
+    g[fwb.indices] = _system_solve(fwb, h).cpu().numpy()
+    if ts.holes:
+        # holes: weighted average of the hole-free answer, then re-solve (:366-385)
+        ha = torch.zeros(n, dtype=fd.tdtype, device=fd.device)
+        for system in ts.holes.values():
+            ix = system.indices
+            g[ix] = np.average(g[ix], weights=weights[ix])
+        g_d = put(g)
+        for system in ts.holes.values():
+            minus_A_times(system, g_d, ha)
+        minus_A_times(ts.boundary, g_d, ha)
+        sys3 = ts.film_without_boundary_or_holes
+        h = kernels.film_rhs(zeros, None, ha, sys3.indices_device)
+        g[sys3.indices] = _system_solve(sys3, h).cpu().numpy()
+    g_transport = put(g)
+    # effective field of the boundary stream (:510-524; numba kernel _get_boundary_effective_field
+    # :393-412): sum_j stream_j (dr . -n_j) len_j / (4 pi |dr|^3) over the boundary edges -- the
+    # z component of a "sheet" made of the edge centres with J = (b, -a), (a, b) = -stream len n
+    b_idx = info.boundary_indices
+    boundary_sites = points[b_idx]
+    boundary_stream = g[b_idx]
+    centers = 0.5 * (boundary_sites + np.roll(boundary_sites, -1, axis=0))
+    boundary_stream = 0.5 * (boundary_stream + np.roll(boundary_stream, -1, axis=0))
+    lengths, normals = path_vectors(close_curve(boundary_sites))
+    ab = -(boundary_stream * lengths)[:, None] * normals
+    ev = np.column_stack([points, np.zeros(n)])
+    f64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(fd.device)  # noqa: E731
+    ha_t = kernels.sheet_field(f64(centers), f64(np.ones(len(centers))),
+                               f64(np.column_stack([ab[:, 1], -ab[:, 0]])), 0.0, f64(ev),
+                               1.0 / (4 * np.pi), False).to(fd.tdtype)
+    cache[key] = (g_transport, ha_t)
+    return cache[key]
+
+
 def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
                        check_inversion: bool, vortex_flux_value: float = 0.0) -> _DeviceFilmResult:
     """Device part of ``solve_film`` (``solver/solve_film.py:486-565``)."""
@@ -487,6 +670,11 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
         kernels.index_add_scalar(g, hs.indices_device, current)        # g[hole] += I_circ
         kernels.gemv(hs.A_device, fd.n, len(hs.indices), g, xidx=hs.indices_device,
                      y=ha_eff, alpha=-1.0, beta=1.0)                      # Ha_eff += -(A @ g[ix])
+    has_terminals = name in model.device.terminals
+    if has_terminals:  # solve_film.py:505-524
+        g_transport, ha_transport = _terminal_transport(model, name)
+        g += g_transport
+        ha_eff += ha_transport
     if system.chol is not None:
         h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
         gf = kernels.chol_solve(system.chol, kernels.row_scale(h_nat, system.neg_w_device))
@@ -514,7 +702,14 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
             g_vortex = kernels.scale(model.vortex_column(name, j_film), scale)
             kernels.scatter_add(g, system.indices_device, g_vortex)
     J = kernels.current_density(*fd.grad, g)
-    if model.self_field_mode == "dense":
+    if has_terminals:
+        # solve_film.py:557-562: Biot-Savart of the per-triangle currents (numba kernel
+        # _biot_savart_within_film, :415-437) = z component of a sheet made of the triangle centroids
+        tri = fd.triangle_data(model.device.meshes[name])
+        J_tri = kernels.current_density(*tri["grad"], g)
+        sf = kernels.sheet_field(tri["centroids"], tri["areas"], J_tri, 0.0, tri["sites3"],
+                                 1.0 / (4 * np.pi), False).to(fd.tdtype)
+    elif model.self_field_mode == "dense":
         sf = kernels.gemv(fd.Q, fd.n, fd.n, g, xscale=fd.w_t)
     else:
         sf = kernels.self_field(fd.xy, fd.w, fd.qdiag, g)

@@ -106,3 +106,50 @@ def make_stack_device(
     mesh = Mesh.from_triangulation(sites, elements)  # one mesh object shared by all films
     device.meshes = {film.name: mesh for film in films}
     return device
+
+
+def strip_mesh(nx: int, ny: int, length: float = 10.0, width: float = 4.0) -> Tuple[np.ndarray, np.ndarray]:
+    """Structured ``(nx+1) x (ny+1)`` grid on ``[-length/2, length/2] x [-width/2, width/2]``, every
+    cell split into two counter-clockwise triangles (alternating diagonals).  All vertices lie
+    inside or on the film outline of :func:`make_strip_device`."""
+    xs = np.linspace(-length / 2, length / 2, nx + 1)
+    ys = np.linspace(-width / 2, width / 2, ny + 1)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    sites = np.column_stack([X.ravel(), Y.ravel()])
+
+    def vid(i, j):
+        return i * (ny + 1) + j
+
+    tris = []
+    for i in range(nx):
+        for j in range(ny):
+            a, b, c, d = vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)
+            if (i + j) % 2 == 0:
+                tris += [(a, b, c), (a, c, d)]
+            else:
+                tris += [(a, b, d), (b, c, d)]
+    return sites, np.asarray(tris, dtype=np.int64)
+
+
+def make_strip_device(nx: int = 40, ny: int = 16, *, length: float = 10.0, width: float = 4.0,
+                      Lambda: float = 0.3, hole_radius: float = 0.0, solve_dtype: str = "float64"):
+    """A current-carrying strip: one film with a ``source`` terminal on its left edge and a
+    ``drain`` terminal on its right edge (transport currents, ``solve_film.py:308-390``), optionally
+    with a round hole in the middle."""
+    from .device import Device, Layer, Polygon
+    from .geometry import box
+    from .mesh import Mesh
+
+    sites, elements = strip_mesh(nx, ny, length, width)
+    eps = 1e-3 * min(length / nx, width / ny)
+    film = Polygon("strip", layer="base", points=box(length + 2 * eps, width + 2 * eps, points=401))
+    dx = length / nx
+    src = Polygon("source", layer="base", points=box(dx, width + 4 * eps, points=41, center=(-length / 2, 0.0)))
+    drn = Polygon("drain", layer="base", points=box(dx, width + 4 * eps, points=41, center=(length / 2, 0.0)))
+    holes = []
+    if hole_radius > 0:
+        holes.append(Polygon("hole", layer="base", points=circle_points(hole_radius, 101)))
+    device = Device("strip", layers=[Layer("base", Lambda=Lambda, z0=0.0)], films=[film], holes=holes,
+                    terminals={"strip": [src, drn]}, length_units="um", solve_dtype=solve_dtype)
+    device.meshes = {"strip": Mesh.from_triangulation(sites, elements)}
+    return device

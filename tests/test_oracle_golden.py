@@ -210,3 +210,47 @@ def test_inhomogeneous_lambda(golden):
     assert relerr(sol.stream, d["g"]) < RTOL
     assert relerr(sol.current_density, d["J"]) < RTOL
     assert relerr(sol.self_field, d["self_field"]) < RTOL
+
+
+@pytest.mark.parametrize("name", ["terminals_strip.npz", "terminals_strip_hole.npz"])
+def test_terminal_currents(golden, name):
+    """Transport currents (solver/solve_film.py:308-437, 505-524, 557-562) recorded from the reference."""
+    import importlib.util, os
+    d = golden(name)
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(mod):
+        spec = importlib.util.spec_from_file_location("_" + mod, os.path.join(here, "superscreen_amd", mod + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    syn, geo = load("synthetic"), load("geometry")
+    nx, ny, length, width = int(d["nx"]), int(d["ny"]), 10.0, 4.0
+    sites, elements = syn.strip_mesh(nx, ny, length, width)
+    mesh = orc.make_mesh(sites, elements)
+    eps = 1e-3 * min(length / nx, width / ny)
+    dx = length / nx
+    film_poly = geo.box(length + 2 * eps, width + 2 * eps, points=401)
+    terms = {"source": geo.box(dx, width + 4 * eps, points=41, center=(-length / 2, 0.0)),
+             "drain": geo.box(dx, width + 4 * eps, points=41, center=(length / 2, 0.0))}
+    loop = orc.boundary_vertices(sites, elements)
+    loop = orc.roll_boundary_outside_terminals(
+        loop, [lambda ix, p=p: np.where(contains(p, sites[ix]))[0] for p in terms.values()])
+    assert np.array_equal(loop, d["boundary_indices"])
+    hr = float(d["hole_radius"])
+    holes = {"hole": contains(syn.circle_points(hr, 101), sites)} if hr > 0 else {}
+    film = orc.make_film("film", mesh, z0=0.0, Lambda=float(d["Lambda"]), in_film=contains(film_poly, sites),
+                         holes_mask=holes, boundary_indices=loop,
+                         terminal_masks={t: contains(p, sites[loop]) for t, p in terms.items()})
+    conv = float(d["field_conversion"])
+    for tag in ("a", "b"):
+        cur = float(d[f"current_{tag}"])
+        tc = {"source": cur, "drain": -cur}
+        assert np.array_equal(film.film_indices, d[f"film_indices_{tag}"])
+        assert relerr(orc.terminal_current_stream(film, tc), d[f"g_transport_{tag}"]) < RTOL
+        sol = orc.solve_film(film, float(d[f"field_mT_{tag}"]) * conv * np.ones(len(sites)), field_conversion=conv,
+                             circulating_currents={"hole": float(d[f"circ_{tag}"])}, terminal_currents=tc)
+        assert relerr(sol.stream, d[f"g_{tag}"]) < RTOL
+        assert relerr(sol.current_density, d[f"J_{tag}"]) < RTOL
+        assert relerr(sol.self_field, d[f"self_field_{tag}"]) < RTOL

@@ -404,3 +404,33 @@ def test_inhomogeneous_lambda_vs_reference(golden):
     assert relerr(sol.self_field, d["self_field"]) < 1e-9
     with pytest.raises(ValueError):
         sc.factorize_model(device=device, current_units="uA", method="cholesky")
+
+
+@pytest.mark.parametrize("name", ["terminals_strip.npz", "terminals_strip_hole.npz"])
+@pytest.mark.parametrize("method", ["auto", "lu"])
+def test_terminal_currents_vs_reference(golden, name, method):
+    """Transport currents through terminals (solver/solve_film.py:308-437, 505-524, 557-562)."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    d = golden(name)
+    device = synthetic.make_strip_device(int(d["nx"]), int(d["ny"]), Lambda=float(d["Lambda"]),
+                                         hole_radius=float(d["hole_radius"]))
+    assert np.array_equal(device.boundary_vertices("strip"), d["boundary_indices"])
+    for tag in ("a", "b"):
+        cur = float(d[f"current_{tag}"])
+        circ = {"hole": float(d[f"circ_{tag}"])} if float(d["hole_radius"]) > 0 else None
+        model = sc.factorize_model(device=device, current_units="uA", circulating_currents=circ,
+                                   terminal_currents={"strip": {"source": cur, "drain": -cur}}, method=method)
+        assert np.array_equal(model.film_systems["strip"].indices, d[f"film_indices_{tag}"])
+        sol = sc.solve(model=model, applied_field=sc.ConstantField(float(d[f"field_mT_{tag}"])),
+                       field_units="mT")[-1].film_solutions["strip"]
+        assert relerr(sol.stream, d[f"g_{tag}"]) < 1e-9
+        assert relerr(sol.current_density, d[f"J_{tag}"]) < 1e-9
+        assert relerr(sol.self_field, d[f"self_field_{tag}"]) < 1e-9
+    with pytest.raises(ValueError, match="not conserved"):
+        sc.factorize_model(device=device, current_units="uA", terminal_currents={"strip": {"source": 1.0, "drain": 0.5}})
+    # no terminal current: the transport part vanishes, the terminal film still uses the Biot-Savart self-field
+    model0 = sc.factorize_model(device=device, current_units="uA")
+    s0 = sc.solve(model=model0, applied_field=sc.ConstantField(0.4), field_units="mT")[-1].film_solutions["strip"]
+    assert np.isfinite(s0.stream).all() and np.abs(s0.stream).max() > 0
