@@ -181,11 +181,19 @@ int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void 
  * src_xy [ns,2], src_areas [ns], src_J [ns,2], eval_xyz [np,3], out [np] or [np,3]: float64, in the
  * caller's length / current units; prefactor = (mu_0 / 4 pi) * (A/m per current_unit/length_unit)
  * gives tesla.  Deterministic two-stage reduction; workspace ssa_sheet_field_workspace_bytes.
+ *
+ * ssa_sheet_potential: the in-plane vector potential of the same sheet
+ * (Solution.vector_potential_at_position, solution.py:833-934; cdist + einsum there):
+ *   out[i,0:2] = prefactor * sum_k a_k (Jx_k, Jy_k) / |r_i - r_k|      out [np,2] float64
+ * workspace: ssa_sheet_field_workspace_bytes(np, 1).
  */
 size_t ssa_sheet_field_workspace_bytes(int64_t np, int vector);
 int ssa_sheet_field(const double *src_xy, const double *src_areas, const double *src_J, int64_t ns,
                     double z0, const double *eval_xyz, int64_t np, double prefactor, int vector,
                     double *out, void *workspace, size_t workspace_bytes, void *stream);
+int ssa_sheet_potential(const double *src_xy, const double *src_areas, const double *src_J, int64_t ns,
+                        double z0, const double *eval_xyz, int64_t np, double prefactor, double *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------- */
 /* (3) Per-film vector kernels of solve_film                                           */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ssa_gemm": (c_int, [I64, I64, I64, c_double, P, I64, P, I64, c_double, P, I64, c_int, P]),
     "ssa_sheet_field_workspace_bytes": (c_size_t, [I64, c_int]),
     "ssa_sheet_field": (c_int, [P, P, P, I64, c_double, P, I64, c_double, c_int, P, P, c_size_t, P]),
+    "ssa_sheet_potential": (c_int, [P, P, P, I64, c_double, P, I64, c_double, P, P, c_size_t, P]),
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),
     "ssa_mfma_probe": (c_int, [c_int, P, P, P]),
     "ssa_profile_begin": (c_int, []),

@@ -121,6 +121,53 @@ __global__ __launch_bounds__(kPairThreads) void sheet_field_partial_kernel(
     }
 }
 
+// Vector potential of a current sheet (solution.py:833-934):  A_xy(r) = sum_k a_k J_k / |r - r_k|
+// (prefactor mu_0 / 4 pi and units applied by the combine), two accumulators per point.
+__global__ __launch_bounds__(kPairThreads) void sheet_potential_partial_kernel(
+    const double *__restrict__ src_xy, const double *__restrict__ src_areas, const double *__restrict__ src_J,
+    int64_t ns, int64_t slice_len, double z0, const double *__restrict__ eval_xyz, int64_t np,
+    double *__restrict__ partial) {
+    __shared__ Source s_src[kPairThreads];
+    const int tid = threadIdx.x;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
+    const int64_t j_end = (j_begin + slice_len < ns) ? j_begin + slice_len : ns;
+    const int64_t ic = (i < np) ? i : np - 1;
+    const double xi = eval_xyz[3 * ic], yi = eval_xyz[3 * ic + 1], dz = eval_xyz[3 * ic + 2] - z0;
+    const double dz2 = dz * dz;
+    double ax = 0.0, ay = 0.0;
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        const int64_t j = t0 + tid;
+        Source s;
+        if (j < j_end) {
+            const double a = src_areas[j];
+            s.x = src_xy[2 * j];
+            s.y = src_xy[2 * j + 1];
+            s.a = a * src_J[2 * j];
+            s.b = a * src_J[2 * j + 1];
+        } else {
+            s.x = 0.0; s.y = 0.0; s.a = 0.0; s.b = 0.0;
+        }
+        __syncthreads();
+        s_src[tid] = s;
+        __syncthreads();
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const Source q = s_src[k];
+            const double dx = xi - q.x, dy = yi - q.y;
+            const double y = rsqrt_f64(__builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2)));
+            ax = __builtin_fma(q.a, y, ax);
+            ay = __builtin_fma(q.b, y, ay);
+        }
+    }
+    if (i < np) {
+        double *dst = partial + (static_cast<int64_t>(blockIdx.y) * np + i) * 2;
+        dst[0] = ax;
+        dst[1] = ay;
+    }
+}
+
 __global__ void sheet_field_combine_kernel(const double *__restrict__ partial, int slices, int64_t count,
                                            double prefactor, double *__restrict__ out) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -294,6 +341,27 @@ extern "C" int ssa_sheet_field(const double *src_xy, const double *src_areas, co
     SSA_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(sheet_field_combine_kernel, dim3(static_cast<unsigned>(ceil_div(np * nc, 256))), dim3(256), 0,
                        st, partial, slices, np * nc, prefactor, out);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_sheet_potential(const double *src_xy, const double *src_areas, const double *src_J, int64_t ns,
+                                   double z0, const double *eval_xyz, int64_t np, double prefactor, double *out,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (!src_xy || !src_areas || !src_J || !eval_xyz || !out || ns <= 0 || np <= 0)
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_sheet_field_workspace_bytes(np, 1)) return SSA_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = as_stream(stream);
+    double *partial = static_cast<double *>(workspace);
+    int slices = pick_slices(np, ns);
+    const int64_t slice_len = ceil_div(ceil_div(ns, slices), kPairThreads) * kPairThreads;
+    slices = static_cast<int>(ceil_div(ns, slice_len));
+    hipLaunchKernelGGL(sheet_potential_partial_kernel,
+                       dim3(static_cast<unsigned>(ceil_div(np, kPairThreads)), slices), dim3(kPairThreads), 0, st,
+                       src_xy, src_areas, src_J, ns, slice_len, z0, eval_xyz, np, partial);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(sheet_field_combine_kernel, dim3(static_cast<unsigned>(ceil_div(np * 2, 256))), dim3(256), 0,
+                       st, partial, slices, np * 2, prefactor, out);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }

@@ -345,6 +345,21 @@ def sheet_field(src_xy: torch.Tensor, src_areas: torch.Tensor, src_J: torch.Tens
     return out
 
 
+def sheet_potential(src_xy: torch.Tensor, src_areas: torch.Tensor, src_J: torch.Tensor, z0: float,
+                    eval_xyz: torch.Tensor, prefactor: float) -> torch.Tensor:
+    """In-plane vector potential of a film's sheet current at arbitrary points
+    (``solution.py:833-934``): ``[np, 2]`` float64."""
+    lib = load_library()
+    np_, ns = eval_xyz.shape[0], src_xy.shape[0]
+    out = torch.empty((np_, 2), dtype=torch.float64, device=eval_xyz.device)
+    nbytes = lib.ssa_sheet_field_workspace_bytes(np_, 1)
+    ws = _ws(nbytes, eval_xyz.device)
+    check(lib.ssa_sheet_potential(ptr(src_xy), ptr(src_areas), ptr(src_J), ns, float(z0), ptr(eval_xyz), np_,
+                                  float(prefactor), ptr(out), ptr(ws), nbytes, current_stream()),
+          "ssa_sheet_potential")
+    return out
+
+
 def mfma_probe(iters: int = 2000) -> float:
     """Sustained FP64 MFMA rate of this GPU in TFLOP/s (register-only instruction stream)."""
     lib = load_library()

@@ -266,6 +266,85 @@ class Solution:
             return sum(fields.values()) if not with_units else _sum_quantities(list(fields.values()))
         return fields
 
+    def vector_potential_at_position(self, positions: np.ndarray, *, zs=None, units: Optional[str] = None,
+                                     with_units: bool = True, return_sum: bool = True):
+        """Vector potential of the currents in the device anywhere in space (``solution.py:833-934``):
+        ``A(r) = mu_0 / (4 pi) sum_k a_k J_k / |r - r_k|`` per film, shape ``(m, 3)`` with ``A_z = 0``.
+        The all-pairs sum runs on the GPU (``ssa_sheet_potential``; cdist + einsum in the reference)."""
+        import torch
+
+        from . import _hip, kernels
+
+        _hip.require_gpu()
+        device = self.device
+        dtype = device.solve_dtype
+        units = units or f"{self.field_units} * {device.length_units}"
+        positions, zs = self._split_positions(positions, zs, dtype)
+        new = parse_units(units)
+        length = parse_units(device.length_units).scale
+        current = parse_units(self.current_units).scale
+        tesla_metre, ampere = (1, 1, -2, -1), (0, 0, 0, 1)
+        if new.dims == tesla_metre:
+            to_units = MU_0 / (4 * np.pi) * current / new.scale
+        elif new.dims == ampere:  # H-like field units: A = mu_0 (...)  ->  (...) in current units
+            to_units = 1.0 / (4 * np.pi) * current / new.scale
+        else:
+            raise ValueError(f"{units!r} is not a unit of vector potential.")
+        del length  # (current/length) * length^2 / length = current: no length factor is left
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def put(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+        ev = put(np.column_stack([positions, zs]))
+        out = {}
+        for name, film in device.films.items():
+            z0 = device.layers[film.layer].z0
+            if np.all(zs - z0 == 0) and film.contains_points(positions).all():
+                raise ValueError(f"Cannot evaluate vector potential inside the film ({name!r}).")
+            mesh = device.meshes[name]
+            Axy = kernels.sheet_potential(put(mesh.sites), put(mesh.vertex_areas),
+                                          put(self.film_solutions[name].current_density), float(z0), ev,
+                                          to_units).cpu().numpy()
+            A = np.concatenate([Axy, np.zeros_like(Axy[:, :1])], axis=1)
+            out[name] = Quantity(A, new) if with_units else A
+        if return_sum:
+            vals = list(out.values())
+            return _sum_quantities(vals) if with_units else sum(vals)
+        return out
+
+    def polygon_flux(self, name: str, units: Optional[str] = None, with_units: bool = True):
+        """Flux through a film, hole or abstract region of the device (``solution.py:430-482``):
+        ``sum_i total_field_i w_i`` over the mesh sites inside the polygon."""
+        device = self.device
+        polygons = {p.name: p for p in device.get_polygons(include_terminals=False)}
+        if name not in polygons:
+            raise ValueError(f"Unknown polygon: {name!r}.")
+        units = units or f"{self.field_units} * {device.length_units}**2"
+        polygon = polygons[name]
+        if name in device.films:
+            film_name = name
+        else:
+            film_name = None
+            for film in device.films.values():
+                if film.layer == polygon.layer and film.contains_points(polygon.points).all():
+                    film_name = film.name
+                    break
+            if film_name is None:
+                raise ValueError(f"Polygon {name!r} is not contained in any film of its layer.")
+        mesh = device.meshes[film_name]
+        ix = polygon.contains_points(mesh.sites, index=True)
+        total_field = self.film_solutions[film_name].total_field
+        flux_raw = float(np.einsum("i, i ->", total_field[ix], mesh.vertex_areas[ix]))
+        flux_T_m2 = convert_field(flux_raw, "T", old_units=self.field_units, with_units=False) \
+            * parse_units(device.length_units).scale ** 2
+        new = parse_units(units)
+        if new.dims == (0, 0, 0, 1) or new.dims == (1, 0, 0, 1):  # H-like field units * area
+            q = Quantity(flux_T_m2 / MU_0, "A * m").to(units)
+        else:
+            q = Quantity(flux_T_m2, "Wb").to(units)
+        return q if with_units else float(q.magnitude)
+
     def polygon_fluxoid(self, polygon_coords, *, film: str, interp_method: str = "linear",
                         units: Optional[str] = "Phi_0", with_units: bool = True) -> Fluxoid:
         """Fluxoid of a polygonal region (``solution.py:484-563``):

@@ -434,3 +434,38 @@ def test_terminal_currents_vs_reference(golden, name, method):
     model0 = sc.factorize_model(device=device, current_units="uA")
     s0 = sc.solve(model=model0, applied_field=sc.ConstantField(0.4), field_units="mT")[-1].film_solutions["strip"]
     assert np.isfinite(s0.stream).all() and np.abs(s0.stream).max() > 0
+
+
+def test_vector_potential_and_polygon_flux():
+    """Solution.vector_potential_at_position (solution.py:833-934) against its cdist/einsum formula,
+    and polygon_flux (:430-482) against the flux part of polygon_fluxoid."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+    from superscreen_amd.units import MU_0
+
+    device = synthetic.make_stack_device(12, ("washer", "disk"), z_spacing=0.5)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": 3.0})
+    sol = sc.solve(model=model, applied_field=sc.ConstantField(0.0), field_units="mT", iterations=2)[-1]
+    rng = np.random.default_rng(4)
+    pts = np.column_stack([rng.uniform(-6, 6, 40), rng.uniform(-6, 6, 40), rng.uniform(0.8, 2.0, 40)])
+    got = sol.vector_potential_at_position(pts, units="mT * um", with_units=False, return_sum=False)
+    for name, film in device.films.items():
+        mesh = device.meshes[name]
+        z0 = device.layers[film.layer].z0
+        J = sol.film_solutions[name].current_density
+        rho = np.sqrt(((pts[:, None, :2] - mesh.sites[None, :, :]) ** 2).sum(axis=2) + (pts[:, 2, None] - z0) ** 2)
+        Axy = np.einsum("ijk, j -> ik", J[None, :, :] / rho[:, :, None], mesh.vertex_areas)   # uA
+        ref = MU_0 / (4 * np.pi) * Axy * 1e-6 / (1e-3 * 1e-6)                                  # T m -> mT um
+        assert relerr(got[name][:, :2], ref) < 1e-12 and not got[name][:, 2].any()
+    total = sol.vector_potential_at_position(pts[:, :2], zs=1.5)
+    assert total.magnitude.shape == (40, 3)
+    with pytest.raises(ValueError, match="inside the film"):
+        sol.vector_potential_at_position(np.array([[0.5, 0.5]]) * 4.0, zs=0.0)
+    # polygon_flux of the hole == flux part of the fluxoid of the hole's own outline
+    hole = device.holes["hole0"]
+    flux = sol.polygon_flux("hole0", units="Phi_0", with_units=False)
+    fl = sol.polygon_fluxoid(hole.points, film="washer0", units="Phi_0", with_units=False)
+    assert abs(flux - fl.flux_part) <= 1e-12 * abs(fl.flux_part)
+    assert sol.polygon_flux("washer0").units.dims == sc.units.parse_units("mT * um**2").dims
+    with pytest.raises(ValueError, match="Unknown polygon"):
+        sol.polygon_flux("nope")
