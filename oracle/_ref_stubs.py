@@ -8,8 +8,8 @@ The numba kernels then run as plain Python loops (``njit`` = identity, ``prange`
 
 Nothing from the reference is copied; this file only exists so that
 ``oracle/make_golden.py`` can *call* the reference and record its outputs as fixtures.
-The reference does not exist on the GPU box, so nothing outside ``make_golden.py`` and the
-container-only ``tests/test_oracle_vs_reference.py`` may import this module.
+The reference does not exist on the GPU box, so nothing outside ``make_golden.py`` may import
+this module.
 """
 import os
 import sys

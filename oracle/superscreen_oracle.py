@@ -15,8 +15,8 @@ Parity pinning: the reference holds NO golden vectors for this path (SURVEY.md s
 its tests are physics invariants at 5e-2).  This oracle is therefore pinned against outputs
 of the *reference itself*, run in the build container under inert import stubs
 (``oracle/_ref_stubs.py``), recorded by ``oracle/make_golden.py`` into ``tests/golden/*.npz``
-and re-checked by ``tests/test_oracle_golden.py`` (runs anywhere) and
-``tests/test_oracle_vs_reference.py`` (runs only where ``/root/reference`` exists).
+and re-checked by ``tests/test_oracle_golden.py`` (runs anywhere; the reference itself cannot
+travel to the GPU box, the fixtures can).
 
 Third-party arithmetic on the path (not under /root/reference, versions unpinned there,
 ``setup.py:30-45``): ``scipy.linalg.lu_factor/lu_solve`` (LAPACK getrf/getrs); this oracle

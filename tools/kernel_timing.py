@@ -50,14 +50,11 @@ def main():
 
     sites, elements, dr = synthetic.ring_disk_mesh(args.K)
     n = len(sites)
-    import importlib.util
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("orc", os.path.join(here, "oracle", "superscreen_oracle.py"))
-    orc = importlib.util.module_from_spec(spec)
-    sys.modules["orc"] = orc  # dataclasses need the module registered
-    spec.loader.exec_module(orc)
-    w = orc.vertex_areas(sites, elements)
-    C = orc.C_vector(sites)
+    from superscreen_amd import fem
+    from superscreen_amd.mesh import MeshOperators
+
+    w = fem.vertex_areas(sites, elements)
+    C = MeshOperators.C_vector(sites)
     xy_d, w_d, C_d = (torch.from_numpy(a).cuda() for a in (sites, w, C))
     print(f"mesh K={args.K} n={n}")
 
@@ -100,14 +97,14 @@ def main():
             # representative matrix: -A of a disk film on the K-ring mesh (diagonally dominant)
             s2, e2, dr2 = synthetic.ring_disk_mesh(Klu)
             Kf = synthetic.film_rings(Klu)
-            w2 = orc.vertex_areas(s2, e2)
-            lap = orc.laplace_operator(s2, e2, w2).tocsr()
+            w2 = fem.vertex_areas(s2, e2)
+            lap = fem.laplace_operator(s2, e2, w2).tocsr()
             lap.sort_indices()
             inside = Path(synthetic.circle_points((Kf + 0.5) * dr2), closed=True).contains_points(s2)
-            ix = np.setdiff1d(np.where(inside)[0], orc.find_boundary_indices(e2)).astype(np.int64)
+            ix = np.setdiff1d(np.where(inside)[0], fem.boundary_indices(e2)).astype(np.int64)
             nlu = len(ix)
             put = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-            xy2, wd2, C2 = put(s2), put(w2), put(orc.C_vector(s2))
+            xy2, wd2, C2 = put(s2), put(w2), put(MeshOperators.C_vector(s2))
             _, qd2 = K.q_assemble(xy2, wd2, C2, args.dtype, want_Q=False)
             lap_d = (put(lap.indptr.astype(np.int64)), put(lap.indices.astype(np.int64)), put(lap.data))
             Lam = torch.full((len(s2),), 0.1, dtype=torch.float64, device="cuda")
