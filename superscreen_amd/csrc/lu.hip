@@ -131,7 +131,7 @@ struct PanelArgs {
     unsigned long long *hdr;      // [2][G][2]: {absval bits, pos << 32 | orig}
     T *rows;                      // [2][G][PW]
     unsigned int *timeout;        // set when a bounded spin gives up
-    // speculation protocol (lu_panel_spec_kernel runs first):
+    // speculation protocol (lu_panel_spec3_kernel, lu_spec3.hpp, runs first):
     const T *backup;              // [m][PW] original sub-panel, or nullptr: read A
     const int *spec_flag;         // != 0: speculation failed, this kernel must redo the sub-panel
     const int *zero_col;          // 1-based column of a zero pivot seen by the speculative pass

@@ -1,186 +1,9 @@
-// Speculative sub-panel factorization, second generation (included by lu.hip).
-//
-// Same contract as described in lu.hip ("Speculative sub-panel factorization"): the pivots of
-// the 64-column sub-panel are assumed to lie in its 64 x 64 diagonal block; the assumption is
-// verified exactly while the rows below are forward-substituted, and a failed check makes the
-// cooperative kernel redo the sub-panel from the backup copy.  This version removes the long
-// dependent LDS chains of the first one:
-//   * the diagonal block is factored in REGISTERS: thread (r, q) holds the 16 entries
-//     c = q + 4 i of row r; per column one LDS hop publishes the column, every wave finds the
-//     pivot redundantly (no broadcast step), a second hop exchanges the two rows and hands the
-//     pivot row to everybody; two barriers per column, all LDS traffic in independent batches;
-//   * every row below is shared by two adjacent lanes that split the k-sum of the forward
-//     substitution (even / odd k) and combine with one xor-shuffle; the k loop is unrolled
-//     with independent accumulators;
-//   * workgroup 0 additionally inverts the unit-lower diagonal block (inverse of L11) for the
-//     block triangular solve that follows.
+// Helpers of the LU route (included by lu.hip): inverse of the unit-lower 64 x 64 diagonal
+// blocks of a factored panel and the block triangular solve that uses them.  (The speculative
+// sub-panel kernel itself lives in lu_spec3.hpp.)
 #pragma once
 
 namespace ssa {
-
-constexpr int kSpec2Rows = 128;                 // rows per workgroup (two lanes per row)
-constexpr int kSpec2Stride = kSpec2Rows + 1;    // slab [PW][stride], column-major
-
-template <typename T>
-struct Spec2Args {
-    T *A;
-    int64_t lda;
-    int64_t j0;
-    int m;
-    int jb;
-    int32_t *ipiv;
-    T *backup;            // [m][PW]
-    int *spec_flag;
-    int *zero_col;
-    unsigned int *cnt;    // counters of the cooperative kernel, reset here
-};
-
-template <typename T>
-__device__ __forceinline__ T select16(const T (&v)[16], int idx) {
-    T out = v[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) out = (idx == i) ? v[i] : out;
-    return out;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void lu_panel_spec2_kernel(Spec2Args<T> a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TS = PW + 1;
-    T *slab = reinterpret_cast<T *>(smem_raw);       // [PW][kSpec2Stride]
-    T *top = slab + PW * kSpec2Stride;               // [PW][TS] diagonal block, row-major
-    T *colJ = top + PW * TS;                         // [2][PW]
-    T *rowA = colJ + 2 * PW;                         // [PW] old row J
-    T *rowB = rowA + PW;                             // [PW] pivot row
-    int *lp = reinterpret_cast<int *>(rowB + PW);    // [PW]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
-    const int row_base = g * kSpec2Rows;
-    const int myrows = min(kSpec2Rows, a.m - row_base);
-    const int jb = a.jb;
-    const int nt = min(PW, a.m);
-    T *Ap = a.A + a.j0 * a.lda + a.j0;
-
-    if (g == 0) {
-        for (int i = tid; i < kShards * 32 + 32; i += 256) a.cnt[i] = 0u;
-    }
-    for (int r = wave; r < myrows; r += 4) {
-        if (lane < jb) {
-            const T v = Ap[static_cast<int64_t>(row_base + r) * a.lda + lane];
-            slab[lane * kSpec2Stride + r] = v;
-            a.backup[static_cast<int64_t>(row_base + r) * PW + lane] = v;
-        }
-    }
-    for (int r = wave; r < PW; r += 4) {
-        top[r * TS + lane] = (r < nt && lane < jb) ? Ap[static_cast<int64_t>(r) * a.lda + lane] : T(0);
-    }
-    __syncthreads();
-
-    // ---- diagonal block in registers -------------------------------------------------------
-    const int r = tid >> 2, q = tid & 3;
-    T v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = top[r * TS + q + 4 * i];
-    int zero_col = 0;
-    const int nsteps = min(jb, nt);
-    for (int J = 0; J < nsteps; ++J) {
-        T *cj = colJ + (J & 1) * PW;
-        if (q == (J & 3)) cj[r] = select16(v, J >> 2);
-        __syncthreads();
-        double av = (lane >= J && lane < nt) ? fabs(static_cast<double>(cj[lane])) : -1.0;
-        int p = lane;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(av, off, 64);
-            const int oi = __shfl_xor(p, off, 64);
-            if (ov > av || (ov == av && oi < p)) { av = ov; p = oi; }
-        }
-        const T pv = cj[p];
-        if (r == p) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) rowB[q + 4 * i] = v[i];
-        }
-        if (r == J && p != J) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) rowA[q + 4 * i] = v[i];
-        }
-        __syncthreads();
-        if (p != J) {
-            if (r == J) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = rowB[q + 4 * i];
-            } else if (r == p) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = rowA[q + 4 * i];
-            }
-        }
-        if (pv == T(0)) {
-            if (zero_col == 0) zero_col = J + 1;
-        } else if (r > J && r < nt) {
-            const T aJ = (r == p) ? cj[J] : cj[r];  // column-J entry of the row now at position r
-            const T l = aJ / pv;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = q + 4 * i;
-                const T pr = rowB[c];
-                if (c > J) v[i] -= l * pr;
-                else if (c == J) v[i] = l;
-            }
-        }
-        if (tid == 0) lp[J] = p;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) top[r * TS + q + 4 * i] = v[i];
-    __syncthreads();
-
-    // ---- rows below the block: forward substitution + exactness check ------------------------
-    const int lr = wave * 32 + (lane >> 1);   // local row, two lanes per row
-    const int half = lane & 1;
-    const int prow = row_base + lr;
-    const bool active = (lr < myrows && prow >= nt);
-    bool viol = false;
-    for (int J = 0; J < jb; ++J) {
-        T p0 = T(0), p1 = T(0);
-        if (active) {
-            int k = half;
-            for (; k + 2 < J; k += 4) {
-                p0 += slab[k * kSpec2Stride + lr] * top[k * TS + J];
-                p1 += slab[(k + 2) * kSpec2Stride + lr] * top[(k + 2) * TS + J];
-            }
-            for (; k < J; k += 2) p0 += slab[k * kSpec2Stride + lr] * top[k * TS + J];
-        }
-        T part = p0 + p1;
-        part += __shfl_xor(part, 1, 64);
-        if (active) {
-            const T s = slab[J * kSpec2Stride + lr] - part;
-            const T pv = top[J * TS + J];
-            viol = viol || (fabs(static_cast<double>(s)) > fabs(static_cast<double>(pv)));
-            if (half == 0) slab[J * kSpec2Stride + lr] = (pv != T(0)) ? s / pv : s;
-        }
-    }
-    if (__any(viol) && lane == 0) atomicOr(a.spec_flag, 1);
-    __syncthreads();
-
-    // ---- write back -------------------------------------------------------------------------
-    for (int rr = wave; rr < myrows; rr += 4) {
-        const int pr = row_base + rr;
-        if (lane < jb) {
-            const T val = (pr < nt) ? top[pr * TS + lane] : slab[lane * kSpec2Stride + rr];
-            Ap[static_cast<int64_t>(pr) * a.lda + lane] = val;
-        }
-    }
-    if (g == 0) {
-        if (tid < jb) a.ipiv[a.j0 + tid] = static_cast<int32_t>(a.j0 + (tid < nsteps ? lp[tid] : tid));
-        if (tid == 0) *a.zero_col = zero_col;
-    }
-}
-
-template <typename T>
-constexpr size_t spec2_smem_bytes() {
-    return sizeof(T) * (PW * kSpec2Stride + PW * (PW + 1) + 4 * PW) + sizeof(int) * PW + 64;
-}
 
 // ---------------------------------------------------------------------------------------
 // Inverse of the unit-lower 64 x 64 diagonal block(s) of a factored panel: thread c owns
