@@ -174,9 +174,13 @@ struct CholLane {
 constexpr int kMaxLanes = 16;
 
 inline int get_lanes(int count, CholLane **out) {
-    static CholLane lanes[kMaxLanes];
+    constexpr int kMaxDevices = 32;
+    static CholLane per_device[kMaxDevices][kMaxLanes];  // streams belong to the device they were made on
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return SSA_ERR_HIP;
+    CholLane *lanes = per_device[dev];
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
     for (int i = 0; i < count; ++i) {
@@ -350,6 +354,9 @@ struct FinishPlan {
 template <typename T>
 int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
+    // the lanes (side streams + events) are shared per process: one schedule is enqueued at a time
+    static std::mutex enqueue_mutex;
+    std::lock_guard<std::mutex> enqueue_lock(enqueue_mutex);
     CholLane *lanes = nullptr;
     int rc = get_lanes(count, &lanes);
     if (rc != SSA_OK) return rc;
