@@ -305,7 +305,9 @@ __device__ __forceinline__ void gemm_tile_edge(int64_t M, int64_t N, int64_t K, 
 
 // Element strides of a two-level batch: matrix (y, z) of the grid starts at X + y * x1 + z * x2.
 // tri = 1: B is lower triangular (K == N): rows k < n0 of B do not reach the tile's columns;
-// tri = 2: A is lower triangular (M == K): columns k >= m0 + BM of A are zero for the tile's rows.
+// tri = 2: A is lower triangular (M == K): columns k >= m0 + BM of A are zero for the tile's rows;
+// tri = 3: B is upper triangular (K == N): rows k >= n0 + BN of B are zero for the tile's columns;
+// tri = 4: A is upper triangular (M == K): columns k < m0 of A are zero for the tile's rows.
 // The K range of every tile shrinks accordingly (half the flops of a triangular product).
 struct BatchStrides {
     int64_t a1, a2, b1, b2, c1, c2;
@@ -332,6 +334,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
         K -= kb;
     } else if (bs.tri == 2) {
         K = (m0 + BM < K) ? m0 + BM : K;
+    } else if (bs.tri == 3) {
+        K = (n0 + BN < K) ? n0 + BN : K;
+    } else if (bs.tri == 4) {
+        const int64_t kb = (m0 < K) ? m0 : K;
+        A += kb;
+        B += kb * ldb;
+        K -= kb;
     }
     const bool full = ALIGNED && sizeof(T) == 8 && (m0 + BM <= M) && (n0 + BN <= N) &&
                       (K % KC == 0) && (K > 0) && alpha != T(0);

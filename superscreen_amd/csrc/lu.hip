@@ -55,6 +55,35 @@ int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double 
              double alpha, double beta, hipStream_t st);
 int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
              double alpha, double beta, hipStream_t st);
+int trmv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y, double alpha,
+             double beta, int tri, hipStream_t st);
+int trmv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
+             double beta, int tri, hipStream_t st);
+int gemm_batched_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int batch1,
+                     int batch2, const int64_t *strides, int tri, hipStream_t st);
+int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                     const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int batch1,
+                     int batch2, const int64_t *strides, int tri, hipStream_t st);
+inline int trmv_x(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y, double alpha,
+                  double beta, int tri, hipStream_t st) {
+    return trmv_f64(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+inline int trmv_x(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
+                  double beta, int tri, hipStream_t st) {
+    return trmv_f32(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+inline int gemm_batched_x(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                          const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int b1, int b2,
+                          const int64_t *strides, int tri, hipStream_t st) {
+    return gemm_batched_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, st);
+}
+inline int gemm_batched_x(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
+                          const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int b1, int b2,
+                          const int64_t *strides, int tri, hipStream_t st) {
+    return gemm_batched_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, st);
+}
+
 template <typename T>
 int gemv_t(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha,
            double beta, hipStream_t st);
@@ -465,6 +494,111 @@ struct PanelScratchBytes {
     static constexpr size_t rows() { return 2 * static_cast<size_t>(kMaxPanelGroups) * PW * sizeof(T); }
 };
 
+// ---- solve-phase data: inverses of the LSB x LSB diagonal blocks of L (unit lower) and of U ----
+// Same construction as the Cholesky route (chol.hip): 256 x 256 leaves by the LDS substitution kernel,
+// then one recursion level of all full blocks = two batched GEMMs per factor with triangular K ranges
+//     L:  tmp = L21 inv11,   inv21 = -inv22 tmp        U:  tmp = U12 inv22,   inv12 = -inv11 tmp
+// so that ssa_lu_solve is a chain of 2 row-major GEMVs per block and factor (HBM bound).
+constexpr int64_t LSB = 4096;
+
+struct LuAux {
+    int64_t nblk, nfull, invL, invU, tmp, total;  // offsets in elements
+};
+inline LuAux lu_aux_layout(int64_t n) {
+    LuAux a;
+    a.nblk = ceil_div(n, LSB);
+    a.nfull = n / LSB;
+    a.invL = 0;
+    a.invU = a.nblk * LSB * LSB;
+    a.tmp = 2 * a.nblk * LSB * LSB;
+    a.total = a.tmp + a.nblk * (LSB * LSB / 4);
+    return a;
+}
+
+// inverse of the diagonal block [r0, r0 + sz) of L (UPPER = false) or U (true) from its inverted
+// 256-leaves, recursively (the last, partial LSB block; any sz)
+template <typename T, bool UPPER>
+int lu_block_inverse(const T *A, int64_t lda, int64_t r0, int64_t sz, T *inv, int64_t ldi, T *tmp, hipStream_t st) {
+    if (sz <= NB) return SSA_OK;
+    int64_t h = NB;
+    while (2 * h < sz) h *= 2;
+    const int64_t r = sz - h;
+    int rc = lu_block_inverse<T, UPPER>(A, lda, r0, h, inv, ldi, tmp, st);
+    if (rc != SSA_OK) return rc;
+    rc = lu_block_inverse<T, UPPER>(A, lda, r0 + h, r, inv + h * ldi + h, ldi, tmp, st);
+    if (rc != SSA_OK) return rc;
+    if (!UPPER) {
+        rc = gemm_t<T>(r, h, h, 1.0, A + (r0 + h) * lda + r0, lda, inv, ldi, 0.0, tmp, h, st);
+        if (rc != SSA_OK) return rc;
+        return gemm_t<T>(r, h, r, -1.0, inv + h * ldi + h, ldi, tmp, h, 0.0, inv + h * ldi, ldi, st);
+    }
+    rc = gemm_t<T>(h, r, r, 1.0, A + r0 * lda + r0 + h, lda, inv + h * ldi + h, ldi, 0.0, tmp, r, st);
+    if (rc != SSA_OK) return rc;
+    return gemm_t<T>(h, r, h, -1.0, inv, ldi, tmp, r, 0.0, inv + h, ldi, st);
+}
+
+template <typename T>
+int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_t st) {
+    const LuAux al = lu_aux_layout(n);
+    T *invL = aux + al.invL, *invU = aux + al.invU, *tmp = aux + al.tmp;
+    if (hipMemsetAsync(aux, 0, static_cast<size_t>(al.tmp) * sizeof(T), st) != hipSuccess) return SSA_ERR_HIP;
+    int rc;
+    // leaves, batched by their position s inside the LSB block
+    for (int64_t s = 0; s < LSB / NB; ++s) {
+        const int64_t first = s * NB;
+        if (first + NB > n) break;
+        const int count = static_cast<int>((n - first - NB) / LSB + 1);
+        rc = launch_trsm<T, false, true>(A + first * (lda + 1), lda, LSB * (lda + 1), invL + first * (LSB + 1), LSB,
+                                         LSB * LSB, NB, NB, count, st);
+        if (rc != SSA_OK) return rc;
+        rc = launch_trsm<T, true, true>(A + first * (lda + 1), lda, LSB * (lda + 1), invU + first * (LSB + 1), LSB,
+                                        LSB * LSB, NB, NB, count, st);
+        if (rc != SSA_OK) return rc;
+    }
+    if (n % NB != 0) {  // the last, partial leaf
+        const int64_t r0 = n / NB * NB, Jb = r0 / LSB, off = r0 - Jb * LSB;
+        const int kb = static_cast<int>(n - r0);
+        rc = launch_trsm<T, false, true>(A + r0 * (lda + 1), lda, 0, invL + Jb * LSB * LSB + off * (LSB + 1), LSB, 0,
+                                         kb, kb, 1, st);
+        if (rc != SSA_OK) return rc;
+        rc = launch_trsm<T, true, true>(A + r0 * (lda + 1), lda, 0, invU + Jb * LSB * LSB + off * (LSB + 1), LSB, 0,
+                                        kb, kb, 1, st);
+        if (rc != SSA_OK) return rc;
+    }
+    if (al.nfull > 0) {
+        const int nb = static_cast<int>(al.nfull);
+        for (int64_t h = NB; h < LSB; h *= 2) {
+            const int ppb = static_cast<int>(LSB / (2 * h));
+            const int64_t pair_l = 2 * h * (lda + 1), blk_l = LSB * (lda + 1);
+            const int64_t pair_i = 2 * h * (LSB + 1), blk_i = LSB * LSB;
+            const int64_t pair_t = h * h, blk_t = LSB * LSB / 4;
+            const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+            const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
+            // L: tmp = L21 inv11 ; inv21 = -inv22 tmp
+            rc = gemm_batched_x(h, h, h, 1.0, A + h * lda, lda, invL, LSB, 0.0, tmp, h, ppb, nb, s1, 1, st);
+            if (rc != SSA_OK) return rc;
+            rc = gemm_batched_x(h, h, h, -1.0, invL + h * (LSB + 1), LSB, tmp, h, 0.0, invL + h * LSB, LSB, ppb, nb, s2,
+                                2, st);
+            if (rc != SSA_OK) return rc;
+            // U: tmp = U12 inv22 ; inv12 = -inv11 tmp
+            const int64_t s3[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+            rc = gemm_batched_x(h, h, h, 1.0, A + h, lda, invU + h * (LSB + 1), LSB, 0.0, tmp, h, ppb, nb, s3, 3, st);
+            if (rc != SSA_OK) return rc;
+            rc = gemm_batched_x(h, h, h, -1.0, invU, LSB, tmp, h, 0.0, invU + h, LSB, ppb, nb, s2, 4, st);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    if (n % LSB != 0) {
+        const int64_t r0 = al.nfull * LSB;
+        T *t2 = tmp + al.nfull * (LSB * LSB / 4);
+        rc = lu_block_inverse<T, false>(A, lda, r0, n - r0, invL + al.nfull * LSB * LSB, LSB, t2, st);
+        if (rc != SSA_OK) return rc;
+        rc = lu_block_inverse<T, true>(A, lda, r0, n - r0, invU + al.nfull * LSB * LSB, LSB, t2, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
 template <typename T>
 int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, void *workspace,
           hipStream_t st) {
@@ -580,83 +714,49 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
             if (rc != SSA_OK) return rc;
         }
     }
-    // aux = inverses of the diagonal NB x NB blocks of L (unit lower) and U, for ssa_lu_solve
-    const int64_t nblk = ceil_div(n, NB);
-    const int64_t full = n / NB;  // blocks with kb == NB can be batched
-    T *invL = aux, *invU = aux + nblk * NB * NB;
-    if (full > 0) {
-        rc = launch_trsm<T, false, true>(A, lda, NB * (lda + 1), invL, NB, NB * NB, NB, NB,
-                                         static_cast<int>(full), st);
-        if (rc != SSA_OK) return rc;
-        rc = launch_trsm<T, true, true>(A, lda, NB * (lda + 1), invU, NB, NB * NB, NB, NB,
-                                        static_cast<int>(full), st);
-        if (rc != SSA_OK) return rc;
-    }
-    if (full < nblk) {
-        const int kb = static_cast<int>(n - full * NB);
-        const T *D = A + full * NB * (lda + 1);
-        rc = launch_trsm<T, false, true>(D, lda, 0, invL + full * NB * NB, NB, 0, kb, kb, 1, st);
-        if (rc != SSA_OK) return rc;
-        rc = launch_trsm<T, true, true>(D, lda, 0, invU + full * NB * NB, NB, 0, kb, kb, 1, st);
-        if (rc != SSA_OK) return rc;
-    }
-    return SSA_OK;
+    return lu_build_solve_blocks<T>(A, n, lda, aux, st);
 }
 
-// L U X = B (B already row-permuted).  Block forward / backward substitution where every
-// step is a GEMM: X_k = inv(L_kk) B_k ; B_{>k} -= L_{>k,k} X_k, then the mirror image with U.
-// X (workspace, n x nrhs) and B ping-pong so that no GEMM output aliases its input.
+// L U X = B (B already row-permuted).  Block forward / backward substitution over LSB-row blocks
+// with pre-inverted diagonal blocks: X_k = inv(L_kk) B_k ; B_{>k} -= L_{>k,k} X_k, then the mirror
+// image with U.  Single right-hand side: two row-major GEMVs per block and factor; several: the same
+// recurrence on the MFMA GEMM.  X (workspace, n x nrhs) and B ping-pong.
 template <typename T>
 int getrs(const T *LU, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb,
           T *X, hipStream_t st) {
-    const int64_t nblk = ceil_div(n, NB);
-    const T *invL = aux, *invU = aux + nblk * NB * NB;
+    const LuAux al = lu_aux_layout(n);
+    const T *invL = aux + al.invL, *invU = aux + al.invU;
     const int64_t ldx = nrhs;
+    const bool vec = (nrhs == 1 && ldb == 1);
     int rc;
-    if (nrhs == 1 && ldb == 1) {
-        // single right-hand side: every block step is a pair of HBM-bound GEMVs
-        for (int64_t k = 0; k < nblk; ++k) {
-            const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
-            rc = gemv_t<T>(invL + k * NB * NB, kb, kb, NB, B + r0, X + r0, 1.0, 0.0, st);
-            if (rc != SSA_OK) return rc;
-            const int64_t below = n - r0 - kb;
-            if (below > 0) {
-                rc = gemv_t<T>(LU + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
-                if (rc != SSA_OK) return rc;
-            }
-        }
-        for (int64_t k = nblk - 1; k >= 0; --k) {
-            const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
-            rc = gemv_t<T>(invU + k * NB * NB, kb, kb, NB, X + r0, B + r0, 1.0, 0.0, st);
-            if (rc != SSA_OK) return rc;
-            if (r0 > 0) {
-                rc = gemv_t<T>(LU + r0, r0, kb, lda, B + r0, X, -1.0, 1.0, st);
-                if (rc != SSA_OK) return rc;
-            }
-        }
-        return SSA_OK;
-    }
-    for (int64_t k = 0; k < nblk; ++k) {
-        const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
-        rc = gemm_t<T>(kb, nrhs, kb, 1.0, invL + k * NB * NB, NB, B + r0 * ldb, ldb, 0.0,
-                       X + r0 * ldx, ldx, st);
-        if (rc != SSA_OK) return rc;
+    for (int64_t k = 0; k < al.nblk; ++k) {
+        const int64_t r0 = k * LSB, kb = (n - r0 < LSB) ? n - r0 : LSB;
         const int64_t below = n - r0 - kb;
-        if (below > 0) {
-            rc = gemm_t<T>(below, nrhs, kb, -1.0, LU + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx,
-                           1.0, B + (r0 + kb) * ldb, ldb, st);
-            if (rc != SSA_OK) return rc;
+        const T *inv = invL + k * LSB * LSB;
+        if (vec) {
+            rc = trmv_x(inv, kb, kb, LSB, B + r0, X + r0, 1.0, 0.0, 1, st);
+            if (rc == SSA_OK && below > 0)
+                rc = gemv_t<T>(LU + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
+        } else {
+            rc = gemm_t<T>(kb, nrhs, kb, 1.0, inv, LSB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, st);
+            if (rc == SSA_OK && below > 0)
+                rc = gemm_t<T>(below, nrhs, kb, -1.0, LU + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx, 1.0,
+                               B + (r0 + kb) * ldb, ldb, st);
         }
-    }
-    for (int64_t k = nblk - 1; k >= 0; --k) {
-        const int64_t r0 = k * NB, kb = (n - r0 < NB) ? n - r0 : NB;
-        rc = gemm_t<T>(kb, nrhs, kb, 1.0, invU + k * NB * NB, NB, X + r0 * ldx, ldx, 0.0,
-                       B + r0 * ldb, ldb, st);
         if (rc != SSA_OK) return rc;
-        if (r0 > 0) {
-            rc = gemm_t<T>(r0, nrhs, kb, -1.0, LU + r0, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
-            if (rc != SSA_OK) return rc;
+    }
+    for (int64_t k = al.nblk - 1; k >= 0; --k) {
+        const int64_t r0 = k * LSB, kb = (n - r0 < LSB) ? n - r0 : LSB;
+        const T *inv = invU + k * LSB * LSB;
+        if (vec) {
+            rc = trmv_x(inv, kb, kb, LSB, X + r0, B + r0, 1.0, 0.0, 2, st);
+            if (rc == SSA_OK && r0 > 0) rc = gemv_t<T>(LU + r0, r0, kb, lda, B + r0, X, -1.0, 1.0, st);
+        } else {
+            rc = gemm_t<T>(kb, nrhs, kb, 1.0, inv, LSB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
+            if (rc == SSA_OK && r0 > 0)
+                rc = gemm_t<T>(r0, nrhs, kb, -1.0, LU + r0, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
         }
+        if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
 }
@@ -708,7 +808,7 @@ extern "C" size_t ssa_lu_factor_workspace_bytes(int64_t n, int dtype) {
 
 extern "C" size_t ssa_lu_aux_bytes(int64_t n, int dtype) {
     const size_t es = dtype == SSA_F64 ? 8 : 4;
-    return 2 * static_cast<size_t>(ceil_div(n, NB)) * NB * NB * es;
+    return static_cast<size_t>(lu_aux_layout(n).total) * es;
 }
 
 extern "C" int ssa_lu_factor(void *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info,

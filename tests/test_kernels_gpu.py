@@ -409,3 +409,24 @@ def test_sheet_field_ragged_and_large(K):
         assert relerr(got, ref) < 1e-12
         got2 = K.sheet_field(dev(src), dev(a), dev(2.0 * J), -0.1, dev(ev), MU_0 / (4 * np.pi), True).cpu().numpy()
         assert relerr(got2, 2.0 * got) < 1e-15
+
+
+@pytest.mark.parametrize("n", [4096, 4500, 9011])
+def test_lu_block_solves(K, n):
+    """Orders beyond one 4096-row solve block: level-batched inverses of the diagonal blocks of L
+    and U (triangular K ranges), partial last block, GEMV chain (single rhs) and GEMM chain."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)) / np.sqrt(n) + np.diag(2.0 + rng.random(n))   # well conditioned, no pivoting
+    ld = K.padded_ld(n, "float64")
+    Ad = torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+    Ad[:, :n] = dev(A)
+    f = K.lu_factor(Ad, n)
+    assert f.info == 0
+    lu_ref, piv_ref = la.lu_factor(A)
+    assert np.array_equal(f.ipiv.cpu().numpy(), piv_ref)
+    assert relerr(f.lu.cpu().numpy()[:, :n], lu_ref) < 1e-11
+    for nrhs in (1, 2):
+        b = rng.standard_normal((n, nrhs))
+        x = K.lu_solve(f, dev(b[:, 0].copy()) if nrhs == 1 else dev(b)).cpu().numpy().reshape(n, nrhs)
+        assert relerr(A @ x, b) < 1e-11
+        assert relerr(x, la.lu_solve((lu_ref, piv_ref), b)) < 1e-11
