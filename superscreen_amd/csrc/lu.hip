@@ -164,15 +164,26 @@ struct PanelArgs {
     const T *backup;              // [m][PW] original sub-panel, or nullptr: read A
     const int *spec_flag;         // != 0: speculation failed, this kernel must redo the sub-panel
     const int *zero_col;          // 1-based column of a zero pivot seen by the speculative pass
+    const T *top;                 // [64][64] factored diagonal block parked by the speculative pass
 };
 
 template <typename T>
 __global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(PanelArgs<T> a) {
     if (a.spec_flag != nullptr && *a.spec_flag == 0) {
         // The speculative pass was exact (no row below the diagonal block ever beat its pivot):
-        // nothing to redo.  Only the LAPACK info of an exactly-zero pivot column is finalised.
-        if (blockIdx.x == 0 && threadIdx.x == 0 && *a.zero_col != 0 && *a.info == 0)
-            *a.info = static_cast<int32_t>(a.j0 + *a.zero_col);
+        // nothing to redo.  The factored diagonal block moves from its parking place into A (the
+        // speculative kernel must not overwrite what its late workgroups still have to read), and
+        // the LAPACK info of an exactly-zero pivot column is finalised.
+        if (blockIdx.x == 0) {
+            const int nt = (a.m < PW) ? a.m : PW;
+            T *Ap = a.A + a.j0 * a.lda + a.j0;
+            for (int e = threadIdx.x; e < nt * PW; e += kPanelThreads) {
+                const int r = e / PW, c = e % PW;
+                if (c < a.jb) Ap[static_cast<int64_t>(r) * a.lda + c] = a.top[r * 64 + c];
+            }
+            if (threadIdx.x == 0 && *a.zero_col != 0 && *a.info == 0)
+                *a.info = static_cast<int32_t>(a.j0 + *a.zero_col);
+        }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -622,6 +633,7 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
     int *flags = cv.take<int>(2 * nsub);                     // [nsub] spec flags, [nsub] zero cols
     T *backup = cv.take<T>(static_cast<size_t>(n) * PW);
     T *dinv = cv.take<T>(static_cast<size_t>(NB / PW) * 64 * 64);  // inv(L11) of the sub-panels
+    T *top = cv.take<T>(64 * 64);                                   // factored diagonal block in transit
 
     static bool attr_set = false;
     if (!attr_set) {
@@ -652,7 +664,7 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
             Spec3Args<T> sa;
             sa.A = A; sa.lda = lda; sa.j0 = j0; sa.m = static_cast<int>(m); sa.jb = static_cast<int>(jb);
             sa.ipiv = ipiv; sa.backup = backup; sa.spec_flag = flags + sub; sa.zero_col = flags + nsub + sub;
-            sa.cnt = cnt; sa.dinv = dinv + sidx * 64 * 64;
+            sa.cnt = cnt; sa.dinv = dinv + sidx * 64 * 64; sa.top = top;
             hipLaunchKernelGGL((lu_panel_spec3_kernel<T>), dim3(ceil_div(m, kSpec3Rows) + 1), dim3(256),
                                spec3_smem_bytes<T>(), st, sa);
             SSA_RETURN_IF_LAUNCH_FAILED();
@@ -663,7 +675,7 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
             pa.A = A; pa.lda = lda; pa.j0 = j0; pa.m = static_cast<int>(m);
             pa.jb = static_cast<int>(jb); pa.rpw = rpw; pa.ipiv = ipiv; pa.info = info;
             pa.cnt = cnt; pa.hdr = hdr; pa.rows = rows; pa.timeout = timeout;
-            pa.backup = backup; pa.spec_flag = flags + sub; pa.zero_col = flags + nsub + sub;
+            pa.backup = backup; pa.spec_flag = flags + sub; pa.zero_col = flags + nsub + sub; pa.top = top;
             hipLaunchKernelGGL((lu_panel_kernel<T>), dim3(G), dim3(kPanelThreads),
                                panel_smem_bytes<T>(), st, pa);
             SSA_RETURN_IF_LAUNCH_FAILED();
@@ -803,7 +815,7 @@ extern "C" size_t ssa_lu_factor_workspace_bytes(int64_t n, int dtype) {
     const size_t rows = dtype == SSA_F64 ? PanelScratchBytes::rows<double>() : PanelScratchBytes::rows<float>();
     const size_t nsub = static_cast<size_t>(ceil_div(n, PW) + ceil_div(n, NB));
     return PanelScratchBytes::cnt + PanelScratchBytes::hdr + rows + 2 * nsub * sizeof(int) +
-           static_cast<size_t>(n) * PW * es + (NB / PW) * 64 * 64 * es + 10 * 256;
+           static_cast<size_t>(n) * PW * es + (NB / PW + 1) * 64 * 64 * es + 12 * 256;
 }
 
 extern "C" size_t ssa_lu_aux_bytes(int64_t n, int dtype) {

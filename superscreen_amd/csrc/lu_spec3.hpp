@@ -37,6 +37,7 @@ struct Spec3Args {
     int *zero_col;
     unsigned int *cnt;    // counters of the cooperative kernel, reset here
     T *dinv;              // [64][64] inverse of the unit-lower diagonal block (written by WG 0)
+    T *top;               // [64][64] factored diagonal block L11\U11 (written by WG 0, see below)
 };
 
 // broadcast of lane (4 * (lane / 4) + S) inside every quad, for 64-bit and 32-bit payloads
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(256) void lu_panel_spec3_kernel(Spec3Args<T> a) {
     viol = viol || (active && v2);
     if (__any(viol) && lane == 0) atomicOr(a.spec_flag, 1);
 
-    // ---- write back (top rows of workgroup 0 come from the factored block image) ----------------
+    // ---- write back -------------------------------------------------------------------------------
+    // The factored diagonal block does NOT go to A here: every workgroup reads the ORIGINAL block
+    // from A when it starts, and nothing guarantees that all of them have started before workgroup
+    // 0 gets here (a busy GPU delays workgroups).  It is parked in `top`; the next kernel in the
+    // stream (lu_panel_kernel's early-exit path) copies it into A.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -240,8 +245,8 @@ __global__ __launch_bounds__(256) void lu_panel_spec3_kernel(Spec3Args<T> a) {
             const int rr = 2 * it + (lane >> 5), c = 32 * h + (lane & 31);
             const int pr = wrow0 + rr;
             if (pr < a.m && c < jb) {
-                const T val = (pr < nt) ? U[pr * TS + c] : st[rr * SS + (lane & 31)];
-                Ap[static_cast<int64_t>(pr) * a.lda + c] = val;
+                if (pr < nt) a.top[pr * 64 + c] = U[pr * TS + c];
+                else Ap[static_cast<int64_t>(pr) * a.lda + c] = st[rr * SS + (lane & 31)];
             }
         }
     }
