@@ -29,7 +29,7 @@ The JSON line also carries
                    both measured live with HIP events on the kernel's stream inside the library
                    (ssa_profile_*) over the timed region; `traffic` = memory-side L2 bytes per
                    launch from the rocprofv3 PMC passes of this same command
-                   (profiles/r01_v3_syrk_pmc.json, corrections in tools/summarize_pmc.py), next to
+                   (profiles/r01_v4_syrk_pmc.json, corrections in tools/summarize_pmc.py), next to
                    the algorithmic bytes per launch (C tiles read + written, panel read once)
   cpu_baseline  -- the CPU oracle (numpy/scipy + OpenMP C ports of the numba kernels) timed on
                    this box's host cores on a bounded sample, rank 0 at N = 1 only.
@@ -71,7 +71,7 @@ def syrk_algorithmic_bytes(unknowns, elem=8):
 
 def pmc_traffic():
     """Memory-side bytes per SYRK launch from the committed rocprofv3 PMC summary (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_syrk_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_v4_syrk_pmc.json")
     try:
         with open(path) as f:
             return float(json.load(f)["traffic_bytes_per_launch"])
@@ -313,7 +313,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": pmc_traffic() if "gemm_op_kernel" in dom_label else None,
-                "traffic_source": "profiles/r01_v3_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                "traffic_source": "profiles/r01_v4_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   "this command; bytes per launch, fetch x2 per MI355X_MICROARCH.md)",
                 "algorithmic_bytes_per_launch": syrk_algorithmic_bytes(
                     [int(len(s.indices)) for s in model.film_systems.values()])[0],
