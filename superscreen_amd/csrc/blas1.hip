@@ -115,7 +115,9 @@ int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *
 template <typename T>
 int launch_trmv(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha, double beta,
                 int tri, hipStream_t st) {
-    constexpr int ROWS = 4;
+    // 2 rows per wave (not 4 as in the rectangular GEMV): an inverse block has only 4096 rows, half
+    // of them short; more, smaller waves keep enough loads in flight to approach the HBM rate
+    constexpr int ROWS = 2;
     if (nr <= 0) return SSA_OK;
     const dim3 grid(static_cast<unsigned>(ceil_div(nr, 4 * ROWS)));
     const bool aligned = (reinterpret_cast<uintptr_t>(M) % 16 == 0) && ((ldm * sizeof(T)) % 16 == 0);
