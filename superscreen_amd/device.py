@@ -18,9 +18,8 @@ implemented: it only loops ``solve(model=...)``.
 from __future__ import annotations
 
 import logging
-import numbers
 from copy import deepcopy
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
 

@@ -14,7 +14,7 @@ paths.  A "washer" is the same mesh with a concentric hole of radius ``(K_h + 0.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
