@@ -430,3 +430,64 @@ def test_lu_block_solves(K, n):
         x = K.lu_solve(f, dev(b[:, 0].copy()) if nrhs == 1 else dev(b)).cpu().numpy().reshape(n, nrhs)
         assert relerr(A @ x, b) < 1e-11
         assert relerr(x, la.lu_solve((lu_ref, piv_ref), b)) < 1e-11
+
+
+def test_c_abi_error_codes():
+    """Argument checking of the C ABI: bad pointers / sizes / dtypes give SSA_ERR_INVALID_ARGUMENT (-1),
+    short workspaces SSA_ERR_WORKSPACE_TOO_SMALL (-3); nothing is launched in those cases."""
+    import ctypes
+
+    from superscreen_amd import _hip
+
+    lib = _hip.load_library()
+    n = 64
+    xy = torch.rand(n, 2, dtype=torch.float64, device="cuda")
+    w = torch.ones(n, dtype=torch.float64, device="cuda")
+    out = torch.zeros(n, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+    INVALID, TOO_SMALL = -1, -3
+    # null pointer, non-positive size, bad dtype
+    assert lib.ssa_q_assemble(None, P(w), P(w), n, None, 0, 1, P(out), st) == INVALID
+    assert lib.ssa_q_assemble(P(xy), P(w), P(w), 0, None, 0, 1, P(out), st) == INVALID
+    assert lib.ssa_q_assemble(P(xy), P(w), P(w), n, None, 0, 7, P(out), st) == INVALID
+    assert lib.ssa_gemv(None, n, n, n, P(w), None, None, P(out), 1.0, 0.0, 1, st) == INVALID
+    assert lib.ssa_gemm(n, n, n, 1.0, P(xy), 1, P(xy), n, 0.0, P(out), n, 1, st) == INVALID      # lda < K
+    # factor / solve entry points
+    A = torch.eye(n, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
+    aux = torch.zeros(lib.ssa_lu_aux_bytes(n, 1), dtype=torch.uint8, device="cuda")
+    assert lib.ssa_lu_factor(P(A), n, n - 1, P(ipiv), P(info), P(aux), 1, P(ws), ws.numel(), st) == INVALID  # lda < n
+    assert lib.ssa_lu_factor(P(A), n, n, P(ipiv), P(info), P(aux), 1, P(ws), 16, st) == TOO_SMALL
+    assert lib.ssa_chol_factor(P(A), n, n, P(info), P(aux), 1, st) == INVALID          # lda < padded order (256)
+    assert lib.ssa_chol_factor_batch(0, None, None, None, None, None, 1, st) == INVALID
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    assert lib.ssa_chol_solve(P(A), n, n, P(aux), P(b), 1, 1, 1, P(ws), 8, st) == TOO_SMALL
+    assert lib.ssa_lu_solve(P(A), n, n, P(aux), P(b), 0, 1, 1, P(ws), ws.numel(), st) == INVALID   # nrhs = 0
+    # pairwise kernels
+    assert lib.ssa_biot_savart(P(xy), P(w), P(xy), n, 5, 3, P(xy), n, 0.5, P(out), 0, 1, P(ws), ws.numel(), st) == INVALID
+    assert lib.ssa_self_field(P(xy), P(w), P(w), P(w), n, P(out), 1.0, 1, P(ws), 8, st) == TOO_SMALL
+    assert lib.ssa_sheet_field(P(xy), P(w), P(xy), n, 0.0, None, n, 1.0, 0, P(out), P(ws), ws.numel(), st) == INVALID
+    assert lib.ssa_mfma_probe(0, P(out), None, st) == INVALID
+    assert lib.ssa_error_string(INVALID).decode() and lib.ssa_error_string(TOO_SMALL).decode().startswith("workspace")
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0   # nothing ran
+
+
+def test_tiny_and_degenerate_sizes(K):
+    """n = 1 .. 3 systems and single-point pair sums (ragged edge of every tile loop)."""
+    for n in (1, 2, 3):
+        S = np.diag(2.0 + np.arange(n)) + 0.1 * np.ones((n, n))
+        npad = K.chol_padded_n(n)
+        Sd = torch.zeros((npad, K.padded_ld(npad, "float64")), dtype=torch.float64, device="cuda")
+        Sd[:n, :n] = dev(np.tril(S))
+        f = K.chol_factor(Sd, n)
+        assert f.info == 0
+        b = np.arange(1.0, n + 1)
+        assert relerr(K.chol_solve(f, dev(b)).cpu().numpy(), np.linalg.solve(S, b)) < 1e-13
+        Ad = torch.zeros((n, K.padded_ld(n, "float64")), dtype=torch.float64, device="cuda")
+        Ad[:, :n] = dev(S)
+        lf = K.lu_factor(Ad, n)
+        assert lf.info == 0 and relerr(K.lu_solve(lf, dev(b)).cpu().numpy(), np.linalg.solve(S, b)) < 1e-13
