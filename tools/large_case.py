@@ -14,6 +14,9 @@ from superscreen_amd import kernels, synthetic  # noqa: E402
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 device = synthetic.make_stack_device(K, ("washer", "disk"), solve_dtype="float64")
 n = len(device.meshes["washer0"].sites)
+model = sc.factorize_model(device=device, current_units="uA")  # first call: HBM allocation, lazy init
+torch.cuda.synchronize()
+del model
 t0 = time.perf_counter()
 model = sc.factorize_model(device=device, current_units="uA")
 torch.cuda.synchronize()
