@@ -17,6 +17,14 @@ The reference is single-process; this decomposition is n
   single fused buffer (one latency-bound ring pass) is preferred over one collective per film.
   Per-film factor/solve work is replicated on every rank (a film's dense LU does not shard
   naturally), so the 1 -> N gain is bounded by the coupling share.
+
+* **Owner-computes film placement** (:class:`FilmPlacement`, SURVEY.md section 8e "films of one
+  device"): film f lives on rank ``f mod world``; a rank assembles, factors and solves only its own
+  films and evaluates the complete coupling field of its own TARGET films.  After every pass the
+  owners broadcast their films' small result vectors (g, J, self-field, coupling field:
+  5 n values, 1 MB for a 25k-vertex film), so every rank holds every iterate and returns the same
+  Solutions; nothing of size n^2 ever moves.  With at least as many films as ranks, factorization
+  and solve time divide by the number of ranks.
 """
 from __future__ import annotations
 
@@ -113,3 +121,50 @@ class CouplingPlan:
                                 src_begin=b, src_end=e)
 
         return run
+
+
+class FilmPlacement:
+    """Owner-computes placement of the films of a coupled stack (see the module docstring).
+
+    Pass it to :func:`superscreen_amd.factorize_model` (the rank then factors only its films) and to
+    :func:`superscreen_amd.solve`.  The process group must already exist; tensors travel with
+    ``torch.distributed.broadcast`` (RCCL on GPUs)."""
+
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+        dist = _dist()
+        if rank is None or world is None:
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed is not initialised.")
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError(f"Invalid rank {rank} for world size {world}.")
+        self.rank, self.world, self.group = rank, world, group
+
+    def owners(self, films: Sequence[str]) -> Dict[str, int]:
+        """``{film: owning rank}``: round-robin in device order."""
+        return {f: i % self.world for i, f in enumerate(films)}
+
+    def mine(self, films: Sequence[str]) -> List[str]:
+        own = self.owners(films)
+        return [f for f in films if own[f] == self.rank]
+
+    def _global_rank(self, group_rank: int) -> int:
+        dist = _dist()
+        if self.group is None or not hasattr(dist, "get_global_rank"):
+            return group_rank
+        return dist.get_global_rank(self.group, group_rank)
+
+    def share(self, films: Sequence[str], tensors: Dict[str, Dict[str, "object"]],
+              shapes: Dict[str, Dict[str, tuple]], dtypes: Dict[str, Dict[str, "object"]], device) -> None:
+        """Completes ``tensors[film][key]`` on every rank: the owner broadcasts, the others receive
+        into freshly allocated tensors of the given shape / dtype.  Deterministic order."""
+        import torch
+
+        own = self.owners(films)
+        for f in films:
+            bucket = tensors.setdefault(f, {})
+            for key in sorted(shapes[f]):
+                if own[f] != self.rank:
+                    bucket[key] = torch.empty(shapes[f][key], dtype=dtypes[f][key], device=device)
+                if self.world > 1:
+                    _dist().broadcast(bucket[key], src=self._global_rank(own[f]), group=self.group)

@@ -174,7 +174,7 @@ def make_film_info(*, device: Device, vortices: Sequence[Vortex],
 class FilmDeviceData:
     """Everything of one film that lives in HBM (torch tensors are plumbing only)."""
 
-    def __init__(self, info: FilmInfo, mesh, dtype: np.dtype, store_Q: bool):
+    def __init__(self, info: FilmInfo, mesh, dtype: np.dtype, store_Q: bool, geometry_only: bool = False):
         import torch
 
         from . import kernels
@@ -206,10 +206,13 @@ class FilmDeviceData:
         self.xy, self.w, self.w_t = geo["xy"], geo["w"], geo["w_t"]  # w: f64 geometry; w_t: solve dtype
         self.lap, self.grad = geo["lap"], geo["grad"]
         self.Lambda = put(info.lambda_info.Lambda[:, 0].astype(np.float64))
+        self._geo = geo
+        if geometry_only:  # a film owned by another rank: only a coupling source / target geometry
+            self.Q = self.qdiag = None
+            return
         # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
         # unless the dense Q is wanted for the self-field GEMV.
         self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, geo["C"], dtype, want_Q=store_Q)
-        self._geo = geo
 
     def triangle_data(self, mesh):
         """Per-triangle operators of films with terminals (centroids, areas, triangle gradient CSR
@@ -286,7 +289,8 @@ class TerminalSystems:
 
 
 def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo], *,
-                             store_Q: bool = False, method: str = "auto"):
+                             store_Q: bool = False, method: str = "auto",
+                             owned: Optional[Sequence[str]] = None):
     """``factorize_linear_systems`` (``solver/solve_film.py:151-282``) on the GPU.
     Returns ``(film_systems, hole_systems, terminal_systems, film_data)``.
 
@@ -306,6 +310,11 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     pending = []
     for name, info in film_info_dict.items():
         mesh = device.meshes[name]
+        if owned is not None and name not in owned:
+            # another rank's film (parallel.FilmPlacement): geometry only, no systems
+            film_data[name] = FilmDeviceData(info, mesh, dtype, False, geometry_only=True)
+            hole_systems[name] = {}
+            continue
         fd = FilmDeviceData(info, mesh, dtype, store_Q)
         film_data[name] = fd
         dev = fd.device
@@ -495,7 +504,8 @@ def factorize_model(*, device: Device, current_units: str,
                     terminal_currents: Optional[Dict[str, Dict[str, Union[float, str]]]] = None,
                     circulating_currents: Optional[Dict[str, Union[float, str]]] = None,
                     vortices: Optional[Sequence[Vortex]] = None,
-                    self_field: str = "matrix_free", method: str = "auto") -> FactorizedModel:
+                    self_field: str = "matrix_free", method: str = "auto",
+                    placement: Optional[object] = None) -> FactorizedModel:
     """``factorize_model`` (``solver/solve.py:223-287``).
 
     ``self_field`` (extension): ``"matrix_free"`` regenerates q_ij on the fly for
@@ -503,6 +513,8 @@ def factorize_model(*, device: Device, current_units: str,
     ``"dense"`` stores Q in the solve dtype like the reference and uses a GEMV.
     ``method`` (extension): ``"auto"`` (default) / ``"cholesky"`` / ``"lu"``, see
     :func:`factorize_linear_systems`.
+    ``placement`` (extension): a :class:`superscreen_amd.parallel.FilmPlacement`; this rank then
+    assembles and factors only the films it owns (pass the same object to :func:`solve`).
     """
     if self_field not in ("matrix_free", "dense"):
         raise ValueError(f"Unknown self_field mode {self_field!r}.")
@@ -519,11 +531,14 @@ def factorize_model(*, device: Device, current_units: str,
     film_info = make_film_info(device=device, vortices=vortices,
                                circulating_currents=circulating_currents,
                                terminal_currents=terminal_currents)
+    owned = None if placement is None else placement.mine(list(device.films))
     film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
-        device, film_info, store_Q=(self_field == "dense"), method=method)
-    return FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
-                           terminal_currents, circulating_currents, vortices, current_units,
-                           film_data=film_data, self_field_mode=self_field)
+        device, film_info, store_Q=(self_field == "dense"), method=method, owned=owned)
+    model = FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
+                            terminal_currents, circulating_currents, vortices, current_units,
+                            film_data=film_data, self_field_mode=self_field)
+    model.__dict__["_placement"] = placement
+    return model
 
 
 # ---------------------------------------------------------------------------------------
@@ -774,7 +789,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
           current_units: str = "uA", check_inversion: bool = False, iterations: int = 0,
           return_solutions: bool = True, save_path=None, log_level: Optional[int] = None,
           progress_bar: bool = True, tolerance: Optional[float] = None,
-          coupling: Optional[object] = None,
+          coupling: Optional[object] = None, placement: Optional[object] = None,
           _solver: str = "superscreen_amd.solve") -> Optional[List[Solution]]:
     """``solve`` (``solver/solve.py:290-549``): same arguments, same Jacobi scheme, same list of
     ``iterations + 1`` Solutions (1 for a single film or ``iterations < 1``).
@@ -783,7 +798,10 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     ``max_f max|g_k - g_{k-1}| / max|g_k| < tolerance`` (the reference has no convergence test,
     SURVEY.md quirk 6; ``iterations`` stays the upper bound); ``coupling`` is an optional
     :class:`superscreen_amd.parallel.CouplingPlan` that spreads the inter-film Biot-Savart sums
-    over several GPUs (one RCCL all-reduce per iteration).
+    over several GPUs (one RCCL all-reduce per iteration); ``placement`` an optional
+    :class:`superscreen_amd.parallel.FilmPlacement` (owner-computes: this rank solves the films it
+    factored and the complete coupling field of those films, the owners broadcast the O(n) result
+    vectors after every pass, every rank returns the same Solutions).
     """
     import torch
 
@@ -835,13 +853,39 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                            solver=_solver)
     solutions: List[Solution] = []
     films = list(device.films)
+    if placement is None:
+        placement = model.__dict__.get("_placement")
+    if placement is not None and coupling is not None:
+        raise ValueError("Use either a CouplingPlan or a FilmPlacement, not both.")
+    mine = films if placement is None else placement.mine(films)
+    if placement is not None and any(model.film_systems.get(f) is None for f in mine):
+        raise ValueError("The model was not factorized with this placement.")
 
     def run_pass(other_d):
         results = {}
-        for name in films:
+        for name in mine:
             results[name] = _solve_film_device(model, name, applied_d[name],
                                                None if other_d is None else other_d[name],
                                                check_inversion, vflux)
+        if placement is not None:
+            # owners broadcast their films' result vectors (and coupling fields): O(n) each
+            fds = model.film_data
+            payload = {f: ({"g": results[f].g, "J": results[f].J, "self_field": results[f].self_field}
+                           if f in results else {}) for f in films}
+            shapes = {f: {"g": (fds[f].n,), "J": (fds[f].n, 2), "self_field": (fds[f].n,)} for f in films}
+            dtypes = {f: {"g": fds[f].tdtype, "J": torch.float64, "self_field": fds[f].tdtype} for f in films}
+            if other_d is not None:
+                for f in films:
+                    if f in results:
+                        payload[f]["other"] = other_d[f]
+                    shapes[f]["other"], dtypes[f]["other"] = (fds[f].n,), fds[f].tdtype
+            placement.share(films, payload, shapes, dtypes, fds[films[0]].device)
+            for f in films:
+                if f not in results:
+                    results[f] = _DeviceFilmResult(g=payload[f]["g"], J=payload[f]["J"],
+                                                   self_field=payload[f]["self_field"])
+                if other_d is not None:
+                    other_d[f] = payload[f]["other"]
         return results
 
     def package(staged: _StagedPass):
@@ -860,7 +904,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
             coupling.accumulate(model, results, other_d)
         else:
             for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
-                if src == tgt:
+                if src == tgt or tgt not in mine:  # owner-computes: only this rank's target films
                     continue
                 s, t = model.film_data[src], model.film_data[tgt]
                 kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,

@@ -124,3 +124,18 @@ def test_coupling_allreduce_world2_gloo():
     for rank, worst, total, complete in out:
         assert worst < 1e-13, (rank, worst)
         assert total == 64 and complete
+
+
+def test_film_placement_bookkeeping():
+    from superscreen_amd.parallel import FilmPlacement
+
+    films = ["a", "b", "c", "d", "e"]
+    for world in (1, 2, 3, 8):
+        owned = []
+        for rank in range(world):
+            p = FilmPlacement(rank=rank, world=world)
+            assert p.owners(films) == {f: i % world for i, f in enumerate(films)}
+            owned += p.mine(films)
+        assert sorted(owned) == films          # every film exactly once
+    with pytest.raises(ValueError):
+        FilmPlacement(rank=2, world=2)

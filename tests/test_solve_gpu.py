@@ -1,6 +1,8 @@
 """End-to-end GPU parity: ``superscreen_amd.solve`` (HIP path through the C ABI) against
 (a) fixtures recorded from the reference itself and (b) the CPU oracle on the same inputs.
 Tolerance for float64: stream function max-rel-error < 1e-9 (north_star asks < 1e-6)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -469,3 +471,19 @@ def test_vector_potential_and_polygon_flux():
     assert sol.polygon_flux("washer0").units.dims == sc.units.parse_units("mT * um**2").dims
     with pytest.raises(ValueError, match="Unknown polygon"):
         sol.polygon_flux("nope")
+
+
+def test_film_placement_two_ranks():
+    """parallel.FilmPlacement (owner-computes films, broadcast of the O(n) result vectors): two
+    ranks share this GPU, gloo carries the broadcasts, results equal the single-process solve."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "workers", "placement_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29571", worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("owner-computes == single process") == 2

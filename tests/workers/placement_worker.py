@@ -1,0 +1,59 @@
+"""Worker of tests/test_solve_gpu.py::test_film_placement_two_ranks: launched twice by
+``torch.distributed.run``; both ranks share cuda:0 (gloo carries the broadcasts), so the
+owner-computes path runs with the real kernels on a single-GPU box."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import superscreen_amd as sc  # noqa: E402
+from superscreen_amd import synthetic  # noqa: E402
+from superscreen_amd.parallel import FilmPlacement  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = synthetic.make_stack_device(10, ("washer", "disk", "washer"), z_spacing=1.5)
+    kw = dict(applied_field=sc.ConstantField(0.8), field_units="mT", iterations=4)
+    circ = {"hole0": 1.5, "hole2": -0.5}
+    placement = FilmPlacement()
+    assert placement.owners(list(device.films)) == {"washer0": 0, "disk1": 1 % world, "washer2": 2 % world}
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents=circ, placement=placement)
+    mine = placement.mine(list(device.films))
+    assert set(model.film_systems) == set(mine), (rank, list(model.film_systems))
+    sols = sc.solve(model=model, placement=placement, **kw)
+    # single-process reference on the same GPU
+    ref_model = sc.factorize_model(device=device, current_units="uA", circulating_currents=circ)
+    ref = sc.solve(model=ref_model, **kw)
+    assert len(sols) == len(ref) == 5
+    worst = 0.0
+    for a, b in zip(sols, ref):
+        for name in device.films:
+            fa, fb = a.film_solutions[name], b.film_solutions[name]
+            for x, y in ((fa.stream, fb.stream), (fa.current_density, fb.current_density),
+                         (fa.self_field, fb.self_field)):
+                worst = max(worst, float(np.max(np.abs(x - y)) / np.max(np.abs(y))))
+            if fb.field_from_other_films is not None:
+                x, y = fa.field_from_other_films, fb.field_from_other_films
+                worst = max(worst, float(np.max(np.abs(x - y)) / np.max(np.abs(y))))
+    assert worst < 1e-13, worst
+    # early stop on a tolerance gives the same number of iterates on every rank
+    n_it = len(sc.solve(model=model, placement=placement, applied_field=sc.ConstantField(0.8), iterations=50,
+                        tolerance=1e-2))
+    n_ref = len(sc.solve(model=ref_model, applied_field=sc.ConstantField(0.8), iterations=50, tolerance=1e-2))
+    counts = [None] * world
+    dist.all_gather_object(counts, n_it)
+    assert len(set(counts)) == 1 and n_it == n_ref and 2 < n_it < 51, (counts, n_ref)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: owner-computes == single process (max rel diff {worst:.1e}), films {mine}")
+
+
+if __name__ == "__main__":
+    main()
