@@ -177,12 +177,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path.")
+    # BENCH_SHARE_GPU=1 (testing aid for single-GPU boxes): all ranks use cuda:0 and gloo carries the
+    # barrier / max-reduce, so that the N > 1 control flow can be exercised without N GPUs
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import superscreen_amd as sc
     from superscreen_amd import _hip, kernels, synthetic
