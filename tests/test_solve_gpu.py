@@ -481,9 +481,14 @@ def test_film_placement_two_ranks():
 
     here = os.path.dirname(os.path.abspath(__file__))
     worker = os.path.join(here, "workers", "placement_worker.py")
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29571", worker]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("owner-computes == single process") == 2
