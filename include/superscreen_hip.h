@@ -309,6 +309,23 @@ int ssa_profile_begin(void);
 int ssa_profile_read(int kind, double *ms, double *flops, int64_t *launches);
 int ssa_profile_end(void);
 
+/*
+ * Multi-vector forms of ssa_self_field and ssa_biot_savart for sweeps that carry nvec right-hand
+ * sides through one factorization (BASELINE config 4; the solve itself then runs on the MFMA GEMM
+ * path of ssa_chol_solve / ssa_lu_solve with nrhs = nvec).  Operands are row-major with the vector
+ * index fastest: g, out [n, nvec]; src_J [ns, nvec, 2]; r^-3 is evaluated once per pair and reused
+ * for 16 vectors at a time.  Same formulas, same deterministic two-stage reduction.
+ *   workspace: ssa_pairwise_multi_workspace_bytes(number of targets)
+ */
+size_t ssa_pairwise_multi_workspace_bytes(int64_t nt);
+int ssa_self_field_multi(const double *xy, const double *w, const double *qdiag, const void *g,
+                         int64_t n, int64_t nvec, void *out, double alpha, int dtype, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int ssa_biot_savart_multi(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
+                          const double *tgt_xy, int64_t nt, double dz, int64_t nvec, void *out,
+                          int accumulate, int dtype, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 /* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern (roofline peak). */
 int ssa_fill_probe(void *dst, size_t bytes, void *stream);
 

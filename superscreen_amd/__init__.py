@@ -17,6 +17,7 @@ _LAZY = {
     "Solution": "solution", "FilmSolution": "solution", "Fluxoid": "solution",
     "Vortex": "solution",
     "find_fluxoid_solution": "fluxoid", "make_fluxoid_polygons": "fluxoid",
+    "solve_sweep": "sweep",
 }
 
 

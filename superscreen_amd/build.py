@@ -21,7 +21,7 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIBNAME = "libsuperscreen_hip.so"
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "assemble.hip", "pairwise.hip", "blas1.hip", "gemm.hip", "gemm_ops.hip",
+SOURCES = ["capi.hip", "assemble.hip", "pairwise.hip", "pairwise_multi.hip", "blas1.hip", "gemm.hip", "gemm_ops.hip",
            "lu.hip", "chol.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

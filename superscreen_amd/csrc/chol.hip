@@ -39,6 +39,11 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int
              const double *B, int64_t ldb, double beta, double *C, int64_t ldc, hipStream_t st);
 int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
              const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st);
+int gemm_splitk_pick(int64_t M, int64_t N, int64_t K);
+int gemm_splitk_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                    int64_t ldb, double beta, double *C, int64_t ldc, int splits, double *partial, hipStream_t st);
+int gemm_splitk_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
+                    int64_t ldb, double beta, float *C, int64_t ldc, int splits, float *partial, hipStream_t st);
 int gemv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
              double alpha, double beta, hipStream_t st);
 int gemv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
@@ -76,6 +81,15 @@ inline int gemm_nn_t(int64_t M, int64_t N, int64_t K, double alpha, const double
 inline int gemm_nn_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
                      const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st) {
     return gemm_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+}
+// skinny product of the multi-right-hand-side solves: split-K when there are too few tiles
+inline int gemm_rhs_t(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                      int64_t ldb, double beta, double *C, int64_t ldc, double *partial, hipStream_t st) {
+    return gemm_splitk_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, gemm_splitk_pick(M, N, K), partial, st);
+}
+inline int gemm_rhs_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
+                      int64_t ldb, double beta, float *C, int64_t ldc, float *partial, hipStream_t st) {
+    return gemm_splitk_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, gemm_splitk_pick(M, N, K), partial, st);
 }
 inline int gemv_n_t(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
                     double alpha, double beta, hipStream_t st) {
@@ -432,7 +446,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
 // several: the same recurrence on the MFMA GEMM.
 template <typename T>
 int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb, T *X,
-          hipStream_t st) {
+          T *partial, hipStream_t st) {
     const AuxLayout al = aux_layout(n);
     const int64_t ldx = nrhs;
     const bool vec = (nrhs == 1 && ldb == 1);
@@ -446,10 +460,10 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
             if (rc == SSA_OK && below > 0)
                 rc = gemv_n_t(L + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
         } else {
-            rc = gemm_nn_t(kb, nrhs, kb, 1.0, inv, SNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, st);
+            rc = gemm_rhs_t(kb, nrhs, kb, 1.0, inv, SNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, partial, st);
             if (rc == SSA_OK && below > 0)
-                rc = gemm_nn_t(below, nrhs, kb, -1.0, L + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx, 1.0,
-                               B + (r0 + kb) * ldb, ldb, st);
+                rc = gemm_rhs_t(below, nrhs, kb, -1.0, L + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx, 1.0,
+                                B + (r0 + kb) * ldb, ldb, partial, st);
         }
         if (rc != SSA_OK) return rc;
     }
@@ -461,9 +475,9 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
             rc = trmv_t(invT, kb, kb, SNB, X + r0, B + r0, 1.0, 0.0, 2, st);
             if (rc == SSA_OK && r0 > 0) rc = gemv_n_t(U, r0, kb, lda, B + r0, X, -1.0, 1.0, st);
         } else {
-            rc = gemm_nn_t(kb, nrhs, kb, 1.0, invT, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, st);
+            rc = gemm_rhs_t(kb, nrhs, kb, 1.0, invT, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, partial, st);
             if (rc == SSA_OK && r0 > 0)
-                rc = gemm_nn_t(r0, nrhs, kb, -1.0, U, lda, B + r0 * ldb, ldb, 1.0, X, ldx, st);
+                rc = gemm_rhs_t(r0, nrhs, kb, -1.0, U, lda, B + r0 * ldb, ldb, 1.0, X, ldx, partial, st);
         }
         if (rc != SSA_OK) return rc;
     }
@@ -519,7 +533,7 @@ int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t
         return SSA_ERR_HIP;
     if (np > n && hipMemsetAsync(Bp + n * nrhs, 0, (np - n) * nrhs * sizeof(T), st) != hipSuccess)
         return SSA_ERR_HIP;
-    const int rc = potrs<T>(L, np, lda, aux, Bp, nrhs, nrhs, X, st);
+    const int rc = potrs<T>(L, np, lda, aux, Bp, nrhs, nrhs, X, ws + 2 * np * nrhs, st);
     if (rc != SSA_OK) return rc;
     if (hipMemcpy2DAsync(B, ldb * sizeof(T), Bp, nrhs * sizeof(T), nrhs * sizeof(T), n, hipMemcpyDeviceToDevice,
                          st) != hipSuccess)
@@ -555,8 +569,12 @@ extern "C" int ssa_chol_factor(void *A, int64_t n, int64_t lda, int32_t *info, v
 }
 
 extern "C" size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype) {
-    return 2 * static_cast<size_t>(ssa_chol_padded_n(n)) * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) +
-           256;
+    // X, padded B, and (several right-hand sides) the split-K partial products: gemm_splitk_pick keeps
+    // tiles * pieces < 768 with <= 16 pieces, so pieces * M <= min(16 np, 768 * 128) rows
+    const size_t np = static_cast<size_t>(ssa_chol_padded_n(n));
+    const size_t part = 16 * np < 98304 ? 16 * np : 98304;
+    const size_t rows = 2 * np + (nrhs > 1 ? part : 0);
+    return rows * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) + 256;
 }
 
 extern "C" int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B,

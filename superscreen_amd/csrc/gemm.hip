@@ -417,6 +417,55 @@ int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float 
                               BatchStrides{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], tri});
 }
 
+
+// ---- split-K for skinny products (multi-right-hand-side triangular solves: M x 128 outputs give only
+// M / 128 tiles, far fewer than 256 CUs).  The K range is cut into `splits` pieces computed as one
+// batched launch into `partial` (splits x M x N, ld = N), then reduced: C = alpha * sum + beta * C.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const T *__restrict__ partial, int splits, int64_t M,
+                                                            int64_t N, T alpha, T beta, T *__restrict__ C,
+                                                            int64_t ldc) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int64_t r = idx / N, c = idx - r * N;
+    T acc = T(0);
+    for (int s = 0; s < splits; ++s) acc += partial[static_cast<int64_t>(s) * M * N + idx];
+    T *dst = C + r * ldc + c;
+    *dst = (beta == T(0)) ? alpha * acc : alpha * acc + beta * *dst;
+}
+
+int gemm_splitk_pick(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    int splits = 1;
+    while (splits < 16 && tiles * splits < 384 && K % (2 * splits * 256) == 0) splits *= 2;
+    return splits;
+}
+
+template <typename T>
+int gemm_splitk(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B, int64_t ldb,
+                double beta, T *C, int64_t ldc, int splits, T *partial, hipStream_t st) {
+    if (splits <= 1 || !partial) return launch_gemm<T>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+    if (M <= 0 || N <= 0) return SSA_OK;
+    const int64_t kp = K / splits;
+    const int rc = launch_gemm<T>(M, N, kp, 1.0, A, lda, B, ldb, 0.0, partial, N, st, splits, 1,
+                                  BatchStrides{kp, 0, kp * ldb, 0, M * N, 0, 0});
+    if (rc != SSA_OK) return rc;
+    const int64_t total = M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(static_cast<unsigned>(ceil_div(total, 256))), dim3(256), 0,
+                       st, partial, splits, M, N, static_cast<T>(alpha), static_cast<T>(beta), C, ldc);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+int gemm_splitk_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                    int64_t ldb, double beta, double *C, int64_t ldc, int splits, double *partial,
+                    hipStream_t st) {
+    return gemm_splitk<double>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, splits, partial, st);
+}
+int gemm_splitk_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
+                    int64_t ldb, double beta, float *C, int64_t ldc, int splits, float *partial, hipStream_t st) {
+    return gemm_splitk<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, splits, partial, st);
+}
+
 }  // namespace ssa
 
 using namespace ssa;

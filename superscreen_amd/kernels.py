@@ -258,6 +258,31 @@ def self_field(xy, w, qdiag, g: torch.Tensor, alpha: float = 1.0) -> torch.Tenso
     return out
 
 
+def self_field_multi(xy, w, qdiag, g: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """Matrix-free ``Q @ (w * g)`` for ``g [n, nvec]`` (one evaluation of r^-3 per pair for all vectors)."""
+    lib = load_library()
+    n, nvec = g.shape
+    out = torch.empty_like(g)
+    nbytes = lib.ssa_pairwise_multi_workspace_bytes(n)
+    ws = _ws(nbytes, g.device)
+    check(lib.ssa_self_field_multi(ptr(xy), ptr(w), ptr(qdiag), ptr(g), n, nvec, ptr(out), float(alpha),
+                                   dtype_code(g.dtype), ptr(ws), nbytes, current_stream()), "ssa_self_field_multi")
+    return out
+
+
+def biot_savart_multi(src_xy, src_areas, src_J, tgt_xy, dz: float, out: torch.Tensor, *,
+                      accumulate: bool) -> torch.Tensor:
+    """``biot_savart_film_to_film`` for ``src_J [ns, nvec, 2]`` into ``out [nt, nvec]``."""
+    lib = load_library()
+    ns, nt, nvec = src_xy.shape[0], tgt_xy.shape[0], out.shape[1]
+    nbytes = lib.ssa_pairwise_multi_workspace_bytes(nt)
+    ws = _ws(nbytes, out.device)
+    check(lib.ssa_biot_savart_multi(ptr(src_xy), ptr(src_areas), ptr(src_J), ns, ptr(tgt_xy), nt, float(dz), nvec,
+                                    ptr(out), int(bool(accumulate)), dtype_code(out.dtype), ptr(ws), nbytes,
+                                    current_stream()), "ssa_biot_savart_multi")
+    return out
+
+
 def film_rhs(applied, other, ha_eff, idx, nvec: int = 1) -> torch.Tensor:
     """``h = Hz[indices] - Ha_eff[indices]`` (solver/solve_film.py:486-488, 526-529)."""
     lib = load_library()

@@ -95,8 +95,11 @@ class Solution:
                  applied_field_func: Callable, field_units: str, current_units: str,
                  circulating_currents: Optional[Dict[str, float]] = None,
                  terminal_currents: Optional[Dict[str, float]] = None,
-                 vortices: Optional[List[Vortex]] = None, solver: str = "superscreen_amd.solve"):
-        self.device = device.copy(with_mesh=True, copy_mesh=False)  # solution.py:232
+                 vortices: Optional[List[Vortex]] = None, solver: str = "superscreen_amd.solve",
+                 _device_is_copy: bool = False):
+        # solution.py:232 -- a sweep builds hundreds of Solutions: it copies the device once and
+        # hands the same copy to all of them
+        self.device = device if _device_is_copy else device.copy(with_mesh=True, copy_mesh=False)
         self.film_solutions = film_solutions
         self.applied_field_func = applied_field_func
         self.circulating_currents = circulating_currents or {}

@@ -1,0 +1,168 @@
+"""Sweeps: many applied fields through ONE factorization, all at once.
+
+The reference answers a field scan by calling ``solve(model=...)`` in a loop (its former
+``solve_many`` was removed in v0.9, ``docs/about/changelog.rst:120-124``); each call is
+memory-bound (one right-hand side streams the whole factor).  Here the ``nvec`` fields of a scan
+are carried as the columns of ``[n, nvec]`` operands through the same steps as ``solve_film``
+(``solver/solve_film.py:486-565``) and the Jacobi loop of ``solve`` (``solver/solve.py:491-536``):
+
+* right-hand sides, scatter, sheet current: the ``nvec`` forms of the vector kernels;
+* ``gf = lu_solve(lu_piv, h)``: the block triangular solves on the MFMA GEMM (``nrhs = nvec``)
+  instead of a GEMV chain -- the factor is read once for all fields;
+* self field and inter-film coupling: ``ssa_self_field_multi`` / ``ssa_biot_savart_multi``, which
+  evaluate r^-3 once per pair for 16 fields.
+
+Every field's iterates equal those of its own ``solve(model=..., applied_field=field)`` call up to
+rounding (different summation order only).  Films with terminals or vortices are not handled here
+(their extra terms do not depend on the applied field; use ``solve`` in a loop).
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Callable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from .solution import FilmSolution, Solution
+from .sources import ConstantField
+from .units import field_conversion_factor
+
+
+def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, field_units: str = "mT",
+                iterations: int = 0, return_solutions: bool = True,
+                _solver: str = "superscreen_amd.solve_sweep") -> Optional[List[List[Solution]]]:
+    """Self-consistent solutions for every applied field of a scan.
+
+    ``applied_fields``: callables ``f(x, y, z)`` (e.g. :func:`superscreen_amd.ConstantField`) or
+    plain numbers (uniform fields in ``field_units``).  Returns ``result[k]`` = the list of
+    ``iterations + 1`` Solutions of field ``k`` (1 for a single film), like ``solve`` would."""
+    import torch
+
+    from . import _hip, kernels
+
+    _hip.require_gpu()
+    device = model.device
+    films = list(device.films)
+    if any(name in device.terminals for name in films):
+        raise NotImplementedError("solve_sweep does not handle films with terminals; loop over solve().")
+    if any(info.vortices for info in model.film_info.values()):
+        raise NotImplementedError("solve_sweep does not handle vortices; loop over solve().")
+    fields = [f if callable(f) else ConstantField(float(f)) for f in applied_fields]
+    nvec = len(fields)
+    if nvec == 0:
+        return [] if return_solutions else None
+    current_units = model.current_units
+    conv = field_conversion_factor(field_units, current_units, length_units=device.length_units)
+    dtype = device.solve_dtype
+    info_of, fd_of = model.film_info, model.film_data
+
+    # applied fields on the sites: [n, nvec] per film (host evaluation like solve.py:422-436)
+    applied_h, applied_d = {}, {}
+    for name in films:
+        mesh = device.meshes[name]
+        x, y = mesh.sites[:, 0], mesh.sites[:, 1]
+        z = info_of[name].z0 * np.ones(len(x))
+        cols = []
+        for f in fields:
+            Hz = np.squeeze(np.asarray(f(x, y, z)) * conv)
+            Hz = Hz * np.ones(len(x)) if Hz.ndim == 0 else Hz
+            if Hz.ndim != 1:
+                raise ValueError(f"Expected applied_field to return a 1D vector, got a {Hz.shape[1]}D vector.")
+            cols.append(Hz)
+        H = np.ascontiguousarray(np.stack(cols, axis=1).astype(dtype, copy=False))
+        applied_h[name] = H
+        applied_d[name] = torch.from_numpy(H).to(fd_of[name].device)
+
+    def solve_columns(solve_in_place, rhs):
+        """The block triangular solves run on 128 x 128 MFMA tiles: pad the right-hand sides with
+        zero columns to a multiple of 128 so that every tile is a full one (the guarded edge path is
+        several times slower than the extra flops cost)."""
+        npad = -(-nvec // 128) * 128
+        if npad == nvec:
+            return solve_in_place(rhs)
+        B = torch.zeros((rhs.shape[0], npad), dtype=rhs.dtype, device=rhs.device)
+        B[:, :nvec] = rhs
+        return solve_in_place(B)[:, :nvec].contiguous()
+
+    def run_pass(other_d):
+        results = {}
+        for name in films:
+            fd, info, system = fd_of[name], info_of[name], model.film_systems[name]
+            g = torch.zeros((fd.n, nvec), dtype=fd.tdtype, device=fd.device)
+            ha = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+            g1 = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+            for hole_name, hs in model.hole_systems[name].items():  # field independent (solve_film.py:498-503)
+                current = info.circulating_currents.get(hole_name, 0)
+                kernels.index_add_scalar(g1, hs.indices_device, current)
+                kernels.gemv(hs.A_device, fd.n, len(hs.indices), g1, xidx=hs.indices_device, y=ha,
+                             alpha=-1.0, beta=1.0)
+            g += g1[:, None]
+            ha_all = ha[:, None].expand(fd.n, nvec).contiguous()
+            other = None if other_d is None else other_d[name]
+            if system.chol is not None:
+                h = kernels.film_rhs(applied_d[name], other, ha_all, system.indices_device, nvec=nvec)
+                gf = solve_columns(lambda B: kernels.chol_solve(system.chol, B),
+                                   kernels.row_scale(h, system.neg_w_device))
+            else:
+                h = kernels.film_rhs(applied_d[name], other, ha_all, system.rhs_indices_device, nvec=nvec)
+                gf = solve_columns(lambda B: kernels.lu_solve_permuted(system.factors, B), h)
+            kernels.scatter_add(g, system.indices_device, gf, nvec=nvec)
+            J = kernels.current_density(*fd.grad, g, nvec=nvec)              # [n, nvec, 2]
+            sf = kernels.self_field_multi(fd.xy, fd.w, fd.qdiag, g)
+            results[name] = (g, J, sf)
+        return results
+
+    def to_host(results, other_d):
+        """Field-major host arrays ([nvec, n(, 2)]): every field's slice is then a contiguous view,
+        no per-field host copy.  The transposes run on the device; the copies land in pinned memory."""
+        def fetch(t):
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            return h
+
+        out = {}
+        for name in films:
+            g, J, sf = results[name]
+            out[name] = (fetch(g.t().contiguous()), fetch(J.permute(1, 0, 2).contiguous()), fetch(sf.t().contiguous()),
+                         None if other_d is None else fetch(other_d[name].t().contiguous()))
+        torch.cuda.synchronize()
+        return {name: tuple(None if a is None else a.numpy() for a in arrs) for name, arrs in out.items()}
+
+    trace = []
+    results = run_pass(None)
+    if return_solutions:
+        trace.append(to_host(results, None))
+    if len(films) >= 2 and iterations >= 1:
+        for _ in range(iterations):
+            other_d = {name: torch.zeros((fd_of[name].n, nvec), dtype=fd_of[name].tdtype, device=fd_of[name].device)
+                       for name in films}
+            for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
+                if src == tgt:
+                    continue
+                s, t = fd_of[src], fd_of[tgt]
+                kernels.biot_savart_multi(s.xy, s.w_t, results[src][1], t.xy,
+                                          info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True)
+            results = run_pass(other_d)
+            if return_solutions:
+                trace.append(to_host(results, other_d))
+    if not return_solutions:
+        torch.cuda.synchronize()
+        return None
+    out: List[List[Solution]] = []
+    device_copy = device.copy(with_mesh=True, copy_mesh=False)  # what Solution.__init__ would make, once
+    for k, field in enumerate(fields):
+        sols = []
+        for host in trace:
+            fs = {}
+            for name in films:
+                g, J, sf, other = host[name]
+                fs[name] = FilmSolution(
+                    stream=g[k], current_density=J[k], applied_field=applied_h[name][:, k] / conv,
+                    self_field=sf[k] / conv, field_from_other_films=None if other is None else other[k] / conv)
+            sols.append(Solution(device=device_copy, film_solutions=fs, applied_field_func=field,
+                                 field_units=field_units, current_units=current_units,
+                                 circulating_currents=model.circulating_currents,
+                                 terminal_currents=model.terminal_currents, vortices=model.vortices, solver=_solver,
+                                 _device_is_copy=True))
+        out.append(sols)
+    return out

@@ -491,3 +491,31 @@ def test_tiny_and_degenerate_sizes(K):
         Ad[:, :n] = dev(S)
         lf = K.lu_factor(Ad, n)
         assert lf.info == 0 and relerr(K.lu_solve(lf, dev(b)).cpu().numpy(), np.linalg.solve(S, b)) < 1e-13
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 2e-5)])
+@pytest.mark.parametrize("nvec", [1, 5, 16, 19])
+def test_multi_vector_pairwise_kernels(K, disk, dtype, tol, nvec):
+    """ssa_self_field_multi / ssa_biot_savart_multi column by column against the single-vector kernels."""
+    sites, elements, mesh = disk
+    n = len(sites)
+    rng = np.random.default_rng(nvec)
+    tdt = getattr(torch, dtype)
+    xy, w = dev(sites), dev(mesh.weights)
+    _, qd = K.q_assemble(xy, w, dev(orc.C_vector(sites)), "float64", want_Q=False)
+    g = torch.from_numpy(rng.standard_normal((n, nvec))).to("cuda").to(tdt).contiguous()
+    sf = K.self_field_multi(xy, w, qd, g, alpha=0.5).cpu().numpy().astype(np.float64)
+    for v in range(nvec):
+        ref = K.self_field(xy, w, qd, g[:, v].contiguous(), alpha=0.5).cpu().numpy().astype(np.float64)
+        assert relerr(sf[:, v], ref) < tol
+    # coupling between two different point sets, accumulate on top of an existing field
+    tgt = dev(sites[: n // 2] * 0.9 + 0.05)
+    J = torch.from_numpy(rng.standard_normal((n, nvec, 2))).to("cuda").contiguous()
+    base = torch.from_numpy(rng.standard_normal((n // 2, nvec))).to("cuda").to(tdt).contiguous()
+    out = base.clone()
+    K.biot_savart_multi(xy, w.to(tdt), J, tgt, 0.7, out, accumulate=True)
+    out = out.cpu().numpy().astype(np.float64)
+    for v in range(nvec):
+        ref = base[:, v].contiguous().clone()
+        K.biot_savart(xy, w.to(tdt), J[:, v, :].contiguous(), tgt, 0.7, ref, accumulate=True)
+        assert relerr(out[:, v], ref.cpu().numpy().astype(np.float64)) < tol

@@ -492,3 +492,33 @@ def test_film_placement_two_ranks():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("owner-computes == single process") == 2
+
+
+@pytest.mark.parametrize("method", ["auto", "lu"])
+def test_solve_sweep_equals_looped_solve(method):
+    """solve_sweep (all fields of a scan as columns of one multi-RHS solve) == solve() per field."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(12, ("washer", "disk"), z_spacing=0.6)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": 0.7}, method=method)
+    values = [0.0, 0.3, -1.1, 2.0, 0.05] + [0.1 * k for k in range(14)]     # 19 fields: one full chunk + 3
+    fields = values[:10] + [sc.ConstantField(v) for v in values[10:]]
+    sweep = sc.solve_sweep(model, fields, field_units="mT", iterations=3)
+    assert len(sweep) == len(values) and all(len(s) == 4 for s in sweep)
+    for v, sols in zip(values, sweep):
+        ref = sc.solve(model=model, applied_field=sc.ConstantField(v), field_units="mT", iterations=3)
+        for a, b in zip(sols, ref):
+            for name in device.films:
+                fa, fb = a.film_solutions[name], b.film_solutions[name]
+                scale = max(np.abs(fb.stream).max(), 1e-300)
+                assert np.abs(fa.stream - fb.stream).max() / scale < 1e-11
+                assert relerr(fa.current_density, fb.current_density) < 1e-11
+                assert relerr(fa.self_field, fb.self_field) < 1e-11
+                assert np.array_equal(fa.applied_field, fb.applied_field)
+                if fb.field_from_other_films is not None:
+                    assert relerr(fa.field_from_other_films, fb.field_from_other_films) < 1e-11
+    assert sc.solve_sweep(model, [], iterations=1) == []
+    single = synthetic.make_stack_device(10, ("disk",))
+    m1 = sc.factorize_model(device=single, current_units="uA")
+    assert [len(s) for s in sc.solve_sweep(m1, [1.0, 2.0], iterations=5)] == [1, 1]   # one film: no Jacobi loop
