@@ -4,161 +4,217 @@
 //   film coupling   out[i, v] (+)= sum_j (1/4pi) a_j (Jx[j, v] dy - Jy[j, v] dx) |r_ij|^-3
 // (solver/solve_film.py:565 and solver/solve.py:28-73, :508, applied to [n, nvec] operands.)
 //
-// The expensive part of a pair, r^-3 (rsq + refinement, ~11 FP64 ops), does not depend on the
-// vector: it is evaluated once and reused for a chunk of NV = 16 vectors held in registers, i.e.
-// (11 + 16) / 16 = 1.7 ops per pair and vector instead of 13 (self field), (12 + 48) / 16 = 3.75
-// instead of 14 (coupling).  Same decomposition as pairwise.hip: grid = target blocks of 256 x
-// source slices, sources staged in LDS 64 at a time (coordinates + 16 or 32 "charges" each), slice
-// partials combined by a second kernel in a fixed order (bitwise reproducible, no float atomics).
-// A launch handles one chunk of <= 16 vectors (columns [v0, v0 + nv) of the row-major operands).
+// With several vectors these are products  out = K(targets, sources) * C(sources, vectors)  whose
+// left operand is a function of the coordinates only.  It is never stored: each lane evaluates ONE
+// kernel value per 16 x 4 block, which is exactly the A-operand layout of v_mfma_f64_16x16x4_f64
+// (lane l holds row l & 15, k = l >> 4), and the matrix cores multiply it by the staged charges.
+// The FP64 work per pair drops from (~12 + 2 NV) vector ops to ~12 vector ops + NV / 32 MFMAs, and
+// the LDS traffic from (2 + 2 NV) broadcast reads per pair to one operand read per MFMA.
+//
+// Work split: a workgroup (4 waves) owns 128 targets x one source slice x a chunk of <= 64 vectors;
+// a wave owns 32 targets (two MFMA row blocks sharing every B operand).  Sources are staged 32 at a
+// time: coordinates plus the charge planes  c a_j Jx | -c a_j Jy  (coupling) or  c w_j g  (self
+// field), rows padded so the four k-rows of an operand read fall in distinct LDS banks.  Slice
+// partials are combined by a second kernel in a fixed order (bitwise reproducible, no float atomics).
 #include "common.hpp"
+#include "mfma_traits.hpp"
 
 namespace ssa {
 namespace {
 
-constexpr int kMT = 256;       // targets per workgroup
-constexpr int kMS = 64;        // sources per LDS stage
-constexpr int kNV = 16;        // vectors per launch
-constexpr int kMaxSlicesM = 32;
+constexpr int kTB = 128;        // targets per workgroup (32 per wave)
+constexpr int kKS = 32;         // sources per LDS stage
+constexpr int kChunk = 64;      // vectors per launch
+constexpr int kMaxSlicesM = 16;
 
+// Source slices per target block: the grid should be a whole number of "rounds" of the workgroup
+// slots of the chip (3 resident workgroups per CU: 41 KB of LDS, 160 VGPRs) -- 785 workgroups on 768
+// slots take as long as 1536.  Picks the slice count with the best slot utilisation.
 inline int pick_slices_m(int64_t nt, int64_t ns) {
-    const int64_t tb = ceil_div(nt, kMT);
-    int64_t s = ceil_div(1024, tb);
-    const int64_t max_by_len = ceil_div(ns, 4 * kMS);
-    if (s > max_by_len) s = max_by_len;
-    if (s > kMaxSlicesM) s = kMaxSlicesM;
-    if (s < 1) s = 1;
-    return static_cast<int>(s);
+    static int64_t slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 3 * static_cast<int64_t>(cus > 0 ? cus : 256);
+    }
+    const int64_t tb = ceil_div(nt, kTB);
+    int64_t max_s = ceil_div(ns, 8 * kKS);
+    if (max_s > kMaxSlicesM) max_s = kMaxSlicesM;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int64_t s = 1; s <= max_s; ++s) {
+        const int64_t wgs = tb * s;
+        const double eff = static_cast<double>(wgs) / static_cast<double>(ceil_div(wgs, slots) * slots);
+        if (eff > best_eff + 1e-9) {  // ties: fewer slices, less partial traffic
+            best_eff = eff;
+            best = static_cast<int>(s);
+        }
+    }
+    return best;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kMT) void self_field_multi_kernel(const double *__restrict__ xy,
-                                                               const double *__restrict__ w,
-                                                               const T *__restrict__ g, int64_t n, int64_t nvec,
-                                                               int64_t v0, int nv, int64_t slice_len,
-                                                               double *__restrict__ partial) {
-    __shared__ double s_x[kMS], s_y[kMS];
-    __shared__ __attribute__((aligned(16))) double s_c[kMS][kNV];
-    const int tid = threadIdx.x;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kMT + tid;
+// NB = 16-column blocks of this chunk (1..4); SELF: one charge plane and the i == j exclusion.
+template <typename T, int NB, bool SELF>
+__global__ __launch_bounds__(256) void pair_mfma_kernel(const double *__restrict__ src_xy,
+                                                        const void *__restrict__ src_scale,
+                                                        const void *__restrict__ src_val, int64_t ns,
+                                                        int64_t nvec, int64_t v0, int nv, int64_t slice_len,
+                                                        const double *__restrict__ tgt_xy, int64_t nt, double dz2,
+                                                        double *__restrict__ partial) {
+    using MF = Mfma<double>;
+    using acc_t = MF::acc_t;
+    constexpr int NV = NB * 16;
+    constexpr int NVP = NV | 16;  // row stride = 128 B mod 256 B: k-rows alternate bank halves
+    constexpr int NP = SELF ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) double s_b[NP][kKS][NVP];
+    __shared__ __attribute__((aligned(16))) double s_xy[kKS][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t t_base = static_cast<int64_t>(blockIdx.x) * kTB + wave * 32;
     const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
-    const int64_t j_end = (j_begin + slice_len < n) ? j_begin + slice_len : n;
-    const int64_t ic = (i < n) ? i : n - 1;
-    const double xi = xy[2 * ic], yi = xy[2 * ic + 1];
-    double acc[kNV];
+    const int64_t j_end = (j_begin + slice_len < ns) ? j_begin + slice_len : ns;
+
+    double xi[2], yi[2];
+    int64_t ti[2];
 #pragma unroll
-    for (int v = 0; v < kNV; ++v) acc[v] = 0.0;
-    for (int64_t t0 = j_begin; t0 < j_end; t0 += kMS) {
-        __syncthreads();
-        if (tid < kMS) {
-            const int64_t j = t0 + tid;
-            const bool ok = j < j_end;
-            s_x[tid] = ok ? xy[2 * j] : 0.0;
-            s_y[tid] = ok ? xy[2 * j + 1] : 0.0;
-        }
-        for (int e = tid; e < kMS * kNV; e += kMT) {  // charges (1/4pi) w_j g[j, v0 + v]
-            const int k = e / kNV, v = e % kNV;
-            const int64_t j = t0 + k;
-            s_c[k][v] = (j < j_end && v < nv) ? kOneOver4Pi * (w[j] * static_cast<double>(g[j * nvec + v0 + v])) : 0.0;
-        }
-        __syncthreads();
-        const int cnt = (j_end - t0 < kMS) ? static_cast<int>(j_end - t0) : kMS;
-        for (int k = 0; k < cnt; ++k) {
-            const double dx = xi - s_x[k], dy = yi - s_y[k];
-            const double r2 = __builtin_fma(dx, dx, dy * dy);
-            const double y = rsqrt_f64(r2);
-            const double q = (t0 + k == i) ? 0.0 : y * (y * y);
+    for (int mb = 0; mb < 2; ++mb) {
+        ti[mb] = t_base + mb * 16 + li;
+        const int64_t tc = (ti[mb] < nt) ? ti[mb] : nt - 1;
+        xi[mb] = tgt_xy[2 * tc];
+        yi[mb] = tgt_xy[2 * tc + 1];
+    }
+    acc_t acc[2][NB];
 #pragma unroll
-            for (int v = 0; v < kNV; ++v) acc[v] = __builtin_fma(q, s_c[k][v], acc[v]);
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = acc_t{0, 0, 0, 0};
+
+    for (int64_t s0 = j_begin; s0 < j_end; s0 += kKS) {
+        __syncthreads();
+        if (tid < kKS) {
+            const int64_t j = s0 + tid;
+            const bool ok = j < j_end;  // padding sources sit far away and carry zero charge
+            s_xy[tid][0] = ok ? src_xy[2 * j] : 1e30;
+            s_xy[tid][1] = ok ? src_xy[2 * j + 1] : 1e30;
+        }
+        for (int e = tid; e < kKS * NV; e += 256) {
+            const int k = e / NV, v = e % NV;
+            const int64_t j = s0 + k;
+            const bool ok = j < j_end && v < nv;
+            if constexpr (SELF) {
+                const double wj = ok ? static_cast<const double *>(src_scale)[j] : 0.0;
+                const double gj = ok ? static_cast<double>(static_cast<const T *>(src_val)[j * nvec + v0 + v]) : 0.0;
+                s_b[0][k][v] = kOneOver4Pi * (wj * gj);
+            } else {
+                double2 Jv = make_double2(0.0, 0.0);
+                double ca = 0.0;
+                if (ok) {
+                    ca = kOneOver4Pi * static_cast<double>(static_cast<const T *>(src_scale)[j]);
+                    Jv = *reinterpret_cast<const double2 *>(static_cast<const double *>(src_val) +
+                                                            (j * nvec + v0 + v) * 2);
+                }
+                s_b[0][k][v] = ca * Jv.x;
+                s_b[NP - 1][k][v] = -(ca * Jv.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < kKS / 4; ++ks) {
+            const int k = ks * 4 + lk;
+            const double2 sxy = *reinterpret_cast<const double2 *>(&s_xy[k][0]);
+            double a0[2], a1[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const double dx = xi[mb] - sxy.x, dy = yi[mb] - sxy.y;
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
+                const double y = rsqrt_f64(r2);
+                const double y3 = y * (y * y);
+                if constexpr (SELF) {
+                    a0[mb] = (s0 + k == ti[mb]) ? 0.0 : y3;
+                    a1[mb] = 0.0;
+                } else {
+                    a0[mb] = dy * y3;
+                    a1[mb] = dx * y3;
+                }
+            }
+            double b0[NB], b1[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                b0[nb] = s_b[0][k][nb * 16 + li];
+                if constexpr (!SELF) b1[nb] = s_b[NP - 1][k][nb * 16 + li];
+            }
+            // every accumulator once per sweep: 2 NB independent MFMAs between dependent ones
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MF::run(a0[mb], b0[nb], acc[mb][nb]);
+            if constexpr (!SELF) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = MF::run(a1[mb], b1[nb], acc[mb][nb]);
+            }
         }
     }
-    if (i < n) {
-        double *dst = partial + (static_cast<int64_t>(blockIdx.y) * n + i) * kNV;
+    double *dst = partial + static_cast<int64_t>(blockIdx.y) * nt * NV;
 #pragma unroll
-        for (int v = 0; v < kNV; ++v) dst[v] = acc[v];
-    }
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = t_base + mb * 16 + MF::row(lane, r);
+            if (i < nt) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) dst[i * NV + nb * 16 + li] = acc[mb][nb][r];
+            }
+        }
 }
 
 template <typename T>
-__global__ void self_field_multi_combine_kernel(const double *__restrict__ partial, int slices, int64_t n,
-                                                int64_t nvec, int64_t v0, int nv, const double *__restrict__ w,
-                                                const double *__restrict__ qdiag, const T *__restrict__ g,
-                                                double alpha, T *__restrict__ out) {
+__global__ void self_field_multi_combine_kernel(const double *__restrict__ partial, int slices, int pstride,
+                                                int64_t n, int64_t nvec, int64_t v0, int nv,
+                                                const double *__restrict__ w, const double *__restrict__ qdiag,
+                                                const T *__restrict__ g, double alpha, T *__restrict__ out) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= n * nv) return;
     const int64_t i = t / nv;
     const int v = static_cast<int>(t - i * nv);
     double s = 0.0;
-    for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * n + i) * kNV + v];
+    for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * n + i) * pstride + v];
     const double d = qdiag[i] * (w[i] * static_cast<double>(g[i * nvec + v0 + v]));
     out[i * nvec + v0 + v] = static_cast<T>(alpha * (d - s));
 }
 
 template <typename T>
-__global__ __launch_bounds__(kMT) void biot_savart_multi_kernel(
-    const double *__restrict__ src_xy, const T *__restrict__ src_areas, const double *__restrict__ src_J,
-    int64_t ns, int64_t nvec, int64_t v0, int nv, int64_t slice_len, const double *__restrict__ tgt_xy,
-    int64_t nt, double dz2, double *__restrict__ partial) {
-    __shared__ double s_x[kMS], s_y[kMS];
-    __shared__ __attribute__((aligned(16))) double s_ab[kMS][2 * kNV];  // (a, b) = (1/4pi) area (Jx, Jy) per vector
-    const int tid = threadIdx.x;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kMT + tid;
-    const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
-    const int64_t j_end = (j_begin + slice_len < ns) ? j_begin + slice_len : ns;
-    const int64_t ic = (i < nt) ? i : nt - 1;
-    const double xi = tgt_xy[2 * ic], yi = tgt_xy[2 * ic + 1];
-    double acc[kNV];
-#pragma unroll
-    for (int v = 0; v < kNV; ++v) acc[v] = 0.0;
-    for (int64_t t0 = j_begin; t0 < j_end; t0 += kMS) {
-        __syncthreads();
-        if (tid < kMS) {
-            const int64_t j = t0 + tid;
-            const bool ok = j < j_end;
-            s_x[tid] = ok ? src_xy[2 * j] : 0.0;
-            s_y[tid] = ok ? src_xy[2 * j + 1] : 0.0;
-        }
-        for (int e = tid; e < kMS * 2 * kNV; e += kMT) {
-            const int k = e / (2 * kNV), c = e % (2 * kNV), v = c >> 1, xyc = c & 1;
-            const int64_t j = t0 + k;
-            double val = 0.0;
-            if (j < j_end && v < nv)
-                val = kOneOver4Pi * static_cast<double>(src_areas[j]) * src_J[(j * nvec + v0 + v) * 2 + xyc];
-            s_ab[k][c] = val;
-        }
-        __syncthreads();
-        const int cnt = (j_end - t0 < kMS) ? static_cast<int>(j_end - t0) : kMS;
-        for (int k = 0; k < cnt; ++k) {
-            const double dx = xi - s_x[k], dy = yi - s_y[k];
-            const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
-            const double y = rsqrt_f64(r2);
-            const double y3 = y * (y * y);
-            const double dyq = dy * y3, dxq = dx * y3;
-#pragma unroll
-            for (int v = 0; v < kNV; ++v)
-                acc[v] = __builtin_fma(s_ab[k][2 * v], dyq, __builtin_fma(-s_ab[k][2 * v + 1], dxq, acc[v]));
-        }
-    }
-    if (i < nt) {
-        double *dst = partial + (static_cast<int64_t>(blockIdx.y) * nt + i) * kNV;
-#pragma unroll
-        for (int v = 0; v < kNV; ++v) dst[v] = acc[v];
-    }
-}
-
-template <typename T>
-__global__ void biot_savart_multi_combine_kernel(const double *__restrict__ partial, int slices, int64_t nt,
-                                                 int64_t nvec, int64_t v0, int nv, T *__restrict__ out,
-                                                 int accumulate) {
+__global__ void biot_savart_multi_combine_kernel(const double *__restrict__ partial, int slices, int pstride,
+                                                 int64_t nt, int64_t nvec, int64_t v0, int nv,
+                                                 T *__restrict__ out, int accumulate) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nt * nv) return;
     const int64_t i = t / nv;
     const int v = static_cast<int>(t - i * nv);
     double s = 0.0;
-    for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * nt + i) * kNV + v];
+    for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * nt + i) * pstride + v];
     T *dst = out + i * nvec + v0 + v;
     if (accumulate) s += static_cast<double>(*dst);
     *dst = static_cast<T>(s);
+}
+
+template <typename T, bool SELF>
+void launch_pair_mfma(int nb, dim3 grid, hipStream_t st, const double *src_xy, const void *src_scale,
+                      const void *src_val, int64_t ns, int64_t nvec, int64_t v0, int nv, int64_t slice_len,
+                      const double *tgt_xy, int64_t nt, double dz2, double *partial) {
+#define SSA_PAIR_CASE(NB)                                                                                       \
+    hipLaunchKernelGGL((pair_mfma_kernel<T, NB, SELF>), grid, dim3(256), 0, st, src_xy, src_scale, src_val, ns, \
+                       nvec, v0, nv, slice_len, tgt_xy, nt, dz2, partial)
+    switch (nb) {
+        case 1: SSA_PAIR_CASE(1); break;
+        case 2: SSA_PAIR_CASE(2); break;
+        case 3: SSA_PAIR_CASE(3); break;
+        default: SSA_PAIR_CASE(4); break;
+    }
+#undef SSA_PAIR_CASE
 }
 
 }  // namespace
@@ -167,7 +223,7 @@ __global__ void biot_savart_multi_combine_kernel(const double *__restrict__ part
 using namespace ssa;
 
 extern "C" size_t ssa_pairwise_multi_workspace_bytes(int64_t nt) {
-    return static_cast<size_t>(kMaxSlicesM) * static_cast<size_t>(nt) * kNV * sizeof(double) + 256;
+    return static_cast<size_t>(kMaxSlicesM) * static_cast<size_t>(nt) * kChunk * sizeof(double) + 256;
 }
 
 extern "C" int ssa_self_field_multi(const double *xy, const double *w, const double *qdiag, const void *g,
@@ -179,23 +235,22 @@ extern "C" int ssa_self_field_multi(const double *xy, const double *w, const dou
     hipStream_t st = as_stream(stream);
     double *partial = static_cast<double *>(workspace);
     int slices = pick_slices_m(n, n);
-    const int64_t slice_len = ceil_div(ceil_div(n, slices), kMS) * kMS;
+    const int64_t slice_len = ceil_div(ceil_div(n, slices), kKS) * kKS;
     slices = static_cast<int>(ceil_div(n, slice_len));
-    const dim3 grid(static_cast<unsigned>(ceil_div(n, kMT)), slices);
-    for (int64_t v0 = 0; v0 < nvec; v0 += kNV) {
-        const int nv = static_cast<int>((nvec - v0 < kNV) ? nvec - v0 : kNV);
+    const dim3 grid(static_cast<unsigned>(ceil_div(n, kTB)), slices);
+    for (int64_t v0 = 0; v0 < nvec; v0 += kChunk) {
+        const int nv = static_cast<int>((nvec - v0 < kChunk) ? nvec - v0 : kChunk);
+        const int nb = (nv + 15) / 16;
         const dim3 cgrid(static_cast<unsigned>(ceil_div(n * nv, 256)));
         if (dtype == SSA_F64) {
-            hipLaunchKernelGGL((self_field_multi_kernel<double>), grid, dim3(kMT), 0, st, xy, w,
-                               static_cast<const double *>(g), n, nvec, v0, nv, slice_len, partial);
-            hipLaunchKernelGGL((self_field_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices, n,
-                               nvec, v0, nv, w, qdiag, static_cast<const double *>(g), alpha,
+            launch_pair_mfma<double, true>(nb, grid, st, xy, w, g, n, nvec, v0, nv, slice_len, xy, n, 0.0, partial);
+            hipLaunchKernelGGL((self_field_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
+                               nb * 16, n, nvec, v0, nv, w, qdiag, static_cast<const double *>(g), alpha,
                                static_cast<double *>(out));
         } else {
-            hipLaunchKernelGGL((self_field_multi_kernel<float>), grid, dim3(kMT), 0, st, xy, w,
-                               static_cast<const float *>(g), n, nvec, v0, nv, slice_len, partial);
-            hipLaunchKernelGGL((self_field_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices, n,
-                               nvec, v0, nv, w, qdiag, static_cast<const float *>(g), alpha,
+            launch_pair_mfma<float, true>(nb, grid, st, xy, w, g, n, nvec, v0, nv, slice_len, xy, n, 0.0, partial);
+            hipLaunchKernelGGL((self_field_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
+                               nb * 16, n, nvec, v0, nv, w, qdiag, static_cast<const float *>(g), alpha,
                                static_cast<float *>(out));
         }
         SSA_RETURN_IF_LAUNCH_FAILED();
@@ -214,24 +269,23 @@ extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas
     hipStream_t st = as_stream(stream);
     double *partial = static_cast<double *>(workspace);
     int slices = pick_slices_m(nt, ns);
-    const int64_t slice_len = ceil_div(ceil_div(ns, slices), kMS) * kMS;
+    const int64_t slice_len = ceil_div(ceil_div(ns, slices), kKS) * kKS;
     slices = static_cast<int>(ceil_div(ns, slice_len));
-    const dim3 grid(static_cast<unsigned>(ceil_div(nt, kMT)), slices);
-    for (int64_t v0 = 0; v0 < nvec; v0 += kNV) {
-        const int nv = static_cast<int>((nvec - v0 < kNV) ? nvec - v0 : kNV);
+    const dim3 grid(static_cast<unsigned>(ceil_div(nt, kTB)), slices);
+    for (int64_t v0 = 0; v0 < nvec; v0 += kChunk) {
+        const int nv = static_cast<int>((nvec - v0 < kChunk) ? nvec - v0 : kChunk);
+        const int nb = (nv + 15) / 16;
         const dim3 cgrid(static_cast<unsigned>(ceil_div(nt * nv, 256)));
         if (dtype == SSA_F64) {
-            hipLaunchKernelGGL((biot_savart_multi_kernel<double>), grid, dim3(kMT), 0, st, src_xy,
-                               static_cast<const double *>(src_areas), src_J, ns, nvec, v0, nv, slice_len, tgt_xy,
-                               nt, dz * dz, partial);
+            launch_pair_mfma<double, false>(nb, grid, st, src_xy, src_areas, src_J, ns, nvec, v0, nv, slice_len,
+                                            tgt_xy, nt, dz * dz, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
-                               nt, nvec, v0, nv, static_cast<double *>(out), accumulate);
+                               nb * 16, nt, nvec, v0, nv, static_cast<double *>(out), accumulate);
         } else {
-            hipLaunchKernelGGL((biot_savart_multi_kernel<float>), grid, dim3(kMT), 0, st, src_xy,
-                               static_cast<const float *>(src_areas), src_J, ns, nvec, v0, nv, slice_len, tgt_xy, nt,
-                               dz * dz, partial);
-            hipLaunchKernelGGL((biot_savart_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices, nt,
-                               nvec, v0, nv, static_cast<float *>(out), accumulate);
+            launch_pair_mfma<float, false>(nb, grid, st, src_xy, src_areas, src_J, ns, nvec, v0, nv, slice_len,
+                                           tgt_xy, nt, dz * dz, partial);
+            hipLaunchKernelGGL((biot_savart_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
+                               nb * 16, nt, nvec, v0, nv, static_cast<float *>(out), accumulate);
         }
         SSA_RETURN_IF_LAUNCH_FAILED();
     }

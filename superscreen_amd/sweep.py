@@ -29,13 +29,16 @@ from .units import field_conversion_factor
 
 
 def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, field_units: str = "mT",
-                iterations: int = 0, return_solutions: bool = True,
+                iterations: int = 0, return_solutions: bool = True, all_iterations: bool = True,
                 _solver: str = "superscreen_amd.solve_sweep") -> Optional[List[List[Solution]]]:
     """Self-consistent solutions for every applied field of a scan.
 
     ``applied_fields``: callables ``f(x, y, z)`` (e.g. :func:`superscreen_amd.ConstantField`) or
     plain numbers (uniform fields in ``field_units``).  Returns ``result[k]`` = the list of
-    ``iterations + 1`` Solutions of field ``k`` (1 for a single film), like ``solve`` would."""
+    ``iterations + 1`` Solutions of field ``k`` (1 for a single film), like ``solve`` would.
+    ``all_iterations=False`` keeps only the final iterate (``solve(...)[-1]``): ``result[k]`` then
+    has one Solution, and the self field -- an output, not an input of the next iteration
+    (``solver/solve_film.py:565-572``) -- is evaluated for the final pass only."""
     import torch
 
     from . import _hip, kernels
@@ -84,7 +87,7 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         B[:, :nvec] = rhs
         return solve_in_place(B)[:, :nvec].contiguous()
 
-    def run_pass(other_d):
+    def run_pass(other_d, want_self_field=True):
         results = {}
         for name in films:
             fd, info, system = fd_of[name], info_of[name], model.film_systems[name]
@@ -108,7 +111,7 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                 gf = solve_columns(lambda B: kernels.lu_solve_permuted(system.factors, B), h)
             kernels.scatter_add(g, system.indices_device, gf, nvec=nvec)
             J = kernels.current_density(*fd.grad, g, nvec=nvec)              # [n, nvec, 2]
-            sf = kernels.self_field_multi(fd.xy, fd.w, fd.qdiag, g)
+            sf = kernels.self_field_multi(fd.xy, fd.w, fd.qdiag, g) if want_self_field else None
             results[name] = (g, J, sf)
         return results
 
@@ -129,22 +132,23 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         return {name: tuple(None if a is None else a.numpy() for a in arrs) for name, arrs in out.items()}
 
     trace = []
-    results = run_pass(None)
-    if return_solutions:
+    n_pass = iterations if (len(films) >= 2 and iterations >= 1) else 0
+    results = run_pass(None, all_iterations or n_pass == 0)
+    if return_solutions and (all_iterations or n_pass == 0):
         trace.append(to_host(results, None))
-    if len(films) >= 2 and iterations >= 1:
-        for _ in range(iterations):
-            other_d = {name: torch.zeros((fd_of[name].n, nvec), dtype=fd_of[name].tdtype, device=fd_of[name].device)
-                       for name in films}
-            for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
-                if src == tgt:
-                    continue
-                s, t = fd_of[src], fd_of[tgt]
-                kernels.biot_savart_multi(s.xy, s.w_t, results[src][1], t.xy,
-                                          info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True)
-            results = run_pass(other_d)
-            if return_solutions:
-                trace.append(to_host(results, other_d))
+    for it in range(n_pass):
+        last = it == n_pass - 1
+        other_d = {name: torch.zeros((fd_of[name].n, nvec), dtype=fd_of[name].tdtype, device=fd_of[name].device)
+                   for name in films}
+        for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
+            if src == tgt:
+                continue
+            s, t = fd_of[src], fd_of[tgt]
+            kernels.biot_savart_multi(s.xy, s.w_t, results[src][1], t.xy,
+                                      info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True)
+        results = run_pass(other_d, all_iterations or last)
+        if return_solutions and (all_iterations or last):
+            trace.append(to_host(results, other_d))
     if not return_solutions:
         torch.cuda.synchronize()
         return None

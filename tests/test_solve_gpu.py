@@ -518,6 +518,13 @@ def test_solve_sweep_equals_looped_solve(method):
                 assert np.array_equal(fa.applied_field, fb.applied_field)
                 if fb.field_from_other_films is not None:
                     assert relerr(fa.field_from_other_films, fb.field_from_other_films) < 1e-11
+    final = sc.solve_sweep(model, fields, field_units="mT", iterations=3, all_iterations=False)
+    assert all(len(s) == 1 for s in final)
+    for sols, (last,) in zip(sweep, final):
+        for name in device.films:
+            fa, fb = last.film_solutions[name], sols[-1].film_solutions[name]
+            assert np.array_equal(fa.stream, fb.stream) and np.array_equal(fa.self_field, fb.self_field)
+            assert np.array_equal(fa.field_from_other_films, fb.field_from_other_films)
     assert sc.solve_sweep(model, [], iterations=1) == []
     single = synthetic.make_stack_device(10, ("disk",))
     m1 = sc.factorize_model(device=single, current_units="uA")

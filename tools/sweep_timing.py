@@ -14,11 +14,13 @@ nf = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 device = synthetic.make_stack_device(K, ("washer", "disk"), solve_dtype="float64")
 model = sc.factorize_model(device=device, current_units="uA")
 fields = [0.05 * (k + 1) for k in range(nf)]
-for tag, ret in (("with Solutions", True), ("device only", False)):
-    sc.solve_sweep(model, fields[:16], iterations=10, return_solutions=ret)
+for tag, ret, every in (("Solutions of every iteration", True, True), ("final Solutions", True, False),
+                        ("device only, every iteration's self field", False, True),
+                        ("device only, final self field", False, False)):
+    sc.solve_sweep(model, fields[:16], iterations=10, return_solutions=ret, all_iterations=every)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sc.solve_sweep(model, fields, iterations=10, return_solutions=ret)
+    sc.solve_sweep(model, fields, iterations=10, return_solutions=ret, all_iterations=every)
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     print(f"solve_sweep {nf} fields, 10 iterations ({tag}): {t*1e3:.1f} ms -> {nf/t:.1f} solves/s")
