@@ -286,6 +286,17 @@ def main():
             sc.solve(model=model, applied_field=sc.ConstantField(0.3 + i), iterations=args.iterations)
         torch.cuda.synchronize()
         extras["warm_self_consistent_solves_per_s"] = 3 / (time.perf_counter() - t1)
+        # BASELINE config 4: a 64-value applied-field scan of the same device carried as the columns of
+        # one multi-right-hand-side solve (solve_sweep; final iterate of every field returned as
+        # Solutions on the host).  Reported per GPU; scans shard across ranks without a collective.
+        scan = [0.05 * (k + 1) for k in range(64)]
+        sc.solve_sweep(model, scan[:8], iterations=args.iterations, all_iterations=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        swept = sc.solve_sweep(model, scan, iterations=args.iterations, all_iterations=False)
+        torch.cuda.synchronize()
+        extras["field_sweep_64_values_solves_per_s"] = len(swept) / (time.perf_counter() - t1)
+        del swept
         # iterations needed for max|dg|/max|g| < 1e-8 (the reference has no convergence test)
         conv = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=200, tolerance=1e-8,
                         return_solutions=True)
