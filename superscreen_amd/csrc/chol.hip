@@ -40,6 +40,10 @@ int gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int
 int gemm_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda,
              const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st);
 int gemm_splitk_pick(int64_t M, int64_t N, int64_t K);
+size_t gemm_rhs_partial_elems(int64_t m_max, int64_t nrhs);
+bool gemm_skinny_ok(int64_t N, int64_t K, const void *A, int64_t lda);
+int gemm_skinny_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                    int64_t ldb, double beta, double *C, int64_t ldc, int tri, double *partial, hipStream_t st);
 int gemm_splitk_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
                     int64_t ldb, double beta, double *C, int64_t ldc, int splits, double *partial, hipStream_t st);
 int gemm_splitk_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
@@ -82,13 +86,16 @@ inline int gemm_nn_t(int64_t M, int64_t N, int64_t K, double alpha, const float 
                      const float *B, int64_t ldb, double beta, float *C, int64_t ldc, hipStream_t st) {
     return gemm_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
 }
-// skinny product of the multi-right-hand-side solves: split-K when there are too few tiles
+// product of the multi-right-hand-side solves: <= 64 columns stream the factor once (skinny kernel,
+// tri = 1 / 2: A lower / upper triangular), more columns run on the tiled GEMM with split-K
 inline int gemm_rhs_t(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
-                      int64_t ldb, double beta, double *C, int64_t ldc, double *partial, hipStream_t st) {
+                      int64_t ldb, double beta, double *C, int64_t ldc, int tri, double *partial, hipStream_t st) {
+    if (gemm_skinny_ok(N, K, A, lda))
+        return gemm_skinny_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, partial, st);
     return gemm_splitk_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, gemm_splitk_pick(M, N, K), partial, st);
 }
 inline int gemm_rhs_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
-                      int64_t ldb, double beta, float *C, int64_t ldc, float *partial, hipStream_t st) {
+                      int64_t ldb, double beta, float *C, int64_t ldc, int, float *partial, hipStream_t st) {
     return gemm_splitk_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, gemm_splitk_pick(M, N, K), partial, st);
 }
 inline int gemv_n_t(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
@@ -460,10 +467,10 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
             if (rc == SSA_OK && below > 0)
                 rc = gemv_n_t(L + (r0 + kb) * lda + r0, below, kb, lda, X + r0, B + r0 + kb, -1.0, 1.0, st);
         } else {
-            rc = gemm_rhs_t(kb, nrhs, kb, 1.0, inv, SNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, partial, st);
+            rc = gemm_rhs_t(kb, nrhs, kb, 1.0, inv, SNB, B + r0 * ldb, ldb, 0.0, X + r0 * ldx, ldx, 1, partial, st);
             if (rc == SSA_OK && below > 0)
                 rc = gemm_rhs_t(below, nrhs, kb, -1.0, L + (r0 + kb) * lda + r0, lda, X + r0 * ldx, ldx, 1.0,
-                                B + (r0 + kb) * ldb, ldb, partial, st);
+                                B + (r0 + kb) * ldb, ldb, 0, partial, st);
         }
         if (rc != SSA_OK) return rc;
     }
@@ -475,9 +482,9 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
             rc = trmv_t(invT, kb, kb, SNB, X + r0, B + r0, 1.0, 0.0, 2, st);
             if (rc == SSA_OK && r0 > 0) rc = gemv_n_t(U, r0, kb, lda, B + r0, X, -1.0, 1.0, st);
         } else {
-            rc = gemm_rhs_t(kb, nrhs, kb, 1.0, invT, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, partial, st);
+            rc = gemm_rhs_t(kb, nrhs, kb, 1.0, invT, SNB, X + r0 * ldx, ldx, 0.0, B + r0 * ldb, ldb, 2, partial, st);
             if (rc == SSA_OK && r0 > 0)
-                rc = gemm_rhs_t(r0, nrhs, kb, -1.0, U, lda, B + r0 * ldb, ldb, 1.0, X, ldx, partial, st);
+                rc = gemm_rhs_t(r0, nrhs, kb, -1.0, U, lda, B + r0 * ldb, ldb, 1.0, X, ldx, 0, partial, st);
         }
         if (rc != SSA_OK) return rc;
     }
@@ -569,12 +576,10 @@ extern "C" int ssa_chol_factor(void *A, int64_t n, int64_t lda, int32_t *info, v
 }
 
 extern "C" size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype) {
-    // X, padded B, and (several right-hand sides) the split-K partial products: gemm_splitk_pick keeps
-    // tiles * pieces < 768 with <= 16 pieces, so pieces * M <= min(16 np, 768 * 128) rows
+    // X, padded B, and (several right-hand sides) the partial products of the split-K / skinny GEMMs
     const size_t np = static_cast<size_t>(ssa_chol_padded_n(n));
-    const size_t part = 16 * np < 98304 ? 16 * np : 98304;
-    const size_t rows = 2 * np + (nrhs > 1 ? part : 0);
-    return rows * static_cast<size_t>(nrhs) * (dtype == SSA_F64 ? 8 : 4) + 256;
+    const size_t elems = 2 * np * static_cast<size_t>(nrhs) + (nrhs > 1 ? gemm_rhs_partial_elems(np, nrhs) : 0);
+    return elems * (dtype == SSA_F64 ? 8 : 4) + 256;
 }
 
 extern "C" int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B,

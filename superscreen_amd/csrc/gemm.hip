@@ -466,6 +466,162 @@ int gemm_splitk_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *
     return gemm_splitk<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, splits, partial, st);
 }
 
+
+// ---- tall-and-skinny products  C[M, N <= 64] = alpha A[M, K] B[K, N] + beta C  (few right-hand sides:
+// the factor A is streamed from HBM once, the product is memory-bound like a GEMV chain).  No LDS image
+// of A: lane (r = l & 15, g = l >> 4) loads 16 B of row r straight from global memory, the MFMA k index is
+// permuted (k = 2 g + (m & 1) + 8 (m >> 1) for the m-th MFMA of a 16-wide k step) identically for the B
+// operand, which is read from a 64-row LDS image shared by the four waves (64 rows of C) of a workgroup.
+// K is cut into pieces (grid.y) so that about four workgroups per CU exist; pieces go to `partial`
+// ([pieces][M][16 NB]) and are reduced in a fixed order.  tri = 1 / 2: A is lower / upper triangular
+// (inverted diagonal blocks): k beyond / before the rows of the workgroup is skipped.
+constexpr int kSkinnyRows = 64;  // rows of C per workgroup
+constexpr int kSkinnyKC = 32;    // k granularity of the pieces (LDS image: 64 rows, 32 for > 32 columns)
+
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(int64_t M, int N, int64_t K, int64_t kpiece, int tri,
+                                                          const double *__restrict__ A, int64_t lda,
+                                                          const double *__restrict__ B, int64_t ldb,
+                                                          double *__restrict__ partial) {
+    using MF = Mfma<double>;
+    constexpr int NV = 16 * NB, SBS = NV + 8;  // row stride = 8 mod 16 doubles: rows 2 g land in distinct bank halves
+    constexpr int KC = NB <= 2 ? 64 : 32;      // k rows per LDS image (register budget: 2 x KC / 8 + 4 NB + ... pairs)
+    __shared__ __attribute__((aligned(16))) double s_b[KC][SBS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t m_blk = static_cast<int64_t>(blockIdx.x) * kSkinnyRows;
+    const int64_t m0 = m_blk + wave * 16;
+    int64_t kb = static_cast<int64_t>(blockIdx.y) * kpiece;
+    int64_t ke = (kb + kpiece < K) ? kb + kpiece : K;
+    if (tri == 1 && ke > m_blk + kSkinnyRows) ke = m_blk + kSkinnyRows;
+    if (tri == 2 && kb < m_blk) kb = m_blk;
+    const int64_t row = (m0 + r < M) ? m0 + r : M - 1;
+    const double *arow = A + row * lda + 2 * g;
+    MF::acc_t acc[NB][2];  // two chains per column block: consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb][0] = acc[nb][1] = MF::acc_t{0, 0, 0, 0};
+
+    constexpr int STEPS = KC / 16;
+    double2 cur[2 * STEPS], nxt[2 * STEPS];
+    auto load_a = [&](int64_t kc, double2 (&dst)[2 * STEPS]) {
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+            const int64_t k = kc + 16 * t;
+            if (k < ke) {  // K and the piece bounds are multiples of 16
+                dst[2 * t] = *reinterpret_cast<const double2 *>(arow + k);
+                dst[2 * t + 1] = *reinterpret_cast<const double2 *>(arow + k + 8);
+            } else {
+                dst[2 * t] = make_double2(0.0, 0.0);
+                dst[2 * t + 1] = make_double2(0.0, 0.0);
+            }
+        }
+    };
+    // the B image of the next chunk waits in registers too: nothing but LDS writes between the barriers
+    constexpr int BPT = KC * NV / 256;
+    double breg[BPT];
+    auto load_b = [&](int64_t kc) {
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const int e = tid + 256 * u, kr = e / NV, c = e % NV;
+            const int64_t k = kc + kr;
+            breg[u] = (k < ke && c < N) ? B[k * ldb + c] : 0.0;
+        }
+    };
+    if (kb < ke) {
+        load_a(kb, cur);
+        load_b(kb);
+    }
+    for (int64_t kc = kb; kc < ke; kc += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const int e = tid + 256 * u;
+            s_b[e / NV][e % NV] = breg[u];
+        }
+        __syncthreads();
+        if (kc + KC < ke) load_b(kc + KC);
+        if (kc + KC < ke) load_a(kc + KC, nxt);
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+            const double *sb = &s_b[16 * t + 2 * g][r];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][0] = MF::run(cur[2 * t].x, sb[nb * 16], acc[nb][0]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][1] = MF::run(cur[2 * t].y, sb[SBS + nb * 16], acc[nb][1]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][0] = MF::run(cur[2 * t + 1].x, sb[8 * SBS + nb * 16], acc[nb][0]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb][1] = MF::run(cur[2 * t + 1].y, sb[9 * SBS + nb * 16], acc[nb][1]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2 * STEPS; ++t) cur[t] = nxt[t];
+    }
+    double *dst = partial + static_cast<int64_t>(blockIdx.y) * M * NV;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = m0 + MF::row(lane, q);
+        if (i < M) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) dst[i * NV + nb * 16 + r] = acc[nb][0][q] + acc[nb][1][q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const double *__restrict__ partial, int pieces, int nv,
+                                                            int64_t M, int N, double alpha, double beta,
+                                                            double *__restrict__ C, int64_t ldc) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int64_t i = idx / N;
+    const int c = static_cast<int>(idx - i * N);
+    double acc = 0.0;
+    for (int p = 0; p < pieces; ++p) acc += partial[(static_cast<int64_t>(p) * M + i) * nv + c];
+    double *dst = C + i * ldc + c;
+    *dst = (beta == 0.0) ? alpha * acc : alpha * acc + beta * *dst;
+}
+
+// scratch elements a multi-right-hand-side solve needs for its products of <= m_max rows (split-K or skinny)
+size_t gemm_rhs_partial_elems(int64_t m_max, int64_t nrhs) {
+    const size_t m = static_cast<size_t>(m_max);
+    const size_t splitk = (16 * m < 98304 ? 16 * m : 98304) * static_cast<size_t>(nrhs);
+    const size_t skinny = nrhs <= 64 ? (65536 + m) * 64 : 0;
+    return (splitk > skinny ? splitk : skinny) + 64;
+}
+
+bool gemm_skinny_ok(int64_t N, int64_t K, const void *A, int64_t lda) {
+    return N >= 1 && N <= 64 && K > 0 && K % 16 == 0 && lda % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0;
+}
+
+int gemm_skinny_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                    int64_t ldb, double beta, double *C, int64_t ldc, int tri, double *partial, hipStream_t st) {
+    if (M <= 0) return SSA_OK;
+    if (!gemm_skinny_ok(N, K, A, lda) || !partial) return SSA_ERR_INVALID_ARGUMENT;
+    const int nb = static_cast<int>((N + 15) / 16);
+    const int64_t rb = ceil_div(M, kSkinnyRows);
+    int64_t pieces = ceil_div(1024, rb);
+    const int64_t max_pieces = ceil_div(K, kSkinnyKC);
+    if (pieces > max_pieces) pieces = max_pieces;
+    const int64_t kpiece = ceil_div(ceil_div(K, pieces), kSkinnyKC) * kSkinnyKC;
+    pieces = ceil_div(K, kpiece);
+    const dim3 grid(static_cast<unsigned>(rb), static_cast<unsigned>(pieces));
+#define SSA_SKINNY_CASE(NB)                                                                                   \
+    hipLaunchKernelGGL((skinny_gemm_kernel<NB>), grid, dim3(256), 0, st, M, static_cast<int>(N), K, kpiece, tri, \
+                       A, lda, B, ldb, partial)
+    switch (nb) {
+        case 1: SSA_SKINNY_CASE(1); break;
+        case 2: SSA_SKINNY_CASE(2); break;
+        case 3: SSA_SKINNY_CASE(3); break;
+        default: SSA_SKINNY_CASE(4); break;
+    }
+#undef SSA_SKINNY_CASE
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(skinny_reduce_kernel, dim3(static_cast<unsigned>(ceil_div(total, 256))), dim3(256), 0, st,
+                       partial, static_cast<int>(pieces), nb * 16, M, static_cast<int>(N), alpha, beta, C, ldc);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
 }  // namespace ssa
 
 using namespace ssa;

@@ -77,9 +77,12 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         applied_d[name] = torch.from_numpy(H).to(fd_of[name].device)
 
     def solve_columns(solve_in_place, rhs):
-        """The block triangular solves run on 128 x 128 MFMA tiles: pad the right-hand sides with
-        zero columns to a multiple of 128 so that every tile is a full one (the guarded edge path is
-        several times slower than the extra flops cost)."""
+        """float64, <= 64 fields: the skinny kernel streams the factor once, any column count.  Otherwise
+        the block triangular solves run on 128 x 128 MFMA tiles: pad the right-hand sides with zero
+        columns to a multiple of 128 so that every tile is a full one (the guarded edge path is several
+        times slower than the extra flops cost)."""
+        if nvec <= 64 and rhs.dtype == torch.float64:
+            return solve_in_place(rhs)
         npad = -(-nvec // 128) * 128
         if npad == nvec:
             return solve_in_place(rhs)

@@ -321,7 +321,7 @@ def test_cholesky_block_solves(K, n):
     Lref = np.linalg.cholesky(S)
     assert relerr(np.tril(F), Lref) < 1e-12
     assert np.array_equal(np.triu(F, 1), np.tril(F, -1).T)  # the mirror is a copy, not a recomputation
-    for nrhs in (1, 3):
+    for nrhs in (1, 3, 33, 64, 130):   # GEMV chain | skinny kernel (1, 3, 4 column blocks) | tiled GEMM + split-K
         b = rng.standard_normal((n, nrhs))
         x = K.chol_solve(f, dev(b[:, 0].copy()) if nrhs == 1 else dev(b)).cpu().numpy().reshape(n, nrhs)
         assert relerr(S @ x, b) < 1e-11
@@ -425,7 +425,7 @@ def test_lu_block_solves(K, n):
     lu_ref, piv_ref = la.lu_factor(A)
     assert np.array_equal(f.ipiv.cpu().numpy(), piv_ref)
     assert relerr(f.lu.cpu().numpy()[:, :n], lu_ref) < 1e-11
-    for nrhs in (1, 2):
+    for nrhs in (1, 2, 20, 70):
         b = rng.standard_normal((n, nrhs))
         x = K.lu_solve(f, dev(b[:, 0].copy()) if nrhs == 1 else dev(b)).cpu().numpy().reshape(n, nrhs)
         assert relerr(A @ x, b) < 1e-11
