@@ -400,6 +400,27 @@ class Device:
             return result[0]
         return result
 
+    def __eq__(self, other) -> bool:
+        """Same name, layers, films, holes, terminals, abstract regions and length units, in any
+        order (``device/device.py:1048-1071``); meshes are not compared."""
+        if other is self:
+            return True
+        if not isinstance(other, Device):
+            return False
+
+        def same(first, second):
+            return sorted(first, key=lambda x: x.name) == sorted(second, key=lambda x: x.name)
+
+        return (self.name == other.name
+                and same(self.layers.values(), other.layers.values())
+                and same(self.films.values(), other.films.values())
+                and same(self.holes.values(), other.holes.values())
+                and self.terminals == other.terminals
+                and same(self.abstract_regions.values(), other.abstract_regions.values())
+                and self.length_units == other.length_units)
+
+    __hash__ = None
+
     def __repr__(self) -> str:
         return (f"Device({self.name!r}, layers={list(self.layers)!r}, films={list(self.films)!r}, "
                 f"holes={list(self.holes)!r}, length_units={self.length_units!r})")

@@ -153,6 +153,47 @@ class Solution:
         q = Quantity(J, default_units).to(units)
         return q if with_units else q.magnitude
 
+    def current_through_path(self, path_coords: np.ndarray, *, film: str, interp_method: str = "linear",
+                             units: Optional[str] = None, with_units: bool = True):
+        """Total current crossing a path (``solution.py:321-362``): J at the edge centres, dotted with
+        the edge normals ``dr x z`` (``geometry.py:12-29``), times the edge lengths, summed with the
+        reference's unit-spacing trapezoid rule."""
+        device = self.device
+        units = units or self.current_units
+        path_coords = np.asarray(path_coords, dtype=float)
+        centres = (path_coords[:-1] + path_coords[1:]) / 2
+        J_edge = self.interp_current_density(centres, film=film, method=interp_method, with_units=False)
+        dr = np.diff(path_coords, axis=0)
+        lengths = np.linalg.norm(dr, axis=1)
+        normals = np.stack([dr[:, 1], -dr[:, 0]], axis=1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            normals = normals / lengths[:, None]
+        J_dot_n = np.sum(J_edge * normals, axis=1)
+        total = Quantity(np.trapezoid(J_dot_n * lengths), self.current_units).to(units)
+        return total if with_units else total.magnitude
+
+    def equals(self, other, require_same_timestamp: bool = False) -> bool:
+        """``solution.py:1089-1126``: same device, units, currents, applied field, vortices and film
+        solutions (to ``FilmSolution.is_close`` tolerances)."""
+        if other is self:
+            return True
+        if not isinstance(other, Solution):
+            return False
+        if not (self.device == other.device and self.field_units == other.field_units
+                and self.current_units == other.current_units
+                and self.circulating_currents == other.circulating_currents
+                and getattr(self, "terminal_currents", None) == getattr(other, "terminal_currents", None)
+                and self.applied_field_func == other.applied_field_func and self.vortices == other.vortices):
+            return False
+        if require_same_timestamp and self.time_created != other.time_created:
+            return False
+        return self.film_solutions == other.film_solutions
+
+    def __eq__(self, other) -> bool:
+        return self.equals(other, require_same_timestamp=True)
+
+    __hash__ = None
+
     def interp_field(self, positions: np.ndarray, *, film: str, dataset: str = "field", method: str = "linear",
                      units: Optional[str] = None, with_units: bool = False):
         """Interpolates the z component of a field inside a film (``solution.py:364-428``)."""

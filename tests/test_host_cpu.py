@@ -193,3 +193,37 @@ def test_mutual_inductance_argument_checks():
         device.mutual_inductance_matrix(hole_polygon_mapping={"nope": tiny})
     with pytest.raises(ValueError, match="not completely contained"):
         device.mutual_inductance_matrix(hole_polygon_mapping={"hole0": tiny})
+
+
+def test_solution_current_through_path_and_equality():
+    """Solution.current_through_path (solution.py:321-362) and equals / __eq__ (:1089-1129) are host
+    logic: checked on a hand-made Solution whose sheet current is uniform, J = (0, 2)."""
+    from superscreen_amd.solution import FilmSolution, Solution
+
+    device = synthetic.make_stack_device(6, ("disk",))
+    n = len(device.meshes["disk0"].sites)
+
+    def make(J, stream=0.0):
+        fs = FilmSolution(stream=np.full(n, stream), current_density=J, applied_field=np.ones(n), self_field=np.zeros(n),
+                          field_from_other_films=None)
+        return Solution(device=device, film_solutions={"disk0": fs}, applied_field_func=sc.ConstantField(1.0),
+                        field_units="mT", current_units="uA")
+
+    a = make(np.tile([0.0, 2.0], (n, 1)))
+    # path along +x from -1 to 1 inside the film: the normal dr x z of every edge is (0, -1)
+    xs = np.linspace(-1.0, 1.0, 41)
+    path = np.stack([xs, np.zeros_like(xs)], axis=1)
+    edge = np.diff(xs)
+    products = -2.0 * edge                      # J . n * length per edge
+    expect = np.trapezoid(products)             # the reference sums the per-edge products with np.trapezoid
+    assert a.current_through_path(path, film="disk0", with_units=False) == pytest.approx(expect, rel=1e-12)
+    q = a.current_through_path(path, film="disk0", units="mA")
+    assert q.magnitude == pytest.approx(expect * 1e-3, rel=1e-12)
+    # a path along +y sees no current crossing it
+    assert abs(a.current_through_path(path[:, ::-1], film="disk0", with_units=False)) < 1e-12
+
+    b = make(np.tile([0.0, 2.0], (n, 1)))
+    assert a.equals(b) and a.equals(a) and not (a == b)        # __eq__ also wants the same time stamp
+    # FilmSolution.is_close compares stream and fields, not the current density (solution.py:166-185)
+    assert not a.equals(make(np.tile([0.0, 2.0], (n, 1)), stream=0.5)) and not a.equals("solution")
+    assert a.device == device and device == device.copy() and device != synthetic.make_stack_device(6, ("washer",))

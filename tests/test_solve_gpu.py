@@ -530,3 +530,38 @@ def test_solve_sweep_equals_looped_solve(method, dtype, tol):
     single = synthetic.make_stack_device(10, ("disk",))
     m1 = sc.factorize_model(device=single, current_units="uA")
     assert [len(s) for s in sc.solve_sweep(m1, [1.0, 2.0], iterations=5)] == [1, 1]   # one film: no Jacobi loop
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pre_factorize", [False, True])
+def test_circulating_current_value(pre_factorize):
+    """The reference's own physics test (``test/test_solve.py:96-183``): a ring carrying a circulating
+    current of 1 mA, no applied field -- the current crossing any radial cut of the ring is 1000 uA to
+    5 %, from ``Solution.current_through_path`` and from the interpolated sheet current."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    K = 40
+    device = synthetic.make_stack_device(K, ("washer",), Lambda=0.5)
+    Kf = synthetic.film_rings(K)
+    dr = 5.0 / (Kf + 0.5)
+    r_hole, r_film = (Kf // 3 + 0.5) * dr, 5.0
+    cc = {"hole0": "1 mA"}
+    if pre_factorize:
+        model = sc.factorize_model(device=device, circulating_currents=cc, current_units="uA")
+        sols = sc.solve(model=model, applied_field=sc.ConstantField(0), field_units="mT", iterations=1)
+    else:
+        sols = sc.solve(device=device, applied_field=sc.ConstantField(0), circulating_currents=cc,
+                        field_units="mT", current_units="uA", iterations=1)
+    assert isinstance(sols, list) and len(sols) == 1
+    solution = sols[0]
+    xs = np.linspace(r_hole - 0.1, r_film + 0.1, 1001)
+    positions = np.stack([xs, np.zeros_like(xs)], axis=1)
+    for angle, axis in [(0, 1), (90, 0), (180, 1), (270, 0)]:
+        c, s = np.cos(np.radians(angle)), np.sin(np.radians(angle))
+        coords = positions @ np.array([[c, -s], [s, c]]).T
+        current = solution.current_through_path(coords, film="washer0", units="uA", with_units=False)
+        assert np.isclose(abs(current), 1000, rtol=5e-2)
+        j = solution.interp_current_density(coords, film="washer0", units="uA / um", with_units=False)
+        seg = np.linalg.norm(np.diff(coords, axis=0), axis=1)
+        assert np.isclose(abs(np.sum(j[1:, axis] * seg)), 1000, rtol=5e-2)
