@@ -565,3 +565,33 @@ def test_circulating_current_value(pre_factorize):
         j = solution.interp_current_density(coords, film="washer0", units="uA / um", with_units=False)
         seg = np.linalg.norm(np.diff(coords, axis=0), axis=1)
         assert np.isclose(abs(np.sum(j[1:, axis] * seg)), 1000, rtol=5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hole_radius,field", [(0.0, 0.0), (0.0, 0.002), (0.0, -0.001), (0.8, 0.0)])
+def test_transport_current_through_cross_sections(hole_radius, field):
+    """Physics check in the manner of the reference's ``test/test_transport.py:203-249``: the current
+    crossing any full cross-section of a strip equals the terminal current to 5 %, with an applied
+    field of the reference test's size (uT; screening currents integrate to zero across the strip) and with a hole carrying a
+    circulating current (it adds to one side of the hole and subtracts from the other)."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_strip_device(60, 24, Lambda=0.3, hole_radius=hole_radius)
+    circ = {"hole": 1.0} if hole_radius > 0 else None
+    sol = sc.solve(device, terminal_currents={"strip": {"source": "2 uA", "drain": "-2 uA"}},
+                   circulating_currents=circ, applied_field=sc.ConstantField(field), field_units="mT",
+                   current_units="uA")[-1]
+    ys = np.linspace(-2.0, 2.0, 401)
+    for x0 in (-3.0, 0.0 if hole_radius == 0 else 2.0, 3.5):
+        section = np.stack([np.full_like(ys, x0), ys], axis=1)
+        current = sol.current_through_path(section, film="strip", units="uA", with_units=False)
+        assert np.isclose(abs(current), 2.0, rtol=5e-2)
+    if hole_radius > 0:
+        # cuts from the centre of the hole to either edge of the strip at x = 0: I/2 -+ the circulating current
+        up = np.stack([np.zeros(201), np.linspace(0.0, 2.0, 201)], axis=1)
+        down = np.stack([np.zeros(201), np.linspace(-2.0, 0.0, 201)], axis=1)
+        i_up = sol.current_through_path(up, film="strip", units="uA", with_units=False)
+        i_down = sol.current_through_path(down, film="strip", units="uA", with_units=False)
+        assert np.isclose(abs(i_up + i_down), 2.0, rtol=5e-2)
+        assert np.isclose(abs(i_up - i_down), 2.0, rtol=8e-2)      # the 1 uA circulating current, twice
