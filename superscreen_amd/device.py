@@ -73,6 +73,32 @@ class Layer:
     def copy(self) -> "Layer":
         return deepcopy(self)
 
+    def to_hdf5(self, h5group) -> None:
+        """``device/layer.py:108-116``."""
+        from .io import serialize_obj
+
+        h5group.attrs["name"] = self.name
+        h5group.attrs["z0"] = self.z0
+        if self.thickness is not None:
+            h5group.attrs["thickness"] = self.thickness
+        if self.london_lambda is not None:
+            serialize_obj(h5group, self.london_lambda, "london_lambda", attr=True)
+        else:
+            serialize_obj(h5group, self.Lambda, "Lambda", attr=True)
+
+    @staticmethod
+    def from_hdf5(h5group) -> "Layer":
+        """``device/layer.py:118-138``."""
+        from .io import deserialize_obj
+
+        Lambda = london_lambda = None
+        if "london_lambda" in h5group.attrs or "london_lambda.pickle" in h5group.attrs:
+            london_lambda = deserialize_obj(h5group, "london_lambda", attr=True)
+        else:
+            Lambda = deserialize_obj(h5group, "Lambda", attr=True)
+        return Layer(h5group.attrs["name"], Lambda=Lambda, london_lambda=london_lambda,
+                     thickness=h5group.attrs.get("thickness", None), z0=h5group.attrs["z0"])
+
     def __eq__(self, other) -> bool:
         if other is self:
             return True
@@ -160,6 +186,20 @@ class Polygon:
         if index:
             return np.where(mask)[0]
         return mask
+
+    def to_hdf5(self, h5group) -> None:
+        """``device/polygon.py:621-626``."""
+        if self.name:
+            h5group.attrs["name"] = self.name
+        if self.layer:
+            h5group.attrs["layer"] = self.layer
+        h5group["points"] = self.points
+
+    @staticmethod
+    def from_hdf5(h5group) -> "Polygon":
+        """``device/polygon.py:628-634``."""
+        return Polygon(name=h5group.attrs.get("name", None), layer=h5group.attrs.get("layer", None),
+                       points=np.asarray(h5group["points"]))
 
     def copy(self) -> "Polygon":
         return Polygon(self.name, layer=self.layer, points=self._points.copy())
@@ -399,6 +439,62 @@ class Device:
             assert len(result) == 1
             return result[0]
         return result
+
+    def to_hdf5(self, path_or_group, save_mesh: bool = True, compress: bool = True) -> None:
+        """Serializes the device (``device/device.py:936-977``): same group / attribute names as the
+        reference's HDF5 layout, on h5py or on the ``.npz`` container of :mod:`superscreen_amd.io`."""
+        from contextlib import nullcontext
+
+        from . import io
+
+        ctx = nullcontext(path_or_group) if io.is_group(path_or_group) else io.open_file(path_or_group, "x")
+        with ctx as h5group:
+            h5group.attrs["name"] = self.name
+            h5group.attrs["length_units"] = self.length_units
+            h5group.attrs["solve_dtype"] = str(self.solve_dtype)
+            groups = {key: h5group.create_group(key)
+                      for key in ("layers", "films", "holes", "terminals", "abstract_regions")}
+            for name, layer in self.layers.items():
+                layer.to_hdf5(groups["layers"].create_group(name))
+            for key, polygons in (("films", self.films), ("holes", self.holes),
+                                  ("abstract_regions", self.abstract_regions)):
+                for name, polygon in polygons.items():
+                    polygon.to_hdf5(groups[key].create_group(name))
+            for film_name, terminals in self.terminals.items():
+                grp = groups["terminals"].create_group(film_name)
+                for i, terminal in enumerate(terminals):
+                    terminal.to_hdf5(grp.create_group(str(i)))
+            if save_mesh and self.meshes:
+                mesh_grp = h5group.create_group("mesh")
+                for name, mesh in self.meshes.items():
+                    mesh.to_hdf5(mesh_grp.create_group(name), compress=compress)
+
+    @staticmethod
+    def from_hdf5(path_or_group) -> "Device":
+        """``device/device.py:979-1016``."""
+        from contextlib import nullcontext
+
+        from . import io
+        from .mesh import Mesh
+
+        ctx = nullcontext(path_or_group) if io.is_group(path_or_group) else io.open_file(path_or_group, "r")
+        with ctx as h5group:
+            terminals = {}
+            for film, grp in h5group["terminals"].items():
+                terminals[film] = [Polygon.from_hdf5(grp[str(i)]) for i in range(len(grp))]
+            device = Device(
+                name=h5group.attrs["name"],
+                layers=[Layer.from_hdf5(grp) for grp in h5group["layers"].values()],
+                films=[Polygon.from_hdf5(grp) for grp in h5group["films"].values()],
+                holes=[Polygon.from_hdf5(grp) for grp in h5group["holes"].values()],
+                terminals=terminals or None,
+                abstract_regions=[Polygon.from_hdf5(grp) for grp in h5group["abstract_regions"].values()],
+                length_units=h5group.attrs["length_units"],
+                solve_dtype=h5group.attrs["solve_dtype"],
+            )
+            if "mesh" in h5group:
+                device.meshes = {name: Mesh.from_hdf5(grp) for name, grp in h5group["mesh"].items()}
+            return device
 
     def __eq__(self, other) -> bool:
         """Same name, layers, films, holes, terminals, abstract regions and length units, in any

@@ -154,6 +154,30 @@ class Mesh:
     def find_boundary_indices(elements: np.ndarray) -> np.ndarray:
         return fem.boundary_indices(np.asarray(elements))
 
+    def to_hdf5(self, h5group, compress: bool = True) -> None:
+        """``device/mesh.py:250-264``: sites and elements; with ``compress=False`` also the derived
+        arrays (the reference's edge mesh is not kept by this package and is not written)."""
+        h5group["sites"] = self.sites
+        h5group["elements"] = self.elements
+        if not compress:
+            h5group["triangle_centroids"] = self.triangle_centroids
+            h5group["boundary_indices"] = self.boundary_indices
+            h5group["vertex_areas"] = self.vertex_areas
+            h5group["triangle_areas"] = self.triangle_areas
+
+    @staticmethod
+    def from_hdf5(h5group) -> "Mesh":
+        """``device/mesh.py:266-293``: the derived arrays are taken from the file when all of them are
+        there, otherwise recomputed from the triangulation."""
+        if not ("sites" in h5group and "elements" in h5group):
+            raise IOError("Could not load mesh due to missing data.")
+        sites = np.array(h5group["sites"]).squeeze()
+        elements = np.array(h5group["elements"], dtype=np.int64)
+        if all(key in h5group for key in ("boundary_indices", "vertex_areas", "triangle_areas")):
+            return Mesh(sites, elements, np.array(h5group["boundary_indices"], dtype=np.int64),
+                        np.array(h5group["vertex_areas"]), np.array(h5group["triangle_areas"]))
+        return Mesh.from_triangulation(sites, elements)
+
     def copy(self) -> "Mesh":
         return Mesh(self.sites.copy(), self.elements.copy(), self.boundary_indices.copy(),
                     self.vertex_areas.copy(), self.triangle_areas.copy(),

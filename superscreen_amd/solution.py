@@ -45,6 +45,19 @@ class Vortex:
     film: str
     nPhi0: float = 1
 
+    def to_hdf5(self, h5group) -> None:
+        """``solution.py:79-83``."""
+        h5group.attrs["x"] = self.x
+        h5group.attrs["y"] = self.y
+        h5group.attrs["film"] = self.film
+        h5group.attrs["nPhi0"] = self.nPhi0
+
+    @staticmethod
+    def from_hdf5(h5group) -> "Vortex":
+        """``solution.py:85-92``."""
+        return Vortex(x=h5group.attrs["x"], y=h5group.attrs["y"], film=h5group.attrs["film"],
+                      nPhi0=h5group.attrs["nPhi0"])
+
 
 class FilmSolution:
     """Raw solution data for a single film (``solution.py:95-130``)."""
@@ -69,6 +82,24 @@ class FilmSolution:
                 total = total + self.field_from_other_films
             self._total_field = total
         return self._total_field
+
+    def to_hdf5(self, h5group) -> None:
+        """``solution.py:132-143``."""
+        h5group["stream"] = self.stream
+        h5group["current_density"] = self.current_density
+        h5group["applied_field"] = self.applied_field
+        h5group["self_field"] = self.self_field
+        if self.field_from_other_films is not None:
+            h5group["field_from_other_films"] = self.field_from_other_films
+
+    @staticmethod
+    def from_hdf5(h5group) -> "FilmSolution":
+        """``solution.py:145-164``."""
+        other = h5group.get("field_from_other_films", None)
+        return FilmSolution(stream=np.array(h5group["stream"]), current_density=np.array(h5group["current_density"]),
+                            applied_field=np.array(h5group["applied_field"]),
+                            self_field=np.array(h5group["self_field"]),
+                            field_from_other_films=None if other is None else np.array(other))
 
     def is_close(self, other: "FilmSolution", rtol: float = 1e-4, atol: float = 1e-7) -> bool:
         """``solution.py:166-185``."""
@@ -171,6 +202,90 @@ class Solution:
         J_dot_n = np.sum(J_edge * normals, axis=1)
         total = Quantity(np.trapezoid(J_dot_n * lengths), self.current_units).to(units)
         return total if with_units else total.magnitude
+
+    def to_hdf5(self, path_or_group, device_path: Optional[str] = None, compress: bool = True) -> None:
+        """Saves the Solution (``solution.py:936-980``): same layout as the reference's HDF5 files, on
+        h5py or on the ``.npz`` container of :mod:`superscreen_amd.io`.  ``device_path``: where in the
+        file the device is already stored (a link is written instead of a second copy)."""
+        from contextlib import nullcontext
+
+        from . import io
+
+        ctx = nullcontext(path_or_group) if io.is_group(path_or_group) else io.open_file(path_or_group, "x")
+        with ctx as h5group:
+            h5group.attrs["time_created"] = self.time_created.isoformat()
+            h5group.attrs["field_units"] = self.field_units
+            h5group.attrs["current_units"] = self.current_units
+            h5group.attrs["solver"] = self.solver
+            h5group.create_group("version_info").attrs.update(self.version_info)
+            if device_path is None:
+                self.device.to_hdf5(h5group.create_group("device"), save_mesh=True, compress=compress)
+            else:
+                h5group["device"] = io.soft_link(h5group, device_path)
+            grp = h5group.create_group("film_solutions")
+            for name, film_solution in self.film_solutions.items():
+                film_solution.to_hdf5(grp.create_group(name))
+            vortices_grp = h5group.create_group("vortices")
+            for i, vortex in enumerate(self.vortices):
+                vortex.to_hdf5(vortices_grp.create_group(str(i)))
+            io.serialize_obj(h5group, self.applied_field_func, "applied_field_func")
+            h5group.create_group("circulating_currents").attrs.update(self.circulating_currents)
+            term_grp = h5group.create_group("terminal_currents")
+            for film_name, current_dict in self.terminal_currents.items():
+                term_grp.create_group(film_name).attrs.update(current_dict)
+
+    @staticmethod
+    def from_hdf5(path_or_group) -> "Solution":
+        """``solution.py:982-1030``."""
+        from contextlib import nullcontext
+
+        from . import io
+
+        ctx = nullcontext(path_or_group) if io.is_group(path_or_group) else io.open_file(path_or_group, "r")
+        with ctx as h5group:
+            device = Device.from_hdf5(h5group["device"])
+            film_solutions = {name: FilmSolution.from_hdf5(grp) for name, grp in h5group["film_solutions"].items()}
+            vortices = [Vortex.from_hdf5(h5group[f"vortices/{i}"]) for i in sorted(h5group["vortices"], key=int)]
+            terminal_currents = {film: dict(grp.attrs) for film, grp in h5group["terminal_currents"].items()}
+            solution = Solution(
+                device=device, film_solutions=film_solutions,
+                applied_field_func=io.deserialize_obj(h5group, "applied_field_func"), vortices=vortices,
+                circulating_currents=dict(h5group["circulating_currents"].attrs),
+                terminal_currents=terminal_currents, current_units=h5group.attrs["current_units"],
+                field_units=h5group.attrs["field_units"], solver=h5group.attrs["solver"])
+            solution._time_created = dt.datetime.fromisoformat(h5group.attrs["time_created"])
+            solution._version_info = dict(h5group["version_info"].attrs)
+        return solution
+
+    @staticmethod
+    def save_solutions(solutions, path_or_group, compress: bool = True) -> None:
+        """A series of Solutions in one file, the device stored once (``solution.py:1032-1064``)."""
+        from contextlib import nullcontext
+
+        from . import io
+
+        if not solutions:
+            return
+        device = solutions[0].device
+        ctx = nullcontext(path_or_group) if io.is_group(path_or_group) else io.open_file(path_or_group, "x")
+        with ctx as h5group:
+            device_grp = h5group.create_group("device")
+            device.to_hdf5(device_grp)
+            for i, solution in enumerate(solutions):
+                device_path = device_grp.name if solution.device == device else None
+                solution.to_hdf5(h5group.create_group(str(i)), device_path=device_path, compress=compress)
+
+    @staticmethod
+    def load_solutions(path_or_group) -> List["Solution"]:
+        """``solution.py:1066-1087``."""
+        from contextlib import nullcontext
+
+        from . import io
+
+        ctx = nullcontext(path_or_group) if io.is_group(path_or_group) else io.open_file(path_or_group, "r")
+        with ctx as h5group:
+            groups = sorted((key for key in h5group if key.isdigit()), key=int)
+            return [Solution.from_hdf5(h5group[group]) for group in groups]
 
     def equals(self, other, require_same_timestamp: bool = False) -> bool:
         """``solution.py:1089-1126``: same device, units, currents, applied field, vortices and film

@@ -19,7 +19,7 @@ Memory (per film, n vertices, n_i unknowns, s = sizeof(solve dtype)): LU n_i^2 s
 n = 50k in f64), hole systems n * k_h * s, optional stored Q n^2 s; the reference additionally
 keeps A, a float64 Q and a DENSE Laplacian (solver/utils.py:290-292), about 5 n^2 words.
 
-Not implemented (raise NotImplementedError): HDF5 persistence.  Transport currents through terminals
+Persistence (``to_hdf5`` / ``from_hdf5`` / ``save_path``): superscreen_amd.io.  Transport currents through terminals
 (solve_film.py:308-437, 505-524, 557-562) reuse the film factorization where the reference factors
 the same matrix again, and run their all-pairs sums through ``ssa_sheet_field``.  Vortices (solve_film.py:541-554) are one extra right-hand side per vortex through the
 existing factorization; a film with Lambda(x, y) (grad(Lambda) term, :181-185) goes through the LU
@@ -448,6 +448,37 @@ class FactorizedModel:
     current_units: str
     film_data: Dict[str, FilmDeviceData] = field(default_factory=dict, repr=False)
     self_field_mode: str = "matrix_free"
+    method: str = "auto"
+
+    def to_hdf5(self, h5group) -> None:
+        """Saves what defines the model (``solver/solve.py:102-132``): device with meshes, currents,
+        vortices, units and the factorization options.  The reference also writes every dense system
+        and its LU factors; here the factors live in HBM (3-14 GB per film) and
+        :meth:`from_hdf5` rebuilds them, which takes less time on an MI355X (0.1-0.5 s) than reading
+        them back from storage would."""
+        h5group.attrs["current_units"] = self.current_units
+        h5group.attrs["self_field"] = self.self_field_mode
+        h5group.attrs["method"] = self.method
+        self.device.to_hdf5(h5group.create_group("device"))
+        term_grp = h5group.create_group("terminal_currents")
+        for film, terminals in self.terminal_currents.items():
+            term_grp.create_group(film).attrs.update(terminals)
+        h5group.create_group("circulating_currents").attrs.update(self.circulating_currents)
+        vortex_grp = h5group.create_group("vortices")
+        vortices = [v for info in self.film_info.values() for v in info.vortices]
+        for i, vortex in enumerate(vortices):
+            vortex.to_hdf5(vortex_grp.create_group(str(i)))
+
+    @staticmethod
+    def from_hdf5(h5group) -> "FactorizedModel":
+        """``solver/solve.py:134-180``; re-factorizes on the GPU (see :meth:`to_hdf5`)."""
+        vortex_grp = h5group["vortices"]
+        return factorize_model(
+            device=Device.from_hdf5(h5group["device"]), current_units=h5group.attrs["current_units"],
+            terminal_currents={film: dict(grp.attrs) for film, grp in h5group["terminal_currents"].items()} or None,
+            circulating_currents=dict(h5group["circulating_currents"].attrs),
+            vortices=[Vortex.from_hdf5(vortex_grp[i]) for i in sorted(vortex_grp, key=int)],
+            self_field=h5group.attrs.get("self_field", "matrix_free"), method=h5group.attrs.get("method", "auto"))
 
     def set_circulating_currents(self, circulating_currents: Dict[str, Union[float, str]]) -> None:
         """``solver/solve.py:182-202``: no re-factorization needed."""
@@ -536,7 +567,7 @@ def factorize_model(*, device: Device, current_units: str,
         device, film_info, store_Q=(self_field == "dense"), method=method, owned=owned)
     model = FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
                             terminal_currents, circulating_currents, vortices, current_units,
-                            film_data=film_data, self_field_mode=self_field)
+                            film_data=film_data, self_field_mode=self_field, method=method)
     model.__dict__["_placement"] = placement
     return model
 
@@ -809,8 +840,6 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
 
     if log_level is not None:
         logging.basicConfig(level=log_level)
-    if save_path is not None:
-        raise NotImplementedError("HDF5 persistence (save_path) is out of scope.")
     if model is None:
         if device is None:
             raise ValueError("Either a model or a device must be provided.")
@@ -888,14 +917,32 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                     other_d[f] = payload[f]["other"]
         return results
 
+    keep = return_solutions or save_path is not None
+    n_saved = [0]
+
     def package(staged: _StagedPass):
+        """Builds the iteration's Solution on the host; with ``save_path`` it also goes to the file:
+        the device once in the root group, every iterate in a group named after its index
+        (``solver/solve.py:474-483, 539-547``; read back by ``Solution.load_solutions``)."""
         fs = {name: staged.film_solution(name, applied_h[name], conv) for name in films}
-        return Solution(device=device, film_solutions=fs, **solution_kwargs)
+        solution = Solution(device=device, film_solutions=fs, **solution_kwargs)
+        if save_path is not None:
+            from . import io
+
+            with io.open_file(save_path, "x" if n_saved[0] == 0 else "r+") as h5file:
+                if n_saved[0] == 0:
+                    device.to_hdf5(h5file.create_group("device"))
+                solution.to_hdf5(h5file.create_group(str(n_saved[0])), device_path="/device")
+            n_saved[0] += 1
+        if return_solutions:
+            solutions.append(solution)
 
     results = run_pass(None)
-    pending = _StagedPass(results, None, films) if return_solutions else None
+    pending = _StagedPass(results, None, films) if keep else None
     if len(films) < 2 or iterations < 1:
-        return [package(pending)] if return_solutions else None
+        if keep:
+            package(pending)
+        return solutions if return_solutions else None
 
     for it in range(iterations):
         other_d = {name: torch.zeros(model.film_data[name].n, dtype=model.film_data[name].tdtype,
@@ -912,10 +959,10 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                                     accumulate=True)
         prev = results
         results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
-        if return_solutions:
+        if keep:
             # the previous iterate is unpacked on the host while the GPU works on this one
             staged = _StagedPass(results, other_d, films)
-            solutions.append(package(pending))
+            package(pending)
             pending = staged
         if tolerance is not None:
             change = max(((results[n].g - prev[n].g).abs().max() / results[n].g.abs().max()).item()
@@ -923,6 +970,6 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
             logger.debug(f"iteration {it + 1}: relative change {change:.3e}")
             if change < tolerance:
                 break
-    if return_solutions:
-        solutions.append(package(pending))
+    if keep:
+        package(pending)
     return solutions if return_solutions else None

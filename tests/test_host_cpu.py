@@ -227,3 +227,73 @@ def test_solution_current_through_path_and_equality():
     # FilmSolution.is_close compares stream and fields, not the current density (solution.py:166-185)
     assert not a.equals(make(np.tile([0.0, 2.0], (n, 1)), stream=0.5)) and not a.equals("solution")
     assert a.device == device and device == device.copy() and device != synthetic.make_stack_device(6, ("washer",))
+
+
+def test_persistence_round_trips(tmp_path):
+    """Device / Solution persistence (device/device.py:936-1016, solution.py:936-1087) on the .npz
+    container of superscreen_amd.io (h5py is not installed here): the reference's own round-trip tests
+    (test_transport.py:115-119, test_solution.py:71-77, 159-179) restated."""
+    from superscreen_amd import io
+    from superscreen_amd.solution import FilmSolution, Solution, Vortex
+
+    # the container itself: groups, attributes, datasets, links, modes
+    path = tmp_path / "tree.npz"
+    with io.File(path, "x") as f:
+        g = f.create_group("a/b")
+        g.attrs["name"] = "bee"
+        g.attrs["z0"] = np.float64(0.5)
+        g["data"] = np.arange(6).reshape(2, 3)
+        f["link"] = io.SoftLink("/a/b")
+        io.serialize_obj(f, {"k": [1, 2]}, "blob")
+    with pytest.raises(FileExistsError):
+        io.File(path, "x")
+    with pytest.raises(FileNotFoundError):
+        io.File(tmp_path / "missing.npz", "r")
+    with io.File(path, "r+") as f:
+        assert f["a/b"].attrs["name"] == "bee" and f["link"].attrs["z0"] == 0.5
+        assert np.array_equal(f["/a/b/data"], np.arange(6).reshape(2, 3)) and f["link"].name == "/a/b"
+        assert io.deserialize_obj(f, "blob") == {"k": [1, 2]}
+        assert "a/b/data" in f and "a/c" not in f and f.get("nope") is None and sorted(f) == ["a", "blob.pickle", "link"]
+        with pytest.raises(ValueError):
+            f["a/b/data"] = np.zeros(1)
+        f.create_group("a/c")["more"] = np.ones(2)
+    with io.File(path, "r") as f:
+        assert np.array_equal(f["a/c/more"], np.ones(2))
+
+    # a device with terminals, a hole and a position-dependent Lambda (a Parameter: pickled with dill)
+    device = synthetic.make_strip_device(8, 4, hole_radius=0.5)
+    device.layers["base"].Lambda = sc.Parameter(_linear_lambda, offset=0.3)
+    device.to_hdf5(tmp_path / "device.npz")
+    loaded = sc.Device.from_hdf5(tmp_path / "device.npz")
+    assert loaded == device and loaded.solve_dtype == device.solve_dtype
+    assert np.array_equal(loaded.meshes["strip"].sites, device.meshes["strip"].sites)
+    assert np.array_equal(loaded.meshes["strip"].elements, device.meshes["strip"].elements)
+    assert loaded.layers["base"].Lambda(np.ones(2), np.ones(2))[0] == pytest.approx(0.5)
+    with pytest.raises(FileExistsError):
+        device.to_hdf5(tmp_path / "device.npz")
+
+    n = len(device.meshes["strip"].sites)
+    rng = np.random.default_rng(0)
+
+    def make(other):
+        fs = FilmSolution(rng.standard_normal(n), rng.standard_normal((n, 2)), np.ones(n), rng.standard_normal(n), other)
+        return Solution(device=device, film_solutions={"strip": fs}, applied_field_func=sc.ConstantField(0.3),
+                        field_units="mT", current_units="uA", circulating_currents={"hole": 1.5},
+                        terminal_currents={"strip": {"source": 1.0, "drain": -1.0}},
+                        vortices=[Vortex(0.1, 0.2, "strip", nPhi0=2)])
+
+    a, b = make(None), make(rng.standard_normal(n))
+    a.to_hdf5(tmp_path / "solution.npz")
+    back = Solution.from_hdf5(tmp_path / "solution.npz")
+    assert back == a and back.time_created == a.time_created and back.version_info == a.version_info
+    assert back.film_solutions["strip"].field_from_other_films is None and back.vortices == a.vortices
+    assert np.array_equal(back.film_solutions["strip"].current_density, a.film_solutions["strip"].current_density)
+    Solution.save_solutions([a, b], tmp_path / "series.npz")
+    series = Solution.load_solutions(tmp_path / "series.npz")
+    assert len(series) == 2 and series[0] == a and series[1] == b and series[1] != a
+    Solution.save_solutions([], tmp_path / "nothing.npz")
+    assert not (tmp_path / "nothing.npz").exists()
+
+
+def _linear_lambda(x, y, offset=0.0):
+    return offset + 0.1 * (x + y)

@@ -658,3 +658,42 @@ def test_bz_from_vector_potential():
     interior = np.linalg.norm(positions, axis=1) < 0.9 * np.linalg.norm(positions, axis=1).max()
     assert np.all(np.abs(Bz_from_A - Bz)[interior] < 5e-2 * np.abs(Bz).max())
     assert np.abs(Bz).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("return_solutions", [False, True])
+def test_save_path_and_model_persistence(tmp_path, return_solutions):
+    """``solve(save_path=...)`` writes the device once and every iterate under its index
+    (``solver/solve.py:474-483, 539-547``), readable with ``Solution.load_solutions``; a saved
+    ``FactorizedModel`` comes back as an equivalent model (``test/test_solve.py:122-136``: save, load,
+    solve).  Container: superscreen_amd.io (.npz), h5py when it is installed."""
+    import superscreen_amd as sc
+    from superscreen_amd import io, synthetic
+
+    device = synthetic.make_stack_device(10, ("washer", "disk"), z_spacing=0.7)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": "2 uA"})
+    model_path = tmp_path / "model.npz"
+    with io.open_file(model_path, "x") as f:
+        model.to_hdf5(f)
+    with io.open_file(model_path, "r") as f:
+        loaded = sc.FactorizedModel.from_hdf5(f)
+    assert isinstance(loaded, sc.FactorizedModel) and loaded.circulating_currents == {"hole0": 2.0}
+    assert loaded.device == device and loaded.current_units == "uA"
+
+    save_path = tmp_path / "solutions.npz"
+    out = sc.solve(model=loaded, applied_field=sc.ConstantField(0.4), field_units="mT", iterations=3,
+                   return_solutions=return_solutions, save_path=save_path)
+    ref = sc.solve(model=model, applied_field=sc.ConstantField(0.4), field_units="mT", iterations=3)
+    assert (out is None) != return_solutions
+    on_disk = sc.Solution.load_solutions(save_path)
+    assert len(on_disk) == 4
+    for k, (a, b) in enumerate(zip(on_disk, ref)):
+        assert a.equals(b) and a.device == device and a.circulating_currents == {"hole0": 2.0}
+        for name in device.films:
+            fa, fb = a.film_solutions[name], b.film_solutions[name]
+            assert np.array_equal(fa.stream, fb.stream) and np.array_equal(fa.current_density, fb.current_density)
+            assert (fa.field_from_other_films is None) == (k == 0)
+        if return_solutions:
+            assert a == out[k]          # same time stamp as the Solution that was returned
+    with pytest.raises(FileExistsError):
+        sc.solve(model=model, applied_field=sc.ConstantField(0.4), iterations=1, save_path=save_path)
