@@ -79,6 +79,21 @@ def pmc_traffic():
         return None
 
 
+def pmc_mfma():
+    """MFMA-pipe busy fraction and effective clock of the SYRK launches from the committed rocprofv3 PMC
+    summary (profiles/r01_v5_syrk_mfma_pmc.json; None if absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_v5_syrk_mfma_pmc.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return {"mfma_busy_fraction_of_active_cycles": float(d["mfma_busy_fraction_of_active_cycles"]),
+                "effective_clock_GHz": float(d["effective_clock_GHz"]),
+                "source": "profiles/r01_v5_syrk_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                          "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 pass of this command)"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +354,7 @@ def main():
                 "launches": int(gemm_n.value),
                 "avg_launch_us": gemm_ms.value * 1e3 / max(1, gemm_n.value),
                 "avg_launch_gflop": gemm_fl.value / max(1, gemm_n.value) / 1e9,
+                "mfma_pipe": pmc_mfma() if "gemm_op_kernel" in dom_label else None,
             },
             "extras": extras,
         }
