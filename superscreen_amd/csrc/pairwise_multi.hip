@@ -171,6 +171,122 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const double *__restrict
         }
 }
 
+// Few vectors (<= 12): v_mfma_f64_4x4x4_4b_f64 = four independent 4 x 4 x 4 products per instruction,
+// a quarter of the 16-column instruction's work.  Lane maps (found with tools/probes/mfma4x4_layout.hip):
+// A: row block = (l >> 2) & 3, row i = l & 3, k = l >> 4  -- i.e. target l & 15, source l >> 4: the SAME
+// pair-per-lane evaluation as above; B: block, k = l >> 4, column j = l & 3 (the charges do not depend on
+// the target block: every block reads the same four values); D: row i = l >> 4, block, column j = l & 3,
+// one value per lane.  NQ = groups of four vectors.
+template <typename T, int NQ, bool SELF>
+__global__ __launch_bounds__(256) void pair_mfma4_kernel(const double *__restrict__ src_xy,
+                                                         const void *__restrict__ src_scale,
+                                                         const void *__restrict__ src_val, int64_t ns,
+                                                         int64_t nvec, int64_t v0, int nv, int64_t slice_len,
+                                                         const double *__restrict__ tgt_xy, int64_t nt, double dz2,
+                                                         double *__restrict__ partial) {
+    constexpr int NV = NQ * 4;
+    constexpr int NP = SELF ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) double s_b[NP][kKS][NV];
+    __shared__ __attribute__((aligned(16))) double s_xy[kKS][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4, lj = lane & 3;
+    const int64_t t_base = static_cast<int64_t>(blockIdx.x) * kTB + wave * 32;
+    const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
+    const int64_t j_end = (j_begin + slice_len < ns) ? j_begin + slice_len : ns;
+
+    double xi[2], yi[2];
+    int64_t ti[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        ti[mb] = t_base + mb * 16 + li;
+        const int64_t tc = (ti[mb] < nt) ? ti[mb] : nt - 1;
+        xi[mb] = tgt_xy[2 * tc];
+        yi[mb] = tgt_xy[2 * tc + 1];
+    }
+    double acc[2][NQ];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[mb][q] = 0.0;
+
+    for (int64_t s0 = j_begin; s0 < j_end; s0 += kKS) {
+        __syncthreads();
+        if (tid < kKS) {
+            const int64_t j = s0 + tid;
+            const bool ok = j < j_end;
+            s_xy[tid][0] = ok ? src_xy[2 * j] : 1e30;
+            s_xy[tid][1] = ok ? src_xy[2 * j + 1] : 1e30;
+        }
+        for (int e = tid; e < kKS * NV; e += 256) {
+            const int k = e / NV, v = e % NV;
+            const int64_t j = s0 + k;
+            const bool ok = j < j_end && v < nv;
+            if constexpr (SELF) {
+                const double wj = ok ? static_cast<const double *>(src_scale)[j] : 0.0;
+                const double gj = ok ? static_cast<double>(static_cast<const T *>(src_val)[j * nvec + v0 + v]) : 0.0;
+                s_b[0][k][v] = kOneOver4Pi * (wj * gj);
+            } else {
+                double2 Jv = make_double2(0.0, 0.0);
+                double ca = 0.0;
+                if (ok) {
+                    ca = kOneOver4Pi * static_cast<double>(static_cast<const T *>(src_scale)[j]);
+                    Jv = *reinterpret_cast<const double2 *>(static_cast<const double *>(src_val) +
+                                                            (j * nvec + v0 + v) * 2);
+                }
+                s_b[0][k][v] = ca * Jv.x;
+                s_b[NP - 1][k][v] = -(ca * Jv.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < kKS / 4; ++ks) {
+            const int k = ks * 4 + lk;
+            const double2 sxy = *reinterpret_cast<const double2 *>(&s_xy[k][0]);
+            double a0[2], a1[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const double dx = xi[mb] - sxy.x, dy = yi[mb] - sxy.y;
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
+                const double y = rsqrt_f64(r2);
+                const double y3 = y * (y * y);
+                if constexpr (SELF) {
+                    a0[mb] = (s0 + k == ti[mb]) ? 0.0 : y3;
+                    a1[mb] = 0.0;
+                } else {
+                    a0[mb] = dy * y3;
+                    a1[mb] = dx * y3;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const double b0 = s_b[0][k][q * 4 + lj];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[mb], b0, acc[mb][q], 0, 0, 0);
+            }
+            if constexpr (!SELF) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const double b1 = s_b[NP - 1][k][q * 4 + lj];
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc[mb][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[mb], b1, acc[mb][q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    double *dst = partial + static_cast<int64_t>(blockIdx.y) * nt * NV;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int64_t i = t_base + mb * 16 + ((lane >> 2) & 3) * 4 + lk;  // D: row l >> 4 of block (l >> 2) & 3
+        if (i < nt) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dst[i * NV + q * 4 + lj] = acc[mb][q];
+        }
+    }
+}
+
 template <typename T>
 __global__ void self_field_multi_combine_kernel(const double *__restrict__ partial, int slices, int pstride,
                                                 int64_t n, int64_t nvec, int64_t v0, int nv,
@@ -201,13 +317,24 @@ __global__ void biot_savart_multi_combine_kernel(const double *__restrict__ part
     *dst = static_cast<T>(s);
 }
 
+// launches the pair kernel for one chunk of nv <= 64 vectors; returns the row stride of `partial`
 template <typename T, bool SELF>
-void launch_pair_mfma(int nb, dim3 grid, hipStream_t st, const double *src_xy, const void *src_scale,
-                      const void *src_val, int64_t ns, int64_t nvec, int64_t v0, int nv, int64_t slice_len,
-                      const double *tgt_xy, int64_t nt, double dz2, double *partial) {
-#define SSA_PAIR_CASE(NB)                                                                                       \
-    hipLaunchKernelGGL((pair_mfma_kernel<T, NB, SELF>), grid, dim3(256), 0, st, src_xy, src_scale, src_val, ns, \
-                       nvec, v0, nv, slice_len, tgt_xy, nt, dz2, partial)
+int launch_pair_mfma(int nv, dim3 grid, hipStream_t st, const double *src_xy, const void *src_scale,
+                     const void *src_val, int64_t ns, int64_t nvec, int64_t v0, int64_t slice_len,
+                     const double *tgt_xy, int64_t nt, double dz2, double *partial) {
+#define SSA_PAIR_ARGS src_xy, src_scale, src_val, ns, nvec, v0, nv, slice_len, tgt_xy, nt, dz2, partial
+#define SSA_PAIR_CASE(NB) hipLaunchKernelGGL((pair_mfma_kernel<T, NB, SELF>), grid, dim3(256), 0, st, SSA_PAIR_ARGS)
+#define SSA_PAIR4_CASE(NQ) hipLaunchKernelGGL((pair_mfma4_kernel<T, NQ, SELF>), grid, dim3(256), 0, st, SSA_PAIR_ARGS)
+    if (nv <= 12) {
+        const int nq = (nv + 3) / 4;
+        switch (nq) {
+            case 1: SSA_PAIR4_CASE(1); break;
+            case 2: SSA_PAIR4_CASE(2); break;
+            default: SSA_PAIR4_CASE(3); break;
+        }
+        return nq * 4;
+    }
+    const int nb = (nv + 15) / 16;
     switch (nb) {
         case 1: SSA_PAIR_CASE(1); break;
         case 2: SSA_PAIR_CASE(2); break;
@@ -215,6 +342,9 @@ void launch_pair_mfma(int nb, dim3 grid, hipStream_t st, const double *src_xy, c
         default: SSA_PAIR_CASE(4); break;
     }
 #undef SSA_PAIR_CASE
+#undef SSA_PAIR4_CASE
+#undef SSA_PAIR_ARGS
+    return nb * 16;
 }
 
 }  // namespace
@@ -240,17 +370,18 @@ extern "C" int ssa_self_field_multi(const double *xy, const double *w, const dou
     const dim3 grid(static_cast<unsigned>(ceil_div(n, kTB)), slices);
     for (int64_t v0 = 0; v0 < nvec; v0 += kChunk) {
         const int nv = static_cast<int>((nvec - v0 < kChunk) ? nvec - v0 : kChunk);
-        const int nb = (nv + 15) / 16;
         const dim3 cgrid(static_cast<unsigned>(ceil_div(n * nv, 256)));
         if (dtype == SSA_F64) {
-            launch_pair_mfma<double, true>(nb, grid, st, xy, w, g, n, nvec, v0, nv, slice_len, xy, n, 0.0, partial);
+            const int ps = launch_pair_mfma<double, true>(nv, grid, st, xy, w, g, n, nvec, v0, slice_len, xy, n, 0.0,
+                                                          partial);
             hipLaunchKernelGGL((self_field_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
-                               nb * 16, n, nvec, v0, nv, w, qdiag, static_cast<const double *>(g), alpha,
+                               ps, n, nvec, v0, nv, w, qdiag, static_cast<const double *>(g), alpha,
                                static_cast<double *>(out));
         } else {
-            launch_pair_mfma<float, true>(nb, grid, st, xy, w, g, n, nvec, v0, nv, slice_len, xy, n, 0.0, partial);
+            const int ps = launch_pair_mfma<float, true>(nv, grid, st, xy, w, g, n, nvec, v0, slice_len, xy, n, 0.0,
+                                                         partial);
             hipLaunchKernelGGL((self_field_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
-                               nb * 16, n, nvec, v0, nv, w, qdiag, static_cast<const float *>(g), alpha,
+                               ps, n, nvec, v0, nv, w, qdiag, static_cast<const float *>(g), alpha,
                                static_cast<float *>(out));
         }
         SSA_RETURN_IF_LAUNCH_FAILED();
@@ -274,18 +405,17 @@ extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas
     const dim3 grid(static_cast<unsigned>(ceil_div(nt, kTB)), slices);
     for (int64_t v0 = 0; v0 < nvec; v0 += kChunk) {
         const int nv = static_cast<int>((nvec - v0 < kChunk) ? nvec - v0 : kChunk);
-        const int nb = (nv + 15) / 16;
         const dim3 cgrid(static_cast<unsigned>(ceil_div(nt * nv, 256)));
         if (dtype == SSA_F64) {
-            launch_pair_mfma<double, false>(nb, grid, st, src_xy, src_areas, src_J, ns, nvec, v0, nv, slice_len,
-                                            tgt_xy, nt, dz * dz, partial);
+            const int ps = launch_pair_mfma<double, false>(nv, grid, st, src_xy, src_areas, src_J, ns, nvec, v0,
+                                                           slice_len, tgt_xy, nt, dz * dz, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
-                               nb * 16, nt, nvec, v0, nv, static_cast<double *>(out), accumulate);
+                               ps, nt, nvec, v0, nv, static_cast<double *>(out), accumulate);
         } else {
-            launch_pair_mfma<float, false>(nb, grid, st, src_xy, src_areas, src_J, ns, nvec, v0, nv, slice_len,
-                                           tgt_xy, nt, dz * dz, partial);
+            const int ps = launch_pair_mfma<float, false>(nv, grid, st, src_xy, src_areas, src_J, ns, nvec, v0,
+                                                          slice_len, tgt_xy, nt, dz * dz, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
-                               nb * 16, nt, nvec, v0, nv, static_cast<float *>(out), accumulate);
+                               ps, nt, nvec, v0, nv, static_cast<float *>(out), accumulate);
         }
         SSA_RETURN_IF_LAUNCH_FAILED();
     }

@@ -494,7 +494,7 @@ def test_tiny_and_degenerate_sizes(K):
 
 
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 2e-5)])
-@pytest.mark.parametrize("nvec", [1, 5, 16, 19, 33, 48, 70])
+@pytest.mark.parametrize("nvec", [1, 4, 5, 9, 12, 13, 16, 19, 33, 48, 70])
 def test_multi_vector_pairwise_kernels(K, disk, dtype, tol, nvec):
     """ssa_self_field_multi / ssa_biot_savart_multi column by column against the single-vector kernels."""
     sites, elements, mesh = disk
