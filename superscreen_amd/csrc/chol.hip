@@ -187,10 +187,12 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
     }
 }
 
-// One side stream + two events per concurrently factored matrix (look-ahead lanes).
+// Per concurrently factored matrix (look-ahead lane): the high-priority side stream of the panel chain
+// with its two events, and a low-priority stream on which a matrix that is done before the others
+// (a smaller film) builds its solve-phase blocks while the tail of the others still runs.
 struct CholLane {
-    hipStream_t side = nullptr;
-    hipEvent_t ev_strip = nullptr, ev_panel = nullptr;
+    hipStream_t side = nullptr, finish = nullptr;
+    hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr;
 };
 constexpr int kMaxLanes = 16;
 
@@ -207,8 +209,11 @@ inline int get_lanes(int count, CholLane **out) {
     for (int i = 0; i < count; ++i) {
         if (lanes[i].side != nullptr) continue;
         if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&lanes[i].finish, hipStreamNonBlocking, lo) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_strip, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
     *out = lanes;
@@ -401,11 +406,30 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (rc != SSA_OK) return rc;
         if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
     }
+    bool detached[kMaxLanes] = {};
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
         for (int i = 0; i < count; ++i) {
             const CholJob<T> &J = jobs[i];
             CholLane &ln = lanes[i];
-            if (k0 + CNB >= J.n) continue;
+            if (k0 + CNB >= J.n) {
+                // this (smaller) matrix has no panels left while others are still in their chain-bound
+                // tail: its remaining finishing steps go to its own low-priority stream, behind its last
+                // panel and behind what the caller's stream holds for it so far
+                if (!detached[i]) {
+                    detached[i] = true;
+                    if (hipEventRecord(ln.ev_fork, st) != hipSuccess ||
+                        hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess ||
+                        hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess)
+                        return SSA_ERR_HIP;
+                    FinishPlan<T> &fp = plans[i];
+                    while (fp.next < fp.n_total) {
+                        rc = fp.run_step(fp.next++, ln.finish);
+                        if (rc != SSA_OK) return rc;
+                    }
+                    if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
+                }
+                continue;
+            }
             const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
             const T *P = J.A + (k0 + CNB) * J.lda + k0;       // panel k below its diagonal block
@@ -435,7 +459,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         }
     }
     for (int i = 0; i < count; ++i) {  // join, then the inverses of the diagonal blocks
-        if (hipStreamWaitEvent(st, lanes[i].ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+        if (hipStreamWaitEvent(st, detached[i] ? lanes[i].ev_finish : lanes[i].ev_panel, 0) != hipSuccess)
+            return SSA_ERR_HIP;
     }
     for (int i = 0; i < count; ++i) {
         FinishPlan<T> &fp = plans[i];
