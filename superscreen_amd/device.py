@@ -427,8 +427,9 @@ class Device:
                                  units: str = "pH", all_iterations: bool = False, progress_bar: bool = False,
                                  **solve_kwargs):
         """``M[i, j] = fluxoid(polygon S_i around hole i) / I_j`` for a current ``I_j`` circulating
-        around hole ``j`` (``device/device.py:538-648``): one factorization, one warm
-        ``solve(model=...)`` per hole.  Returns a :class:`~superscreen_amd.units.Quantity` holding
+        around hole ``j`` (``device/device.py:538-648``): one factorization; the columns (one warm
+        ``solve(model=...)`` per hole in the reference) run together as one multi-column solve
+        (:func:`superscreen_amd.solve_sweep`).  Returns a :class:`~superscreen_amd.units.Quantity` holding
         the ``(n_holes, n_holes)`` matrix, or a list of them (one per iterate) if ``all_iterations``."""
         from .fluxoid import make_fluxoid_polygons
         from .solver import factorize_model, solve
@@ -460,16 +461,28 @@ class Device:
         to_units = PHI_0 / I_circ_A / parse_units(units).scale  # (Phi_0 / I) -> `units`
         if parse_units(units).dims != parse_units("H").dims:
             raise ValueError(f"{units!r} is not a unit of inductance.")
-        model = None
-        for j, hole_name in enumerate(hole_names):
-            logger.info(f"Evaluating {self.name!r} mutual inductance matrix column "
-                        f"({j + 1}/{len(hole_names)}), source = {hole_name!r}.")
-            if model is None:
-                model = factorize_model(device=self, current_units="mA", circulating_currents={hole_name: "1 mA"})
-                I_circ_val = model.circulating_currents[hole_name]
-            else:
+        model = factorize_model(device=self, current_units="mA", circulating_currents={hole_names[0]: "1 mA"})
+        I_circ_val = model.circulating_currents[hole_names[0]]
+        plain = set(solve_kwargs) <= {"applied_field", "field_units", "iterations", "progress_bar", "return_solutions"}
+        if n_holes >= 2 and plain and not self.terminals and solve_kwargs.get("return_solutions", True):
+            # every column of M is a solve with its own circulating current: all of them at once as the
+            # columns of one multi-right-hand-side solve (solve_sweep) instead of one solve per hole
+            from .sources import ConstantField
+            from .sweep import solve_sweep
+
+            field = solve_kwargs.get("applied_field") or ConstantField(0)
+            logger.info(f"Evaluating the {n_holes} columns of the {self.name!r} mutual inductance matrix at once.")
+            columns = solve_sweep(model, [field] * len(hole_names), field_units=solve_kwargs.get("field_units", "mT"),
+                                  iterations=iterations, all_iterations=all_iterations,
+                                  circulating_currents=[{name: I_circ_val} for name in hole_names])
+        else:
+            columns = []
+            for j, hole_name in enumerate(hole_names):
+                logger.info(f"Evaluating {self.name!r} mutual inductance matrix column "
+                            f"({j + 1}/{len(hole_names)}), source = {hole_name!r}.")
                 model.set_circulating_currents({hole_name: I_circ_val})
-            solutions = solve(model=model, **solve_kwargs)[solution_slice]
+                columns.append(solve(model=model, **solve_kwargs)[solution_slice])
+        for j, solutions in enumerate(columns):
             for n, solution in enumerate(solutions):
                 for i, name in enumerate(hole_names):
                     fluxoid = solution.polygon_fluxoid(hole_polygon_mapping[name], film=films_by_hole[name],

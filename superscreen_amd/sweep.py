@@ -30,12 +30,16 @@ from .units import field_conversion_factor
 
 def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, field_units: str = "mT",
                 iterations: int = 0, return_solutions: bool = True, all_iterations: bool = True,
+                circulating_currents: Optional[Sequence[dict]] = None,
                 _solver: str = "superscreen_amd.solve_sweep") -> Optional[List[List[Solution]]]:
     """Self-consistent solutions for every applied field of a scan.
 
     ``applied_fields``: callables ``f(x, y, z)`` (e.g. :func:`superscreen_amd.ConstantField`) or
     plain numbers (uniform fields in ``field_units``).  Returns ``result[k]`` = the list of
     ``iterations + 1`` Solutions of field ``k`` (1 for a single film), like ``solve`` would.
+    ``circulating_currents``: optionally one ``{hole: current}`` dict per column that replaces the
+    model's circulating currents for that column (a scan over circulating currents, or the columns
+    of a mutual-inductance matrix, ``device/device.py:619-627``); the model is not modified.
     ``all_iterations=False`` keeps only the final iterate (``solve(...)[-1]``): ``result[k]`` then
     has one Solution, and the self field -- an output, not an input of the next iteration
     (``solver/solve_film.py:565-572``) -- is evaluated for the final pass only."""
@@ -55,6 +59,20 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
     if nvec == 0:
         return [] if return_solutions else None
     current_units = model.current_units
+    if circulating_currents is None:
+        column_currents = [dict(model.circulating_currents)] * nvec
+    else:
+        from .units import current_to_float
+
+        if len(circulating_currents) != nvec:
+            raise ValueError(f"Expected {nvec} circulating-current dicts (one per field), got {len(circulating_currents)}.")
+        column_currents = []
+        for currents in circulating_currents:
+            for hole_name in currents:
+                if hole_name not in device.holes:
+                    raise KeyError(f"Unknown hole {hole_name!r}.")
+            column_currents.append({k: current_to_float(v, current_units) for k, v in currents.items()})
+    uniform_currents = all(c == column_currents[0] for c in column_currents)
     conv = field_conversion_factor(field_units, current_units, length_units=device.length_units)
     dtype = device.solve_dtype
     info_of, fd_of = model.film_info, model.film_data
@@ -90,20 +108,37 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         B[:, :nvec] = rhs
         return solve_in_place(B)[:, :nvec].contiguous()
 
+    _hole_terms = {}
+
+    def hole_terms(name):
+        """``g[hole] += I`` and the holes' effective field (``solve_film.py:498-503``) as ``[n, nvec]``
+        arrays: independent of the applied field and of the iteration, evaluated once per distinct set
+        of circulating currents."""
+        if name not in _hole_terms:
+            fd = fd_of[name]
+            cols = []
+            for k in range(1 if uniform_currents else nvec):
+                ha = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+                g1 = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+                for hole_name, hs in model.hole_systems[name].items():
+                    kernels.index_add_scalar(g1, hs.indices_device, column_currents[k].get(hole_name, 0))
+                    kernels.gemv(hs.A_device, fd.n, len(hs.indices), g1, xidx=hs.indices_device, y=ha,
+                                 alpha=-1.0, beta=1.0)
+                cols.append((g1, ha))
+            if uniform_currents:
+                _hole_terms[name] = (cols[0][0][:, None].expand(fd.n, nvec).contiguous(),
+                                     cols[0][1][:, None].expand(fd.n, nvec).contiguous())
+            else:
+                _hole_terms[name] = (torch.stack([c[0] for c in cols], dim=1).contiguous(),
+                                     torch.stack([c[1] for c in cols], dim=1).contiguous())
+        return _hole_terms[name]
+
     def run_pass(other_d, want_self_field=True):
         results = {}
         for name in films:
             fd, info, system = fd_of[name], info_of[name], model.film_systems[name]
-            g = torch.zeros((fd.n, nvec), dtype=fd.tdtype, device=fd.device)
-            ha = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
-            g1 = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
-            for hole_name, hs in model.hole_systems[name].items():  # field independent (solve_film.py:498-503)
-                current = info.circulating_currents.get(hole_name, 0)
-                kernels.index_add_scalar(g1, hs.indices_device, current)
-                kernels.gemv(hs.A_device, fd.n, len(hs.indices), g1, xidx=hs.indices_device, y=ha,
-                             alpha=-1.0, beta=1.0)
-            g += g1[:, None]
-            ha_all = ha[:, None].expand(fd.n, nvec).contiguous()
+            g1_all, ha_all = hole_terms(name)
+            g = g1_all.clone()
             other = None if other_d is None else other_d[name]
             if system.chol is not None:
                 h = kernels.film_rhs(applied_d[name], other, ha_all, system.indices_device, nvec=nvec)
@@ -168,7 +203,7 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                     self_field=sf[k] / conv, field_from_other_films=None if other is None else other[k] / conv)
             sols.append(Solution(device=device_copy, film_solutions=fs, applied_field_func=field,
                                  field_units=field_units, current_units=current_units,
-                                 circulating_currents=model.circulating_currents,
+                                 circulating_currents=dict(column_currents[k]),
                                  terminal_currents=model.terminal_currents, vortices=model.vortices, solver=_solver,
                                  _device_is_copy=True))
         out.append(sols)

@@ -526,6 +526,22 @@ def test_solve_sweep_equals_looped_solve(method, dtype, tol):
             fa, fb = last.film_solutions[name], sols[-1].film_solutions[name]
             assert np.array_equal(fa.stream, fb.stream) and np.array_equal(fa.self_field, fb.self_field)
             assert np.array_equal(fa.field_from_other_films, fb.field_from_other_films)
+    # one set of circulating currents per column (the model's own are left alone)
+    per_column = [{"hole0": 0.5}, {"hole0": "2 uA"}, {}]
+    swept = sc.solve_sweep(model, [0.1, 0.1, 0.3], field_units="mT", iterations=2, all_iterations=False,
+                           circulating_currents=per_column)
+    assert model.circulating_currents == {"hole0": 0.7}
+    for (sol,), currents, v in zip(swept, per_column, [0.1, 0.1, 0.3]):
+        other = sc.factorize_model(device=device, current_units="uA", circulating_currents=currents, method=method)
+        ref = sc.solve(model=other, applied_field=sc.ConstantField(v), field_units="mT", iterations=2)[-1]
+        assert sol.circulating_currents == other.circulating_currents
+        for name in device.films:
+            assert relerr(sol.film_solutions[name].stream, ref.film_solutions[name].stream) < tol
+            assert relerr(sol.film_solutions[name].self_field, ref.film_solutions[name].self_field) < tol
+    with pytest.raises(ValueError):
+        sc.solve_sweep(model, [0.1, 0.2], circulating_currents=[{}])
+    with pytest.raises(KeyError):
+        sc.solve_sweep(model, [0.1], circulating_currents=[{"nope": 1.0}])
     assert sc.solve_sweep(model, [], iterations=1) == []
     single = synthetic.make_stack_device(10, ("disk",))
     m1 = sc.factorize_model(device=single, current_units="uA")
