@@ -159,6 +159,9 @@ int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *
  *                    per-matrix arguments of ssa_chol_factor.  Results identical to `count`
  *                    separate ssa_chol_factor calls.
  *   ssa_chol_solve:  L L^T X = B in place, nrhs >= 1; workspace ssa_chol_solve_workspace_bytes.
+ *                    nrhs = 1: triangular GEMV chain at the HBM rate; 2..64 (float64): the factor is
+ *                    streamed once by an MFMA kernel that takes its operands straight from global memory;
+ *                    more: tiled MFMA GEMMs with split-K (applied-field scans, solve_sweep).
  */
 int64_t ssa_chol_padded_n(int64_t n);
 size_t ssa_chol_aux_bytes(int64_t n, int dtype);
