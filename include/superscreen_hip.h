@@ -228,6 +228,28 @@ int ssa_self_field(const double *xy, const double *w, const double *qdiag, const
 size_t ssa_self_field_workspace_bytes(int64_t n);
 
 /*
+ * The same quantity from O(n) data where that is possible.  For a row i of the film interior the
+ * solved system  -A gf = h  (solve_film.py:529-531) IS the London equation
+ *   H_applied[i] + H_other[i] + (Q (w g))[i] = (Laplacian (Lambda g))[i],
+ * (A = Q w - Lambda Laplacian, the hole columns enter through Ha_eff: both sides carry the same terms),
+ * so on those rows  self_field = Laplacian(Lambda g) - H_applied - H_other  with the sparse mesh
+ * Laplacian.  Valid for a homogeneous film without vortices or terminals; agrees with the all-pairs sum to
+ * the residual of the linear solve (1e-12 relative in float64).
+ *   ssa_london_field_rows: out[rows[k]] = sum_j lap[r,j] Lambda[j] g[j] - applied[r] - other[r], r = rows[k]
+ *                          (other may be NULL); g, applied, other, out: [n] dtype
+ *   ssa_self_field_rows:   out[rows[k]] = the all-pairs value of ssa_self_field, for the remaining rows
+ *                          (mesh vertices outside the film interior: boundary, vacuum buffer, holes);
+ *                          workspace ssa_self_field_workspace_bytes(nr)
+ * Other entries of out are left untouched.
+ */
+int ssa_self_field_rows(const double *xy, const double *w, const double *qdiag, const void *g, int64_t n,
+                        const int64_t *rows, int64_t nr, void *out, double alpha, int dtype,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int ssa_london_field_rows(const int64_t *lap_indptr, const int64_t *lap_indices, const double *lap_data,
+                          const double *Lambda, const void *g, const void *applied, const void *other,
+                          const int64_t *rows, int64_t nr, void *out, int dtype, void *stream);
+
+/*
  * Replaces  h = Hz_applied[indices] - Ha_eff[indices]  solver/solve_film.py:486-488,526-529
  * with the LU row permutation folded in (see ssa_lu_solve):
  *   h[k,b] = applied[idx[k], b] + (other ? other[idx[k], b] : 0) - ha_eff[idx[k], b]

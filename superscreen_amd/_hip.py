@@ -53,6 +53,8 @@ SIGNATURES = {
     "ssa_row_scale": (c_int, [P, P, P, I64, I64, c_int, P]),
     "ssa_self_field_workspace_bytes": (c_size_t, [I64]),
     "ssa_self_field": (c_int, [P, P, P, P, I64, P, c_double, c_int, P, c_size_t, P]),
+    "ssa_self_field_rows": (c_int, [P, P, P, P, I64, P, I64, P, c_double, c_int, P, c_size_t, P]),
+    "ssa_london_field_rows": (c_int, [P, P, P, P, P, P, P, P, I64, P, c_int, P]),
     "ssa_film_rhs": (c_int, [P, P, P, P, I64, I64, P, c_int, P]),
     "ssa_scatter_add": (c_int, [P, P, P, I64, I64, c_int, P]),
     "ssa_index_add_scalar": (c_int, [P, P, I64, P, I64, c_int, P]),

@@ -251,6 +251,86 @@ __global__ void self_field_combine_kernel(const double *__restrict__ partial, in
     out[i] = static_cast<T>(alpha * (d - s));
 }
 
+// The same sum for a LIST of target rows (sorted or not): out[rows[k]], k < nr.  Used for the mesh
+// vertices outside the film interior; inside it the London equation gives the self field from O(n)
+// data (ssa_london_field_rows).
+template <typename T>
+__global__ __launch_bounds__(kPairThreads) void self_field_rows_partial_kernel(
+    const double *__restrict__ xy, const double *__restrict__ w, const T *__restrict__ g, int64_t n,
+    const int64_t *__restrict__ rows, int64_t nr, int64_t slice_len, double *__restrict__ partial) {
+    __shared__ double s_x[kPairThreads], s_y[kPairThreads], s_c[kPairThreads];
+    const int tid = threadIdx.x;
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t i = rows[(k < nr) ? k : nr - 1];
+    const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
+    const int64_t j_end = (j_begin + slice_len < n) ? j_begin + slice_len : n;
+    const double xi = xy[2 * i], yi = xy[2 * i + 1];
+    double acc = 0.0;
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        const int64_t j = t0 + tid;
+        double sx = 0.0, sy = 0.0, sc = 0.0;
+        if (j < j_end) {
+            sx = xy[2 * j];
+            sy = xy[2 * j + 1];
+            sc = kOneOver4Pi * (w[j] * static_cast<double>(g[j]));
+        }
+        __syncthreads();
+        s_x[tid] = sx; s_y[tid] = sy; s_c[tid] = sc;
+        __syncthreads();
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+#pragma unroll 4
+        for (int q = 0; q < cnt; ++q) {
+            const double dx = xi - s_x[q], dy = yi - s_y[q];
+            const double y = rsqrt_f64(__builtin_fma(dx, dx, dy * dy));
+            acc += (t0 + q == i) ? 0.0 : (s_c[q] * y) * (y * y);
+        }
+    }
+    if (k < nr) partial[static_cast<int64_t>(blockIdx.y) * nr + k] = acc;
+}
+
+template <typename T>
+__global__ void self_field_rows_combine_kernel(const double *__restrict__ partial, int slices, int64_t nr,
+                                               const int64_t *__restrict__ rows, const double *__restrict__ w,
+                                               const double *__restrict__ qdiag, const T *__restrict__ g,
+                                               double alpha, T *__restrict__ out) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= nr) return;
+    double s = 0.0;
+    for (int q = 0; q < slices; ++q) s += partial[static_cast<int64_t>(q) * nr + k];
+    const int64_t i = rows[k];
+    const double d = qdiag[i] * (w[i] * static_cast<double>(g[i]));
+    out[i] = static_cast<T>(alpha * (d - s));
+}
+
+// out[rows[k]] = sum_j lap[r, j] Lambda_j g_j - applied[r] - other[r],  r = rows[k]: the London equation
+// H_applied + H_other + H_self = Laplacian(Lambda g) read as a formula for the self field.  One 8-lane
+// segment per row (the mesh Laplacian has about 7 entries per row).
+template <typename T>
+__global__ void london_field_rows_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices,
+                                         const double *__restrict__ data, const double *__restrict__ Lambda,
+                                         const T *__restrict__ g, const T *__restrict__ applied,
+                                         const T *__restrict__ other, const int64_t *__restrict__ rows, int64_t nr,
+                                         T *__restrict__ out) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t k = t >> 3;
+    const int sub = static_cast<int>(t & 7);
+    const int64_t r = rows[(k < nr) ? k : nr - 1];
+    double acc = 0.0;
+    if (k < nr) {
+        for (int64_t p = indptr[r] + sub; p < indptr[r + 1]; p += 8) {
+            const int64_t j = indices[p];
+            acc = __builtin_fma(data[p], Lambda[j] * static_cast<double>(g[j]), acc);
+        }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);
+    if (k < nr && sub == 0) {
+        double hz = static_cast<double>(applied[r]);
+        if (other) hz += static_cast<double>(other[r]);
+        out[r] = static_cast<T>(acc - hz);
+    }
+}
+
 inline int pick_slices(int64_t nt, int64_t ns) {
     const int64_t tb = ceil_div(nt, kPairThreads);
     int64_t s = ceil_div(2048, tb);
@@ -397,6 +477,57 @@ extern "C" int ssa_self_field(const double *xy, const double *w, const double *q
                            slices, n, w, qdiag, static_cast<const float *>(g), alpha,
                            static_cast<float *>(out));
     }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+
+extern "C" int ssa_self_field_rows(const double *xy, const double *w, const double *qdiag, const void *g, int64_t n,
+                                   const int64_t *rows, int64_t nr, void *out, double alpha, int dtype,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (!xy || !w || !qdiag || !g || !out || n <= 0 || nr < 0 || (nr > 0 && !rows)) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (nr == 0) return SSA_OK;
+    if (!workspace || workspace_bytes < ssa_self_field_workspace_bytes(nr)) return SSA_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = as_stream(stream);
+    double *partial = static_cast<double *>(workspace);
+    int slices = pick_slices(nr, n);
+    const int64_t slice_len = ceil_div(ceil_div(n, slices), kPairThreads) * kPairThreads;
+    slices = static_cast<int>(ceil_div(n, slice_len));
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr, kPairThreads)), slices);
+    const dim3 cgrid(static_cast<unsigned>(ceil_div(nr, 256)));
+    if (dtype == SSA_F64) {
+        hipLaunchKernelGGL((self_field_rows_partial_kernel<double>), grid, dim3(kPairThreads), 0, st, xy, w,
+                           static_cast<const double *>(g), n, rows, nr, slice_len, partial);
+        hipLaunchKernelGGL((self_field_rows_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices, nr,
+                           rows, w, qdiag, static_cast<const double *>(g), alpha, static_cast<double *>(out));
+    } else {
+        hipLaunchKernelGGL((self_field_rows_partial_kernel<float>), grid, dim3(kPairThreads), 0, st, xy, w,
+                           static_cast<const float *>(g), n, rows, nr, slice_len, partial);
+        hipLaunchKernelGGL((self_field_rows_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices, nr,
+                           rows, w, qdiag, static_cast<const float *>(g), alpha, static_cast<float *>(out));
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+extern "C" int ssa_london_field_rows(const int64_t *lap_indptr, const int64_t *lap_indices, const double *lap_data,
+                                     const double *Lambda, const void *g, const void *applied, const void *other,
+                                     const int64_t *rows, int64_t nr, void *out, int dtype, void *stream) {
+    if (!lap_indptr || !lap_indices || !lap_data || !Lambda || !g || !applied || !out || nr < 0 || (nr > 0 && !rows))
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    if (nr == 0) return SSA_OK;
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr * 8, 256)));
+    hipStream_t st = as_stream(stream);
+    if (dtype == SSA_F64)
+        hipLaunchKernelGGL((london_field_rows_kernel<double>), grid, dim3(256), 0, st, lap_indptr, lap_indices, lap_data,
+                           Lambda, static_cast<const double *>(g), static_cast<const double *>(applied),
+                           static_cast<const double *>(other), rows, nr, static_cast<double *>(out));
+    else
+        hipLaunchKernelGGL((london_field_rows_kernel<float>), grid, dim3(256), 0, st, lap_indptr, lap_indices, lap_data,
+                           Lambda, static_cast<const float *>(g), static_cast<const float *>(applied),
+                           static_cast<const float *>(other), rows, nr, static_cast<float *>(out));
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }

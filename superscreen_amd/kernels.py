@@ -258,6 +258,32 @@ def self_field(xy, w, qdiag, g: torch.Tensor, alpha: float = 1.0) -> torch.Tenso
     return out
 
 
+def self_field_rows(xy, w, qdiag, g: torch.Tensor, rows: torch.Tensor, out: torch.Tensor,
+                    alpha: float = 1.0) -> torch.Tensor:
+    """``out[rows] = (Q @ (w * g))[rows]`` by the all-pairs sum, other entries of ``out`` untouched."""
+    lib = load_library()
+    n, nr = xy.shape[0], rows.numel()
+    if nr == 0:
+        return out
+    nbytes = lib.ssa_self_field_workspace_bytes(nr)
+    ws = _ws(nbytes, g.device)
+    check(lib.ssa_self_field_rows(ptr(xy), ptr(w), ptr(qdiag), ptr(g), n, ptr(rows), nr, ptr(out), float(alpha),
+                                  dtype_code(g.dtype), ptr(ws), nbytes, current_stream()), "ssa_self_field_rows")
+    return out
+
+
+def london_field_rows(lap_indptr, lap_indices, lap_data, Lambda, g: torch.Tensor, applied: torch.Tensor,
+                      other: Optional[torch.Tensor], rows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """``out[rows] = (Laplacian (Lambda g) - applied - other)[rows]``: the self field of the film interior
+    from the London equation (see ``include/superscreen_hip.h``)."""
+    lib = load_library()
+    check(lib.ssa_london_field_rows(ptr(lap_indptr), ptr(lap_indices), ptr(lap_data), ptr(Lambda), ptr(g),
+                                    ptr(applied), ptr(other) if other is not None else None, ptr(rows),
+                                    rows.numel(), ptr(out), dtype_code(g.dtype), current_stream()),
+          "ssa_london_field_rows")
+    return out
+
+
 def self_field_multi(xy, w, qdiag, g: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     """Matrix-free ``Q @ (w * g)`` for ``g [n, nvec]`` (one evaluation of r^-3 per pair for all vectors)."""
     lib = load_library()

@@ -253,6 +253,7 @@ class LinearSystem:
     A_device: Optional[object] = None                        # hole systems: [n, ld] tensor
     indices_device: Optional[object] = None
     rhs_indices_device: Optional[object] = None              # indices[perm] (LU row order)
+    exterior_device: Optional[object] = None                 # mesh rows that are not unknowns (lazy)
     _lu_factorize: Optional[Callable[[], object]] = None     # builds LUFactors on demand
     _A_host: Optional[np.ndarray] = None
 
@@ -447,7 +448,7 @@ class FactorizedModel:
     vortices: Sequence[Vortex]
     current_units: str
     film_data: Dict[str, FilmDeviceData] = field(default_factory=dict, repr=False)
-    self_field_mode: str = "matrix_free"
+    self_field_mode: str = "auto"
     method: str = "auto"
 
     def to_hdf5(self, h5group) -> None:
@@ -478,7 +479,7 @@ class FactorizedModel:
             terminal_currents={film: dict(grp.attrs) for film, grp in h5group["terminal_currents"].items()} or None,
             circulating_currents=dict(h5group["circulating_currents"].attrs),
             vortices=[Vortex.from_hdf5(vortex_grp[i]) for i in sorted(vortex_grp, key=int)],
-            self_field=h5group.attrs.get("self_field", "matrix_free"), method=h5group.attrs.get("method", "auto"))
+            self_field=h5group.attrs.get("self_field", "auto"), method=h5group.attrs.get("method", "auto"))
 
     def set_circulating_currents(self, circulating_currents: Dict[str, Union[float, str]]) -> None:
         """``solver/solve.py:182-202``: no re-factorization needed."""
@@ -535,19 +536,25 @@ def factorize_model(*, device: Device, current_units: str,
                     terminal_currents: Optional[Dict[str, Dict[str, Union[float, str]]]] = None,
                     circulating_currents: Optional[Dict[str, Union[float, str]]] = None,
                     vortices: Optional[Sequence[Vortex]] = None,
-                    self_field: str = "matrix_free", method: str = "auto",
+                    self_field: str = "auto", method: str = "auto",
                     placement: Optional[object] = None) -> FactorizedModel:
     """``factorize_model`` (``solver/solve.py:223-287``).
 
-    ``self_field`` (extension): ``"matrix_free"`` regenerates q_ij on the fly for
-    ``Q @ (w * g)`` (2.2x faster than streaming a stored Q at n = 50k, and n^2 words less HBM);
-    ``"dense"`` stores Q in the solve dtype like the reference and uses a GEMV.
+    ``self_field`` (extension): how ``Q @ (w * g)`` (``solve_film.py:565``) is evaluated.
+    ``"matrix_free"`` regenerates q_ij on the fly (2.2x faster than streaming a stored Q at n = 50k,
+    and n^2 words less HBM); ``"dense"`` stores Q in the solve dtype like the reference and uses a
+    GEMV; ``"london"`` uses, on the rows that are unknowns of the film system, the solved system itself
+    -- the London equation ``H_applied + H_other + H_self = Laplacian(Lambda g)`` -- i.e. one sparse
+    product, and the all-pairs sum only on the remaining rows (boundary, vacuum buffer, holes: 20-30 %
+    of a mesh); it agrees with the all-pairs value to the residual of the solve (2e-12 relative at
+    25k vertices per film, float64).  ``"auto"`` (default) = ``"london"`` for float64 films with a
+    uniform Lambda and no vortices or terminals, ``"matrix_free"`` otherwise.
     ``method`` (extension): ``"auto"`` (default) / ``"cholesky"`` / ``"lu"``, see
     :func:`factorize_linear_systems`.
     ``placement`` (extension): a :class:`superscreen_amd.parallel.FilmPlacement`; this rank then
     assembles and factors only the films it owns (pass the same object to :func:`solve`).
     """
-    if self_field not in ("matrix_free", "dense"):
+    if self_field not in ("auto", "london", "matrix_free", "dense"):
         raise ValueError(f"Unknown self_field mode {self_field!r}.")
     circulating_currents = {k: current_to_float(v, current_units)
                             for k, v in (circulating_currents or {}).items()}
@@ -757,6 +764,17 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
                                  1.0 / (4 * np.pi), False).to(fd.tdtype)
     elif model.self_field_mode == "dense":
         sf = kernels.gemv(fd.Q, fd.n, fd.n, g, xscale=fd.w_t)
+    elif (model.self_field_mode in ("auto", "london") and fd.tdtype == torch.float64 and not info.vortices
+          and not info.lambda_info.inhomogeneous):
+        # interior rows: the solved system is the London equation, H_applied + H_other + H_self =
+        # Laplacian(Lambda g), i.e. the self field costs one sparse product there; the all-pairs sum
+        # Q @ (w g) is only needed on the rows that are not unknowns (boundary, buffer, holes)
+        if system.exterior_device is None:
+            exterior = np.setdiff1d(np.arange(fd.n, dtype=np.int64), system.indices)
+            system.exterior_device = torch.from_numpy(exterior).to(fd.device)
+        sf = torch.empty_like(g)
+        kernels.london_field_rows(*fd.lap, fd.Lambda, g, applied_d, other_d, system.indices_device, sf)
+        kernels.self_field_rows(fd.xy, fd.w, fd.qdiag, g, system.exterior_device, sf)
     else:
         sf = kernels.self_field(fd.xy, fd.w, fd.qdiag, g)
     return _DeviceFilmResult(g=g, J=J, self_field=sf)

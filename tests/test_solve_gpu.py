@@ -713,3 +713,46 @@ def test_save_path_and_model_persistence(tmp_path, return_solutions):
             assert a == out[k]          # same time stamp as the Solution that was returned
     with pytest.raises(FileExistsError):
         sc.solve(model=model, applied_field=sc.ConstantField(0.4), iterations=1, save_path=save_path)
+
+
+@pytest.mark.gpu
+def test_self_field_from_the_london_equation():
+    """``self_field="london"`` (the default where it applies): on the rows that are unknowns the self
+    field is Laplacian(Lambda g) - H_applied - H_other, elsewhere the all-pairs sum; it must agree with
+    the all-pairs evaluation on every row to the residual of the linear solve.  Vortices, Lambda(x, y),
+    terminals and float32 keep the all-pairs sum."""
+    import superscreen_amd as sc
+    from superscreen_amd import kernels, synthetic
+
+    device = synthetic.make_stack_device(20, ("washer", "disk", "washer"), z_spacing=1.0)
+    cc = {"hole0": 3.0, "hole2": "-1 uA"}
+    sols = {}
+    for mode in ("matrix_free", "london", "auto"):
+        model = sc.factorize_model(device=device, current_units="uA", circulating_currents=cc, self_field=mode)
+        sols[mode] = sc.solve(model=model, applied_field=sc.ConstantField(0.7), field_units="mT", iterations=4)
+    for a, b, c in zip(sols["matrix_free"], sols["london"], sols["auto"]):
+        for name in device.films:
+            fa, fb, fc = (s.film_solutions[name] for s in (a, b, c))
+            assert np.array_equal(fa.stream, fb.stream) and np.array_equal(fb.self_field, fc.self_field)
+            assert not np.array_equal(fa.self_field, fb.self_field)      # a different evaluation ...
+            assert relerr(fb.self_field, fa.self_field) < 1e-11          # ... of the same quantity
+    # kernel level: rows variant == full kernel on those rows
+    fd = model.film_data["washer0"]
+    g = torch.from_numpy(sols["auto"][-1].film_solutions["washer0"].stream).cuda()
+    full = kernels.self_field(fd.xy, fd.w, fd.qdiag, g)
+    rows = torch.arange(3, fd.n, 7, device="cuda")
+    part = torch.full_like(full, float("nan"))
+    kernels.self_field_rows(fd.xy, fd.w, fd.qdiag, g, rows, part)
+    assert relerr(part[rows].cpu().numpy(), full[rows].cpu().numpy()) < 1e-13
+    mask = torch.ones(fd.n, dtype=torch.bool, device="cuda")
+    mask[rows] = False
+    assert torch.isnan(part[mask]).all()
+    # where the identity does not hold as written the all-pairs sum stays
+    with_vortex = sc.solve(device=device, applied_field=sc.ConstantField(0.1), current_units="uA",
+                           vortices=[sc.Vortex(x=0.0, y=3.0, film="disk1")], iterations=1)[-1]
+    ref = sc.solve(model=sc.factorize_model(device=device, current_units="uA", self_field="matrix_free",
+                                            vortices=[sc.Vortex(x=0.0, y=3.0, film="disk1")]),
+                   applied_field=sc.ConstantField(0.1), iterations=1)[-1]
+    assert np.array_equal(with_vortex.film_solutions["disk1"].self_field, ref.film_solutions["disk1"].self_field)
+    with pytest.raises(ValueError):
+        sc.factorize_model(device=device, current_units="uA", self_field="nope")
