@@ -254,3 +254,38 @@ def test_terminal_currents(golden, name):
         assert relerr(sol.stream, d[f"g_{tag}"]) < RTOL
         assert relerr(sol.current_density, d[f"J_{tag}"]) < RTOL
         assert relerr(sol.self_field, d[f"self_field_{tag}"]) < RTOL
+
+
+def test_london_identity_holds_on_the_reference_outputs(golden):
+    """The identity behind ``self_field="london"`` (include/superscreen_hip.h, ssa_london_field_rows),
+    checked on what the REFERENCE itself produced: on the rows that are unknowns of the film system its
+    ``self_field = Q @ (w g)`` equals ``Laplacian(Lambda g) - H_applied - H_other`` to the residual of its
+    LAPACK solve -- single washer with and without a circulating current (the reference's own sparse
+    Laplacian from the fixture), and every Jacobi iterate of the coupled two-film stack."""
+    d = golden("washer_K17.npz")
+    n = len(d["sites"])
+    lap = csr(d, "lap", (n, n))
+    ix, conv = d["film_indices"], float(d["field_conversion"])
+    for L, Lam in enumerate(d["Lambdas"]):
+        for c in range(len(d["circs"])):
+            g = d[f"g_L{L}_c{c}"]
+            sf, Hz = d[f"self_field_L{L}_c{c}"] * conv, d[f"applied_field_L{L}_c{c}"] * conv
+            london = (lap @ (float(Lam) * g))[ix] - Hz[ix]
+            assert np.abs(sf[ix] - london).max() < 1e-12 * np.abs(sf).max()
+    d = golden("stack2_K12.npz")
+    films, _ = _stack(d)
+    conv = float(d["field_conversion"])
+    for it in range(int(d["iterations"]) + 1):
+        for film in films:
+            nm = film.name
+            g, sf = d[f"g_{nm}_it{it}"], d[f"self_field_{nm}_it{it}"] * conv
+            Hz = float(d["field_mT"]) * conv * np.ones_like(g)
+            if it > 0:
+                Hz = Hz + d[f"other_{nm}_it{it}"] * conv
+            ix = film.film_indices
+            london = (film.mesh.laplacian @ (film.Lambda * g))[ix] - Hz[ix]
+            assert np.abs(sf[ix] - london).max() < 1e-12 * np.abs(sf).max()
+            # ... and it is NOT an identity on the other rows (holes, boundary, vacuum buffer)
+            rest = np.setdiff1d(np.arange(len(g)), ix)
+            assert np.abs(sf[rest] - ((film.mesh.laplacian @ (film.Lambda * g))[rest] - Hz[rest])).max() \
+                > 1e-3 * np.abs(sf).max()
