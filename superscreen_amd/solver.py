@@ -207,6 +207,20 @@ class FilmDeviceData:
         self.lap, self.grad = geo["lap"], geo["grad"]
         self.Lambda = put(info.lambda_info.Lambda[:, 0].astype(np.float64))
         self._geo = geo
+        # Index range of the vertices that can carry a sheet current: g lives on the interior and hole
+        # vertices (plus the boundary of a film with terminals), J = curl(g z) on those and their mesh
+        # neighbours.  Vertices outside the range are exact zeros in every coupling sum and are skipped
+        # (with the film vertices numbered first, as a buffered mesh usually is, that is the vacuum ring).
+        support = np.zeros(self.n, dtype=bool)
+        support[info.interior_indices] = True
+        for hole_ix in info.hole_indices.values():
+            support[hole_ix] = True
+        if info.terminal_currents is not None:
+            support[info.boundary_indices] = True
+        pattern = (abs(ops.gradient_x) + abs(ops.gradient_y)).tocsr()
+        carries = support | ((pattern @ support.astype(np.float64)) > 0)
+        self.src_range = (int(np.argmax(carries)), int(self.n - np.argmax(carries[::-1]))) if carries.any() \
+            else (0, self.n)
         if geometry_only:  # a film owned by another rank: only a coupling source / target geometry
             self.Q = self.qdiag = None
             return
@@ -974,7 +988,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                 s, t = model.film_data[src], model.film_data[tgt]
                 kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,
                                     film_info[tgt].z0 - film_info[src].z0, other_d[tgt],
-                                    accumulate=True)
+                                    accumulate=True, src_begin=s.src_range[0], src_end=s.src_range[1])
         prev = results
         results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
         if keep:
