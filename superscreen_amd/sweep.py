@@ -155,7 +155,8 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
 
     def to_host(results, other_d):
         """Field-major host arrays ([nvec, n(, 2)]): every field's slice is then a contiguous view,
-        no per-field host copy.  The transposes run on the device; the copies land in pinned memory."""
+        no per-field host copy.  Transposes and the division by the field conversion run on the device;
+        the copies land in pinned memory and are only waited for once, after the last pass."""
         def fetch(t):
             h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
             h.copy_(t, non_blocking=True)
@@ -164,10 +165,10 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         out = {}
         for name in films:
             g, J, sf = results[name]
-            out[name] = (fetch(g.t().contiguous()), fetch(J.permute(1, 0, 2).contiguous()), fetch(sf.t().contiguous()),
-                         None if other_d is None else fetch(other_d[name].t().contiguous()))
-        torch.cuda.synchronize()
-        return {name: tuple(None if a is None else a.numpy() for a in arrs) for name, arrs in out.items()}
+            out[name] = (fetch(g.t().contiguous()), fetch(J.permute(1, 0, 2).contiguous()),
+                         fetch((sf / conv).t().contiguous()),
+                         None if other_d is None else fetch((other_d[name] / conv).t().contiguous()))
+        return out
 
     trace = []
     n_pass = iterations if (len(films) >= 2 and iterations >= 1) else 0
@@ -192,6 +193,10 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         return None
     out: List[List[Solution]] = []
     device_copy = device.copy(with_mesh=True, copy_mesh=False)  # what Solution.__init__ would make, once
+    torch.cuda.synchronize()                                    # the pinned copies of every pass have landed
+    trace = [{name: tuple(None if a is None else a.numpy() for a in arrs) for name, arrs in host.items()}
+             for host in trace]
+    applied_out = {name: np.ascontiguousarray((applied_h[name] / conv).T) for name in films}
     for k, field in enumerate(fields):
         sols = []
         for host in trace:
@@ -199,8 +204,8 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
             for name in films:
                 g, J, sf, other = host[name]
                 fs[name] = FilmSolution(
-                    stream=g[k], current_density=J[k], applied_field=applied_h[name][:, k] / conv,
-                    self_field=sf[k] / conv, field_from_other_films=None if other is None else other[k] / conv)
+                    stream=g[k], current_density=J[k], applied_field=applied_out[name][k],
+                    self_field=sf[k], field_from_other_films=None if other is None else other[k])
             sols.append(Solution(device=device_copy, film_solutions=fs, applied_field_func=field,
                                  field_units=field_units, current_units=current_units,
                                  circulating_currents=dict(column_currents[k]),
