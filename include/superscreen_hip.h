@@ -236,7 +236,7 @@ size_t ssa_self_field_workspace_bytes(int64_t n);
  * Laplacian.  Valid for a homogeneous film without vortices or terminals; agrees with the all-pairs sum to
  * the residual of the linear solve (1e-12 relative in float64).
  *   ssa_london_field_rows: out[rows[k]] = sum_j lap[r,j] Lambda[j] g[j] - applied[r] - other[r], r = rows[k]
- *                          (other may be NULL); g, applied, other, out: [n] dtype
+ *                          (other may be NULL); g, applied, other, out: [n, nvec] dtype, row-major
  *   ssa_self_field_rows:   out[rows[k]] = the all-pairs value of ssa_self_field, for the remaining rows
  *                          (mesh vertices outside the film interior: boundary, vacuum buffer, holes);
  *                          workspace ssa_self_field_workspace_bytes(nr)
@@ -247,7 +247,7 @@ int ssa_self_field_rows(const double *xy, const double *w, const double *qdiag, 
                         void *workspace, size_t workspace_bytes, void *stream);
 int ssa_london_field_rows(const int64_t *lap_indptr, const int64_t *lap_indices, const double *lap_data,
                           const double *Lambda, const void *g, const void *applied, const void *other,
-                          const int64_t *rows, int64_t nr, void *out, int dtype, void *stream);
+                          const int64_t *rows, int64_t nr, int64_t nvec, void *out, int dtype, void *stream);
 
 /*
  * Replaces  h = Hz_applied[indices] - Ha_eff[indices]  solver/solve_film.py:486-488,526-529
@@ -341,11 +341,15 @@ int ssa_profile_end(void);
  * index fastest: g, out [n, nvec]; src_J [ns, nvec, 2]; r^-3 is evaluated once per pair and reused
  * for 16 vectors at a time.  Same formulas, same deterministic two-stage reduction.
  *   workspace: ssa_pairwise_multi_workspace_bytes(number of targets)
+ *   ssa_self_field_multi_rows: only the listed target rows (out[rows[k], :]), like ssa_self_field_rows.
  */
 size_t ssa_pairwise_multi_workspace_bytes(int64_t nt);
 int ssa_self_field_multi(const double *xy, const double *w, const double *qdiag, const void *g,
                          int64_t n, int64_t nvec, void *out, double alpha, int dtype, void *workspace,
                          size_t workspace_bytes, void *stream);
+int ssa_self_field_multi_rows(const double *xy, const double *w, const double *qdiag, const void *g, int64_t n,
+                              int64_t nvec, const int64_t *rows, int64_t nr, void *out, double alpha, int dtype,
+                              void *workspace, size_t workspace_bytes, void *stream);
 int ssa_biot_savart_multi(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
                           const double *tgt_xy, int64_t nt, double dz, int64_t nvec, void *out,
                           int accumulate, int dtype, void *workspace, size_t workspace_bytes,

@@ -54,7 +54,7 @@ SIGNATURES = {
     "ssa_self_field_workspace_bytes": (c_size_t, [I64]),
     "ssa_self_field": (c_int, [P, P, P, P, I64, P, c_double, c_int, P, c_size_t, P]),
     "ssa_self_field_rows": (c_int, [P, P, P, P, I64, P, I64, P, c_double, c_int, P, c_size_t, P]),
-    "ssa_london_field_rows": (c_int, [P, P, P, P, P, P, P, P, I64, P, c_int, P]),
+    "ssa_london_field_rows": (c_int, [P, P, P, P, P, P, P, P, I64, I64, P, c_int, P]),
     "ssa_film_rhs": (c_int, [P, P, P, P, I64, I64, P, c_int, P]),
     "ssa_scatter_add": (c_int, [P, P, P, I64, I64, c_int, P]),
     "ssa_index_add_scalar": (c_int, [P, P, I64, P, I64, c_int, P]),
@@ -69,6 +69,7 @@ SIGNATURES = {
     "ssa_sheet_potential": (c_int, [P, P, P, I64, c_double, P, I64, c_double, P, P, c_size_t, P]),
     "ssa_pairwise_multi_workspace_bytes": (c_size_t, [I64]),
     "ssa_self_field_multi": (c_int, [P, P, P, P, I64, I64, P, c_double, c_int, P, c_size_t, P]),
+    "ssa_self_field_multi_rows": (c_int, [P, P, P, P, I64, I64, P, I64, P, c_double, c_int, P, c_size_t, P]),
     "ssa_biot_savart_multi": (c_int, [P, P, P, I64, P, I64, c_double, I64, P, c_int, c_int, P, c_size_t, P]),
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),
     "ssa_mfma_probe": (c_int, [c_int, P, P, P]),

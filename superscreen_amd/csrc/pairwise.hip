@@ -302,33 +302,27 @@ __global__ void self_field_rows_combine_kernel(const double *__restrict__ partia
     out[i] = static_cast<T>(alpha * (d - s));
 }
 
-// out[rows[k]] = sum_j lap[r, j] Lambda_j g_j - applied[r] - other[r],  r = rows[k]: the London equation
-// H_applied + H_other + H_self = Laplacian(Lambda g) read as a formula for the self field.  One 8-lane
-// segment per row (the mesh Laplacian has about 7 entries per row).
+// out[r, v] = sum_j lap[r, j] Lambda_j g[j, v] - applied[r, v] - other[r, v],  r = rows[k]: the London
+// equation H_applied + H_other + H_self = Laplacian(Lambda g) read as a formula for the self field.
+// One thread per (row, vector); the mesh Laplacian has about 7 entries per row.
 template <typename T>
 __global__ void london_field_rows_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices,
                                          const double *__restrict__ data, const double *__restrict__ Lambda,
                                          const T *__restrict__ g, const T *__restrict__ applied,
                                          const T *__restrict__ other, const int64_t *__restrict__ rows, int64_t nr,
-                                         T *__restrict__ out) {
+                                         int64_t nvec, T *__restrict__ out) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int64_t k = t >> 3;
-    const int sub = static_cast<int>(t & 7);
-    const int64_t r = rows[(k < nr) ? k : nr - 1];
+    if (t >= nr * nvec) return;
+    const int64_t k = t / nvec, v = t - k * nvec;
+    const int64_t r = rows[k];
     double acc = 0.0;
-    if (k < nr) {
-        for (int64_t p = indptr[r] + sub; p < indptr[r + 1]; p += 8) {
-            const int64_t j = indices[p];
-            acc = __builtin_fma(data[p], Lambda[j] * static_cast<double>(g[j]), acc);
-        }
+    for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+        const int64_t j = indices[p];
+        acc = __builtin_fma(data[p], Lambda[j] * static_cast<double>(g[j * nvec + v]), acc);
     }
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);
-    if (k < nr && sub == 0) {
-        double hz = static_cast<double>(applied[r]);
-        if (other) hz += static_cast<double>(other[r]);
-        out[r] = static_cast<T>(acc - hz);
-    }
+    double hz = static_cast<double>(applied[r * nvec + v]);
+    if (other) hz += static_cast<double>(other[r * nvec + v]);
+    out[r * nvec + v] = static_cast<T>(acc - hz);
 }
 
 inline int pick_slices(int64_t nt, int64_t ns) {
@@ -513,21 +507,23 @@ extern "C" int ssa_self_field_rows(const double *xy, const double *w, const doub
 
 extern "C" int ssa_london_field_rows(const int64_t *lap_indptr, const int64_t *lap_indices, const double *lap_data,
                                      const double *Lambda, const void *g, const void *applied, const void *other,
-                                     const int64_t *rows, int64_t nr, void *out, int dtype, void *stream) {
-    if (!lap_indptr || !lap_indices || !lap_data || !Lambda || !g || !applied || !out || nr < 0 || (nr > 0 && !rows))
+                                     const int64_t *rows, int64_t nr, int64_t nvec, void *out, int dtype,
+                                     void *stream) {
+    if (!lap_indptr || !lap_indices || !lap_data || !Lambda || !g || !applied || !out || nr < 0 || nvec <= 0 ||
+        (nr > 0 && !rows))
         return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     if (nr == 0) return SSA_OK;
-    const dim3 grid(static_cast<unsigned>(ceil_div(nr * 8, 256)));
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr * nvec, 256)));
     hipStream_t st = as_stream(stream);
     if (dtype == SSA_F64)
         hipLaunchKernelGGL((london_field_rows_kernel<double>), grid, dim3(256), 0, st, lap_indptr, lap_indices, lap_data,
                            Lambda, static_cast<const double *>(g), static_cast<const double *>(applied),
-                           static_cast<const double *>(other), rows, nr, static_cast<double *>(out));
+                           static_cast<const double *>(other), rows, nr, nvec, static_cast<double *>(out));
     else
         hipLaunchKernelGGL((london_field_rows_kernel<float>), grid, dim3(256), 0, st, lap_indptr, lap_indices, lap_data,
                            Lambda, static_cast<const float *>(g), static_cast<const float *>(applied),
-                           static_cast<const float *>(other), rows, nr, static_cast<float *>(out));
+                           static_cast<const float *>(other), rows, nr, nvec, static_cast<float *>(out));
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const double *__restrict
                                                         const void *__restrict__ src_val, int64_t ns,
                                                         int64_t nvec, int64_t v0, int nv, int64_t slice_len,
                                                         const double *__restrict__ tgt_xy, int64_t nt, double dz2,
-                                                        double *__restrict__ partial) {
+                                                        const int64_t *__restrict__ tgt_rows, double *__restrict__ partial) {
     using MF = Mfma<double>;
     using acc_t = MF::acc_t;
     constexpr int NV = NB * 16;
@@ -80,10 +80,12 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const double *__restrict
     int64_t ti[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        ti[mb] = t_base + mb * 16 + li;
-        const int64_t tc = (ti[mb] < nt) ? ti[mb] : nt - 1;
-        xi[mb] = tgt_xy[2 * tc];
-        yi[mb] = tgt_xy[2 * tc + 1];
+        const int64_t t = t_base + mb * 16 + li;            // position in the target list
+        const int64_t tc = (t < nt) ? t : nt - 1;
+        const int64_t gi = tgt_rows ? tgt_rows[tc] : tc;    // vertex index of that target
+        ti[mb] = (t < nt) ? gi : -1;
+        xi[mb] = tgt_xy[2 * gi];
+        yi[mb] = tgt_xy[2 * gi + 1];
     }
     acc_t acc[2][NB];
 #pragma unroll
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void pair_mfma4_kernel(const double *__restric
                                                          const void *__restrict__ src_val, int64_t ns,
                                                          int64_t nvec, int64_t v0, int nv, int64_t slice_len,
                                                          const double *__restrict__ tgt_xy, int64_t nt, double dz2,
-                                                         double *__restrict__ partial) {
+                                                         const int64_t *__restrict__ tgt_rows, double *__restrict__ partial) {
     constexpr int NV = NQ * 4;
     constexpr int NP = SELF ? 1 : 2;
     __shared__ __attribute__((aligned(16))) double s_b[NP][kKS][NV];
@@ -199,10 +201,12 @@ __global__ __launch_bounds__(256) void pair_mfma4_kernel(const double *__restric
     int64_t ti[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        ti[mb] = t_base + mb * 16 + li;
-        const int64_t tc = (ti[mb] < nt) ? ti[mb] : nt - 1;
-        xi[mb] = tgt_xy[2 * tc];
-        yi[mb] = tgt_xy[2 * tc + 1];
+        const int64_t t = t_base + mb * 16 + li;            // position in the target list
+        const int64_t tc = (t < nt) ? t : nt - 1;
+        const int64_t gi = tgt_rows ? tgt_rows[tc] : tc;    // vertex index of that target
+        ti[mb] = (t < nt) ? gi : -1;
+        xi[mb] = tgt_xy[2 * gi];
+        yi[mb] = tgt_xy[2 * gi + 1];
     }
     double acc[2][NQ];
 #pragma unroll
@@ -291,13 +295,15 @@ template <typename T>
 __global__ void self_field_multi_combine_kernel(const double *__restrict__ partial, int slices, int pstride,
                                                 int64_t n, int64_t nvec, int64_t v0, int nv,
                                                 const double *__restrict__ w, const double *__restrict__ qdiag,
-                                                const T *__restrict__ g, double alpha, T *__restrict__ out) {
+                                                const T *__restrict__ g, double alpha,
+                                                const int64_t *__restrict__ rows, T *__restrict__ out) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t >= n * nv) return;
-    const int64_t i = t / nv;
-    const int v = static_cast<int>(t - i * nv);
+    if (t >= n * nv) return;  // n = number of targets (rows of the list when there is one)
+    const int64_t k = t / nv;
+    const int v = static_cast<int>(t - k * nv);
     double s = 0.0;
-    for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * n + i) * pstride + v];
+    for (int q = 0; q < slices; ++q) s += partial[(static_cast<int64_t>(q) * n + k) * pstride + v];
+    const int64_t i = rows ? rows[k] : k;
     const double d = qdiag[i] * (w[i] * static_cast<double>(g[i * nvec + v0 + v]));
     out[i * nvec + v0 + v] = static_cast<T>(alpha * (d - s));
 }
@@ -321,8 +327,8 @@ __global__ void biot_savart_multi_combine_kernel(const double *__restrict__ part
 template <typename T, bool SELF>
 int launch_pair_mfma(int nv, dim3 grid, hipStream_t st, const double *src_xy, const void *src_scale,
                      const void *src_val, int64_t ns, int64_t nvec, int64_t v0, int64_t slice_len,
-                     const double *tgt_xy, int64_t nt, double dz2, double *partial) {
-#define SSA_PAIR_ARGS src_xy, src_scale, src_val, ns, nvec, v0, nv, slice_len, tgt_xy, nt, dz2, partial
+                     const double *tgt_xy, int64_t nt, double dz2, const int64_t *tgt_rows, double *partial) {
+#define SSA_PAIR_ARGS src_xy, src_scale, src_val, ns, nvec, v0, nv, slice_len, tgt_xy, nt, dz2, tgt_rows, partial
 #define SSA_PAIR_CASE(NB) hipLaunchKernelGGL((pair_mfma_kernel<T, NB, SELF>), grid, dim3(256), 0, st, SSA_PAIR_ARGS)
 #define SSA_PAIR4_CASE(NQ) hipLaunchKernelGGL((pair_mfma4_kernel<T, NQ, SELF>), grid, dim3(256), 0, st, SSA_PAIR_ARGS)
     if (nv <= 12) {
@@ -356,37 +362,58 @@ extern "C" size_t ssa_pairwise_multi_workspace_bytes(int64_t nt) {
     return static_cast<size_t>(kMaxSlicesM) * static_cast<size_t>(nt) * kChunk * sizeof(double) + 256;
 }
 
-extern "C" int ssa_self_field_multi(const double *xy, const double *w, const double *qdiag, const void *g,
-                                    int64_t n, int64_t nvec, void *out, double alpha, int dtype, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
+namespace {
+int self_field_multi_impl(const double *xy, const double *w, const double *qdiag, const void *g, int64_t n,
+                          int64_t nvec, const int64_t *rows, int64_t nr, void *out, double alpha, int dtype,
+                          void *workspace, size_t workspace_bytes, void *stream) {
     if (!xy || !w || !qdiag || !g || !out || n <= 0 || nvec <= 0) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
-    if (!workspace || workspace_bytes < ssa_pairwise_multi_workspace_bytes(n)) return SSA_ERR_WORKSPACE_TOO_SMALL;
+    const int64_t nt = rows ? nr : n;  // targets: the listed rows, or every vertex
+    if (nt == 0) return SSA_OK;
+    if (!workspace || workspace_bytes < ssa_pairwise_multi_workspace_bytes(nt)) return SSA_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t st = as_stream(stream);
     double *partial = static_cast<double *>(workspace);
-    int slices = pick_slices_m(n, n);
+    int slices = pick_slices_m(nt, n);
     const int64_t slice_len = ceil_div(ceil_div(n, slices), kKS) * kKS;
     slices = static_cast<int>(ceil_div(n, slice_len));
-    const dim3 grid(static_cast<unsigned>(ceil_div(n, kTB)), slices);
+    const dim3 grid(static_cast<unsigned>(ceil_div(nt, kTB)), slices);
     for (int64_t v0 = 0; v0 < nvec; v0 += kChunk) {
         const int nv = static_cast<int>((nvec - v0 < kChunk) ? nvec - v0 : kChunk);
-        const dim3 cgrid(static_cast<unsigned>(ceil_div(n * nv, 256)));
+        const dim3 cgrid(static_cast<unsigned>(ceil_div(nt * nv, 256)));
         if (dtype == SSA_F64) {
-            const int ps = launch_pair_mfma<double, true>(nv, grid, st, xy, w, g, n, nvec, v0, slice_len, xy, n, 0.0,
-                                                          partial);
+            const int ps = launch_pair_mfma<double, true>(nv, grid, st, xy, w, g, n, nvec, v0, slice_len, xy, nt, 0.0,
+                                                          rows, partial);
             hipLaunchKernelGGL((self_field_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
-                               ps, n, nvec, v0, nv, w, qdiag, static_cast<const double *>(g), alpha,
+                               ps, nt, nvec, v0, nv, w, qdiag, static_cast<const double *>(g), alpha, rows,
                                static_cast<double *>(out));
         } else {
-            const int ps = launch_pair_mfma<float, true>(nv, grid, st, xy, w, g, n, nvec, v0, slice_len, xy, n, 0.0,
-                                                         partial);
+            const int ps = launch_pair_mfma<float, true>(nv, grid, st, xy, w, g, n, nvec, v0, slice_len, xy, nt, 0.0,
+                                                         rows, partial);
             hipLaunchKernelGGL((self_field_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
-                               ps, n, nvec, v0, nv, w, qdiag, static_cast<const float *>(g), alpha,
+                               ps, nt, nvec, v0, nv, w, qdiag, static_cast<const float *>(g), alpha, rows,
                                static_cast<float *>(out));
         }
         SSA_RETURN_IF_LAUNCH_FAILED();
     }
     return SSA_OK;
+}
+}  // namespace
+
+extern "C" int ssa_self_field_multi(const double *xy, const double *w, const double *qdiag, const void *g,
+                                    int64_t n, int64_t nvec, void *out, double alpha, int dtype, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return self_field_multi_impl(xy, w, qdiag, g, n, nvec, nullptr, 0, out, alpha, dtype, workspace, workspace_bytes,
+                                 stream);
+}
+
+extern "C" int ssa_self_field_multi_rows(const double *xy, const double *w, const double *qdiag, const void *g,
+                                         int64_t n, int64_t nvec, const int64_t *rows, int64_t nr, void *out,
+                                         double alpha, int dtype, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+    if (nr < 0 || (nr > 0 && !rows)) return SSA_ERR_INVALID_ARGUMENT;
+    if (nr == 0) return SSA_OK;
+    return self_field_multi_impl(xy, w, qdiag, g, n, nvec, rows, nr, out, alpha, dtype, workspace, workspace_bytes,
+                                 stream);
 }
 
 extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
@@ -408,12 +435,12 @@ extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas
         const dim3 cgrid(static_cast<unsigned>(ceil_div(nt * nv, 256)));
         if (dtype == SSA_F64) {
             const int ps = launch_pair_mfma<double, false>(nv, grid, st, src_xy, src_areas, src_J, ns, nvec, v0,
-                                                           slice_len, tgt_xy, nt, dz * dz, partial);
+                                                           slice_len, tgt_xy, nt, dz * dz, nullptr, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
                                ps, nt, nvec, v0, nv, static_cast<double *>(out), accumulate);
         } else {
             const int ps = launch_pair_mfma<float, false>(nv, grid, st, src_xy, src_areas, src_J, ns, nvec, v0,
-                                                          slice_len, tgt_xy, nt, dz * dz, partial);
+                                                          slice_len, tgt_xy, nt, dz * dz, nullptr, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
                                ps, nt, nvec, v0, nv, static_cast<float *>(out), accumulate);
         }

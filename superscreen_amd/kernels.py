@@ -275,11 +275,12 @@ def self_field_rows(xy, w, qdiag, g: torch.Tensor, rows: torch.Tensor, out: torc
 def london_field_rows(lap_indptr, lap_indices, lap_data, Lambda, g: torch.Tensor, applied: torch.Tensor,
                       other: Optional[torch.Tensor], rows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """``out[rows] = (Laplacian (Lambda g) - applied - other)[rows]``: the self field of the film interior
-    from the London equation (see ``include/superscreen_hip.h``)."""
+    from the London equation (see ``include/superscreen_hip.h``); ``g [n]`` or ``[n, nvec]``."""
     lib = load_library()
+    nvec = 1 if g.dim() == 1 else g.shape[1]
     check(lib.ssa_london_field_rows(ptr(lap_indptr), ptr(lap_indices), ptr(lap_data), ptr(Lambda), ptr(g),
                                     ptr(applied), ptr(other) if other is not None else None, ptr(rows),
-                                    rows.numel(), ptr(out), dtype_code(g.dtype), current_stream()),
+                                    rows.numel(), nvec, ptr(out), dtype_code(g.dtype), current_stream()),
           "ssa_london_field_rows")
     return out
 
@@ -293,6 +294,21 @@ def self_field_multi(xy, w, qdiag, g: torch.Tensor, alpha: float = 1.0) -> torch
     ws = _ws(nbytes, g.device)
     check(lib.ssa_self_field_multi(ptr(xy), ptr(w), ptr(qdiag), ptr(g), n, nvec, ptr(out), float(alpha),
                                    dtype_code(g.dtype), ptr(ws), nbytes, current_stream()), "ssa_self_field_multi")
+    return out
+
+
+def self_field_multi_rows(xy, w, qdiag, g: torch.Tensor, rows: torch.Tensor, out: torch.Tensor,
+                          alpha: float = 1.0) -> torch.Tensor:
+    """``out[rows, :] = (Q @ (w * g))[rows, :]`` for ``g [n, nvec]``; other rows of ``out`` untouched."""
+    lib = load_library()
+    n, nvec, nr = g.shape[0], g.shape[1], rows.numel()
+    if nr == 0:
+        return out
+    nbytes = lib.ssa_pairwise_multi_workspace_bytes(nr)
+    ws = _ws(nbytes, g.device)
+    check(lib.ssa_self_field_multi_rows(ptr(xy), ptr(w), ptr(qdiag), ptr(g), n, nvec, ptr(rows), nr, ptr(out),
+                                        float(alpha), dtype_code(g.dtype), ptr(ws), nbytes, current_stream()),
+          "ssa_self_field_multi_rows")
     return out
 
 

@@ -149,7 +149,19 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                 gf = solve_columns(lambda B: kernels.lu_solve_permuted(system.factors, B), h)
             kernels.scatter_add(g, system.indices_device, gf, nvec=nvec)
             J = kernels.current_density(*fd.grad, g, nvec=nvec)              # [n, nvec, 2]
-            sf = kernels.self_field_multi(fd.xy, fd.w, fd.qdiag, g) if want_self_field else None
+            sf = None
+            if want_self_field:
+                if (model.self_field_mode in ("auto", "london") and fd.tdtype == torch.float64
+                        and not info.lambda_info.inhomogeneous):
+                    # interior rows from the London equation, the rest by the all-pairs sum (solver.py)
+                    if system.exterior_device is None:
+                        exterior = np.setdiff1d(np.arange(fd.n, dtype=np.int64), system.indices)
+                        system.exterior_device = torch.from_numpy(exterior).to(fd.device)
+                    sf = torch.empty_like(g)
+                    kernels.london_field_rows(*fd.lap, fd.Lambda, g, applied_d[name], other, system.indices_device, sf)
+                    kernels.self_field_multi_rows(fd.xy, fd.w, fd.qdiag, g, system.exterior_device, sf)
+                else:
+                    sf = kernels.self_field_multi(fd.xy, fd.w, fd.qdiag, g)
             results[name] = (g, J, sf)
         return results
 

@@ -508,6 +508,15 @@ def test_multi_vector_pairwise_kernels(K, disk, dtype, tol, nvec):
     for v in range(nvec):
         ref = K.self_field(xy, w, qd, g[:, v].contiguous(), alpha=0.5).cpu().numpy().astype(np.float64)
         assert relerr(sf[:, v], ref) < tol
+    # a list of target rows: only those rows are written, with the values of the full evaluation
+    rows = torch.arange(2, n, 5, device="cuda")
+    part = torch.full((n, nvec), float("nan"), dtype=tdt, device="cuda")
+    K.self_field_multi_rows(xy, w, qd, g, rows, part, alpha=0.5)
+    got = part.cpu().numpy().astype(np.float64)
+    assert relerr(got[rows.cpu().numpy()], sf[rows.cpu().numpy()]) < tol
+    keep = np.ones(n, dtype=bool)
+    keep[rows.cpu().numpy()] = False
+    assert np.isnan(got[keep]).all()
     # coupling between two different point sets, accumulate on top of an existing field
     tgt = dev(sites[: n // 2] * 0.9 + 0.05)
     J = torch.from_numpy(rng.standard_normal((n, nvec, 2))).to("cuda").contiguous()
