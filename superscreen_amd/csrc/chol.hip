@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
 // (a smaller film) builds its solve-phase blocks while the tail of the others still runs.
 struct CholLane {
     hipStream_t side = nullptr, finish = nullptr;
-    hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr;
+    hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr;
 };
 constexpr int kMaxLanes = 16;
 
@@ -213,6 +213,7 @@ inline int get_lanes(int count, CholLane **out) {
             hipEventCreateWithFlags(&lanes[i].ev_strip, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_syrk, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
@@ -374,9 +375,11 @@ struct FinishPlan {
 // With one matrix this is plain look-ahead (the chain is then the critical path for n ~ 20k);
 // with two or more the chains hide behind the other films' updates.
 //
-// Per matrix and outer step k:   strip   C[:, 0:256]   -= P P[0:256]^T       (caller's stream)
-//                                panel k+1 factored                           (side stream, after strip)
-//                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream)
+// Per matrix and outer step k:   strip   C[:, 0:256]   -= P P[0:256]^T       (side stream, after panel k and
+//                                                                              the matrix' last update)
+//                                panel k+1 factored                           (side stream)
+//                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream; for a large
+//                                        trailing matrix every other step: P = the last two panels, K = 512)
 template <typename T>
 int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
@@ -407,6 +410,13 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
     }
     bool detached[kMaxLanes] = {};
+    int64_t pending_from[kMaxLanes] = {};
+    // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
+    // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
+    // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' strips
+    constexpr int kDelayDepth = 2;
+    constexpr int64_t kDelayMinCols = 8192;
+    bool syrk_recorded[kMaxLanes] = {};
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
         for (int i = 0; i < count; ++i) {
             const CholJob<T> &J = jobs[i];
@@ -432,23 +442,35 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             }
             const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
-            const T *P = J.A + (k0 + CNB) * J.lda + k0;       // panel k below its diagonal block
+            // panels whose update of the trailing matrix is still pending: columns [pend0, k0 + CNB)
+            const int64_t pend0 = pending_from[i], kp = k0 + CNB - pend0;
+            const T *P = J.A + (k0 + CNB) * J.lda + pend0;    // those panels below the diagonal block of panel k
             T *C = J.A + (k0 + CNB) * J.lda + (k0 + CNB);
             if (hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
-            rc = gemm_op_t(0, 1, 0, right, nw, CNB, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, st);  // strip
+            // the strip runs on the chain's own stream, behind panel k (same stream) and behind the last
+            // trailing update of THIS matrix (which wrote the strip's columns): it does not queue behind
+            // the other matrices' updates on the caller's stream
+            if (syrk_recorded[i] && hipStreamWaitEvent(ln.side, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
+            rc = gemm_op_t(0, 1, 0, right, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, ln.side);
             if (rc != SSA_OK) return rc;
-            if (hipEventRecord(ln.ev_strip, st) != hipSuccess ||
-                hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
-                return SSA_ERR_HIP;
             rc = chol_factor_panel(J, k0 + CNB, ln.side);
             if (rc != SSA_OK) return rc;
             if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
-            if (right > nw) {  // rest of the trailing update: lower tiles of the (right - nw) block
+            // every other panel of a large trailing matrix keeps its update pending: the next one then
+            // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
+            // (the phase comes from the matrix' own size, not from its place in the batch: the result
+            // of a matrix does not depend on what else is factored with it)
+            const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
+                               ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
+            if (right > nw && !delay) {  // rest of the trailing update: lower tiles of the (right - nw) block
                 const T *P2 = P + nw * J.lda;
-                rc = gemm_op_t(0, 1, 1, right - nw, right - nw, CNB, -1.0, P2, J.lda, P2, J.lda, 1.0,
+                rc = gemm_op_t(0, 1, 1, right - nw, right - nw, kp, -1.0, P2, J.lda, P2, J.lda, 1.0,
                                C + nw * J.lda + nw, J.lda, st);
                 if (rc != SSA_OK) return rc;
+                if (hipEventRecord(ln.ev_syrk, st) != hipSuccess) return SSA_ERR_HIP;
+                syrk_recorded[i] = true;
             }
+            if (!delay) pending_from[i] = k0 + CNB;
             // one early finishing step per outer step once its inputs (panels <= k, which this
             // stream has waited for) are final: fills the slots where the stream waits for the chain
             FinishPlan<T> &fp = plans[i];
