@@ -29,7 +29,7 @@ The JSON line also carries
                    both measured live with HIP events on the kernel's stream inside the library
                    (ssa_profile_*) over the timed region; `traffic` = memory-side L2 bytes per
                    launch from the rocprofv3 PMC passes of this same command
-                   (profiles/r01_v4_syrk_pmc.json, corrections in tools/summarize_pmc.py), next to
+                   (profiles/r01_v7_syrk_pmc.json, corrections in tools/summarize_pmc.py), next to
                    the algorithmic bytes per launch (C tiles read + written, panel read once)
   cpu_baseline  -- the CPU oracle (numpy/scipy + OpenMP C ports of the numba kernels) timed on
                    this box's host cores on a bounded sample, rank 0 at N = 1 only.
@@ -54,24 +54,31 @@ HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 
 def syrk_algorithmic_bytes(unknowns, elem=8):
     """Average algorithmic bytes of one trailing-update launch of the Cholesky schedule
-    (chol.hip potrf_batch): per outer step the lower 128 x 128 tiles of the (right - 256) trailing
-    block are read and written once and the 256-column panel below them is read once."""
+    (chol.hip potrf_batch): per launch the lower 128 x 128 tiles of the trailing block behind the next
+    panel are read and written once and the pending panels below them (256 columns, or 512 when the
+    previous step's update was kept pending: large trailing matrices, every other step) are read once."""
     total, launches = 0.0, 0
     for n in unknowns:
         npad = -(-n // 256) * 256
+        pend0 = 0
         for k0 in range(0, npad - 256, 256):
-            m = npad - k0 - 512
-            if m <= 0:
-                continue
-            nt = m // 128
-            total += 2.0 * (nt * (nt + 1) // 2) * 128 * 128 * elem + m * 256 * elem
-            launches += 1
+            right = npad - k0 - 256
+            nw = min(right, 256)
+            kp = k0 + 256 - pend0
+            delay = kp < 512 and right > 8192 and ((k0 + npad) // 256) % 2 != 1
+            if right > nw and not delay:
+                m = right - nw
+                nt = m // 128
+                total += 2.0 * (nt * (nt + 1) // 2) * 128 * 128 * elem + m * kp * elem
+                launches += 1
+            if not delay:
+                pend0 = k0 + 256
     return total / max(1, launches), launches
 
 
 def pmc_traffic():
     """Memory-side bytes per SYRK launch from the committed rocprofv3 PMC summary (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_syrk_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_v7_syrk_pmc.json")
     try:
         with open(path) as f:
             return float(json.load(f)["traffic_bytes_per_launch"])
@@ -81,14 +88,14 @@ def pmc_traffic():
 
 def pmc_mfma():
     """MFMA-pipe busy fraction and effective clock of the SYRK launches from the committed rocprofv3 PMC
-    summary (profiles/r01_v5_syrk_mfma_pmc.json; None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_v5_syrk_mfma_pmc.json")
+    summary (profiles/r01_v7_syrk_mfma_pmc.json; None if absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_v7_syrk_mfma_pmc.json")
     try:
         with open(path) as f:
             d = json.load(f)
         return {"mfma_busy_fraction_of_active_cycles": float(d["mfma_busy_fraction_of_active_cycles"]),
                 "effective_clock_GHz": float(d["effective_clock_GHz"]),
-                "source": "profiles/r01_v5_syrk_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
+                "source": "profiles/r01_v7_syrk_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
                           "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 pass of this command)"}
     except (OSError, KeyError, ValueError):
         return None
@@ -360,7 +367,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": pmc_traffic() if "gemm_op_kernel" in dom_label else None,
-                "traffic_source": "profiles/r01_v4_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                "traffic_source": "profiles/r01_v7_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   "this command; bytes per launch, fetch x2 per MI355X_MICROARCH.md)",
                 "algorithmic_bytes_per_launch": syrk_algorithmic_bytes(
                     [int(len(s.indices)) for s in model.film_systems.values()])[0],
