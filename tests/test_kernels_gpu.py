@@ -352,6 +352,22 @@ def test_cholesky_batch_equals_single(K):
         assert torch.equal(a.L[:n, :n], b.L[:n, :n])
         rhs = dev(rng.standard_normal(n))
         assert torch.equal(K.chol_solve(a, rhs.clone()), K.chol_solve(b, rhs.clone()))
+    # orders above 8192 + a panel: trailing updates applied two panels at a time (K = 512), with a phase that
+    # depends on the matrix' own size only -- still bit-identical alone and in a batch, in either order
+    big = []
+    for n in (9300, 8800):
+        U = rng.standard_normal((n, 16))
+        big.append(np.tril(U @ U.T / 16 + np.diag(1.5 + rng.random(n))))
+    alone = [K.chol_factor(buf(S), len(S)) for S in big]
+    together = K.chol_factor_batch([(buf(S), len(S)) for S in big])
+    swapped = K.chol_factor_batch([(buf(S), len(S)) for S in big[::-1]])[::-1]
+    for S, a, b, c in zip(big, alone, together, swapped):
+        n = len(S)
+        assert a.info == 0 and torch.equal(a.L[:n, :n], b.L[:n, :n]) and torch.equal(a.L[:n, :n], c.L[:n, :n])
+        x = rng.standard_normal(n)
+        full = S + np.tril(S, -1).T
+        assert relerr(K.chol_solve(b, dev(full @ x)).cpu().numpy(), x) < 1e-11
+    del alone, together, swapped
     # one indefinite matrix in the batch is reported for that matrix only
     bad = mats[2].copy()
     bad[300, 300] = -5.0
