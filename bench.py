@@ -292,9 +292,10 @@ def main():
         extras["q_assembly_ms"] = tq * 1e3
         extras["q_assembly_frac_of_hbm_peak"] = extras["q_assembly_GBps"] / HBM_PEAK_GBPS
         del Q
-        # what a register-only v_mfma_f64 stream reaches on this box right now (no memory, no LDS):
-        # the matrix pipes are clock / power limited well below the nominal 78.6 TFLOP/s the roofline
-        # fraction is priced against (46-62 TFLOP/s observed, depending on the thermal state)
+        # what a bare register-only v_mfma_f64 stream (8 waves per SIMD, no memory, no LDS) is held at on
+        # this box right now: 45-62 TFLOP/s observed -- the chip lowers its clock under a pure MFMA load,
+        # so this is a power-management reading, not a ceiling (the SYRK engine itself reaches 67 TFLOP/s
+        # at K = 2048, tools/probes/syrk_k_probe.py); the roofline fraction is priced against 78.6
         extras["fp64_mfma_register_only_TFLOPs"] = kernels.mfma_probe(4000)
         # field map above the device: 512 x 512 image, all-pairs Biot-Savart of one film
         gx = torch.linspace(-6.0, 6.0, 512, dtype=torch.float64, device="cuda")
