@@ -168,3 +168,35 @@ class FilmPlacement:
                     bucket[key] = torch.empty(shapes[f][key], dtype=dtypes[f][key], device=device)
                 if self.world > 1:
                     _dist().broadcast(bucket[key], src=self._global_rank(own[f]), group=self.group)
+
+
+def solve_sweep_sharded(model, applied_fields: Sequence, *, rank: Optional[int] = None, world: Optional[int] = None,
+                        group=None, summarize: Optional[Callable] = None, solve_fn: Optional[Callable] = None,
+                        **sweep_kwargs):
+    """Applied-field scan over the ranks of a process group (BASELINE config 4): rank r solves the
+    contiguous slice ``shard_range(len(applied_fields), r, world)`` with
+    :func:`superscreen_amd.solve_sweep` on its own GPU and its own replica of ``model`` -- there is no
+    collective in the data path.  Returns ``(begin, end, local)`` with ``local[k]`` = the result of field
+    ``begin + k``.
+
+    ``summarize(solutions_of_one_field) -> small picklable value`` (e.g. a fluxoid, a susceptibility):
+    if given, the summaries of ALL fields, in field order, are exchanged with one ``all_gather_object``
+    and returned as a fourth item, so that every rank holds the complete curve.
+    ``solve_fn`` replaces ``solve_sweep`` (the CPU tests inject the oracle)."""
+    dist = _dist()
+    if rank is None or world is None:
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised.")
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if solve_fn is None:
+        from .sweep import solve_sweep as solve_fn
+    begin, end = shard_range(len(applied_fields), rank, world)
+    local = solve_fn(model, list(applied_fields[begin:end]), **sweep_kwargs) if end > begin else []
+    if summarize is None:
+        return begin, end, local
+    mine = [summarize(item) for item in local]
+    if world == 1:
+        return begin, end, local, mine
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine, group=group)
+    return begin, end, local, [value for part in gathered for value in part]

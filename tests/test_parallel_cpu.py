@@ -99,6 +99,23 @@ def _worker(rank, world, port, q):
                         film1_sites=meshes[src], film1_z0=z0[src], film1_areas=areas[src],
                         film1_J=J[src], film2_sites=meshes[tgt], film2_z0=z0[tgt])
             worst = max(worst, float(np.max(np.abs(other[tgt].numpy() - ref)) / np.max(np.abs(ref))))
+        # solve_sweep_sharded: contiguous slices, one all_gather_object for the summaries, field order kept
+        from superscreen_amd.parallel import solve_sweep_sharded
+
+        scan = list(np.linspace(0.1, 6.4, 13))               # 13 fields on 2 ranks: 7 + 6
+        calls = []
+
+        def fake_sweep(model, fields, iterations=0):
+            calls.append(list(fields))
+            return [[("solution", model, f, it) for it in range(iterations + 1)] for f in fields]
+
+        b, e, local, curve = solve_sweep_sharded("model", scan, solve_fn=fake_sweep, iterations=2,
+                                                 summarize=lambda sols: round(10 * sols[-1][2], 6))
+        assert (b, e) == ((0, 7) if rank == 0 else (7, 13)) and len(local) == e - b and len(calls) == 1
+        assert calls[0] == scan[b:e] and all(len(s) == 3 for s in local)
+        assert curve == [round(10 * f, 6) for f in scan]
+        b2, e2, local2 = solve_sweep_sharded("model", scan[:1], solve_fn=fake_sweep)   # fewer fields than ranks
+        assert (e2 - b2, len(local2)) == ((1, 1) if rank == 0 else (0, 0))
         # sweep sharding: every field value is solved exactly once across the ranks
         mine = shard_list(list(np.linspace(0.1, 6.4, 64)), rank, world)
         gathered = [None] * world
