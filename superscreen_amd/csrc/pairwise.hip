@@ -302,6 +302,34 @@ __global__ void self_field_rows_combine_kernel(const double *__restrict__ partia
     out[i] = static_cast<T>(alpha * (d - s));
 }
 
+// The mesh-Laplacian SpMV of the London equation, one vector: an 8-lane segment of a wavefront per CSR row
+// (about 7 entries per row: one entry per lane), reduced with xor-shuffles inside the segment.
+template <typename T>
+__global__ void london_field_rows_seg8_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ indices,
+                                              const double *__restrict__ data, const double *__restrict__ Lambda,
+                                              const T *__restrict__ g, const T *__restrict__ applied,
+                                              const T *__restrict__ other, const int64_t *__restrict__ rows,
+                                              int64_t nr, T *__restrict__ out) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t k = t >> 3;
+    const int sub = static_cast<int>(t & 7);
+    const int64_t r = rows[(k < nr) ? k : nr - 1];
+    double acc = 0.0;
+    if (k < nr) {
+        for (int64_t p = indptr[r] + sub; p < indptr[r + 1]; p += 8) {
+            const int64_t j = indices[p];
+            acc = __builtin_fma(data[p], Lambda[j] * static_cast<double>(g[j]), acc);
+        }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);  // every lane of the wave takes part
+    if (k < nr && sub == 0) {
+        double hz = static_cast<double>(applied[r]);
+        if (other) hz += static_cast<double>(other[r]);
+        out[r] = static_cast<T>(acc - hz);
+    }
+}
+
 // out[r, v] = sum_j lap[r, j] Lambda_j g[j, v] - applied[r, v] - other[r, v],  r = rows[k]: the London
 // equation H_applied + H_other + H_self = Laplacian(Lambda g) read as a formula for the self field.
 // One thread per (row, vector); the mesh Laplacian has about 7 entries per row.
@@ -514,8 +542,21 @@ extern "C" int ssa_london_field_rows(const int64_t *lap_indptr, const int64_t *l
         return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     if (nr == 0) return SSA_OK;
-    const dim3 grid(static_cast<unsigned>(ceil_div(nr * nvec, 256)));
     hipStream_t st = as_stream(stream);
+    if (nvec == 1) {  // one vector: segmented reduction, 8 lanes per row
+        const dim3 sgrid(static_cast<unsigned>(ceil_div(nr * 8, 256)));
+        if (dtype == SSA_F64)
+            hipLaunchKernelGGL((london_field_rows_seg8_kernel<double>), sgrid, dim3(256), 0, st, lap_indptr, lap_indices,
+                               lap_data, Lambda, static_cast<const double *>(g), static_cast<const double *>(applied),
+                               static_cast<const double *>(other), rows, nr, static_cast<double *>(out));
+        else
+            hipLaunchKernelGGL((london_field_rows_seg8_kernel<float>), sgrid, dim3(256), 0, st, lap_indptr, lap_indices,
+                               lap_data, Lambda, static_cast<const float *>(g), static_cast<const float *>(applied),
+                               static_cast<const float *>(other), rows, nr, static_cast<float *>(out));
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        return SSA_OK;
+    }
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr * nvec, 256)));
     if (dtype == SSA_F64)
         hipLaunchKernelGGL((london_field_rows_kernel<double>), grid, dim3(256), 0, st, lap_indptr, lap_indices, lap_data,
                            Lambda, static_cast<const double *>(g), static_cast<const double *>(applied),
