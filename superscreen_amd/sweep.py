@@ -195,7 +195,8 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
             if src == tgt:
                 continue
             s, t = fd_of[src], fd_of[tgt]
-            kernels.biot_savart_multi(s.xy, s.w_t, results[src][1], t.xy,
+            b, e = s.src_range  # vertices that can carry current (solver.FilmDeviceData): the rest adds exact zeros
+            kernels.biot_savart_multi(s.xy[b:e], s.w_t[b:e], results[src][1][b:e], t.xy,
                                       info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True)
         results = run_pass(other_d, all_iterations or last)
         if return_solutions and (all_iterations or last):
