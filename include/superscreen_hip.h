@@ -341,12 +341,17 @@ int ssa_profile_end(void);
  * index fastest: g, out [n, nvec]; src_J [ns, nvec, 2]; r^-3 is evaluated once per pair and reused
  * for 16 vectors at a time.  Same formulas, same deterministic two-stage reduction.
  *   workspace: ssa_pairwise_multi_workspace_bytes(number of targets)
- *   ssa_self_field_multi_rows: only the listed target rows (out[rows[k], :]), like ssa_self_field_rows.
+ *   ssa_self_field_multi_rows / ssa_biot_savart_multi_rows: only the listed target rows (out[rows[k], :]),
+ *   like ssa_self_field_rows; workspace for nr targets.
  */
 size_t ssa_pairwise_multi_workspace_bytes(int64_t nt);
 int ssa_self_field_multi(const double *xy, const double *w, const double *qdiag, const void *g,
                          int64_t n, int64_t nvec, void *out, double alpha, int dtype, void *workspace,
                          size_t workspace_bytes, void *stream);
+int ssa_biot_savart_multi_rows(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
+                               const double *tgt_xy, int64_t nt, const int64_t *rows, int64_t nr, double dz,
+                               int64_t nvec, void *out, int accumulate, int dtype, void *workspace,
+                               size_t workspace_bytes, void *stream);
 int ssa_self_field_multi_rows(const double *xy, const double *w, const double *qdiag, const void *g, int64_t n,
                               int64_t nvec, const int64_t *rows, int64_t nr, void *out, double alpha, int dtype,
                               void *workspace, size_t workspace_bytes, void *stream);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ssa_sheet_potential": (c_int, [P, P, P, I64, c_double, P, I64, c_double, P, P, c_size_t, P]),
     "ssa_pairwise_multi_workspace_bytes": (c_size_t, [I64]),
     "ssa_self_field_multi": (c_int, [P, P, P, P, I64, I64, P, c_double, c_int, P, c_size_t, P]),
+    "ssa_biot_savart_multi_rows": (c_int, [P, P, P, I64, P, I64, P, I64, c_double, I64, P, c_int, c_int, P, c_size_t, P]),
     "ssa_self_field_multi_rows": (c_int, [P, P, P, P, I64, I64, P, I64, P, c_double, c_int, P, c_size_t, P]),
     "ssa_biot_savart_multi": (c_int, [P, P, P, I64, P, I64, c_double, I64, P, c_int, c_int, P, c_size_t, P]),
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),

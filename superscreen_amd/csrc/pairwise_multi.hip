@@ -311,14 +311,15 @@ __global__ void self_field_multi_combine_kernel(const double *__restrict__ parti
 template <typename T>
 __global__ void biot_savart_multi_combine_kernel(const double *__restrict__ partial, int slices, int pstride,
                                                  int64_t nt, int64_t nvec, int64_t v0, int nv,
-                                                 T *__restrict__ out, int accumulate) {
+                                                 const int64_t *__restrict__ rows, T *__restrict__ out,
+                                                 int accumulate) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t >= nt * nv) return;
+    if (t >= nt * nv) return;  // nt = number of targets (rows of the list when there is one)
     const int64_t i = t / nv;
     const int v = static_cast<int>(t - i * nv);
     double s = 0.0;
     for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * nt + i) * pstride + v];
-    T *dst = out + i * nvec + v0 + v;
+    T *dst = out + (rows ? rows[i] : i) * nvec + v0 + v;
     if (accumulate) s += static_cast<double>(*dst);
     *dst = static_cast<T>(s);
 }
@@ -416,13 +417,16 @@ extern "C" int ssa_self_field_multi_rows(const double *xy, const double *w, cons
                                  stream);
 }
 
-extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
-                                     const double *tgt_xy, int64_t nt, double dz, int64_t nvec, void *out,
-                                     int accumulate, int dtype, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
-    if (!src_xy || !src_areas || !src_J || !tgt_xy || !out || ns <= 0 || nt <= 0 || nvec <= 0)
+namespace {
+int biot_savart_multi_impl(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
+                           const double *tgt_xy, int64_t nt_all, const int64_t *rows, int64_t nr, double dz,
+                           int64_t nvec, void *out, int accumulate, int dtype, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    if (!src_xy || !src_areas || !src_J || !tgt_xy || !out || ns <= 0 || nt_all <= 0 || nvec <= 0)
         return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    const int64_t nt = rows ? nr : nt_all;  // targets: the listed rows of tgt_xy, or all of them
+    if (nt == 0) return SSA_OK;
     if (!workspace || workspace_bytes < ssa_pairwise_multi_workspace_bytes(nt)) return SSA_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t st = as_stream(stream);
     double *partial = static_cast<double *>(workspace);
@@ -435,16 +439,35 @@ extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas
         const dim3 cgrid(static_cast<unsigned>(ceil_div(nt * nv, 256)));
         if (dtype == SSA_F64) {
             const int ps = launch_pair_mfma<double, false>(nv, grid, st, src_xy, src_areas, src_J, ns, nvec, v0,
-                                                           slice_len, tgt_xy, nt, dz * dz, nullptr, partial);
+                                                           slice_len, tgt_xy, nt, dz * dz, rows, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<double>), cgrid, dim3(256), 0, st, partial, slices,
-                               ps, nt, nvec, v0, nv, static_cast<double *>(out), accumulate);
+                               ps, nt, nvec, v0, nv, rows, static_cast<double *>(out), accumulate);
         } else {
             const int ps = launch_pair_mfma<float, false>(nv, grid, st, src_xy, src_areas, src_J, ns, nvec, v0,
-                                                          slice_len, tgt_xy, nt, dz * dz, nullptr, partial);
+                                                          slice_len, tgt_xy, nt, dz * dz, rows, partial);
             hipLaunchKernelGGL((biot_savart_multi_combine_kernel<float>), cgrid, dim3(256), 0, st, partial, slices,
-                               ps, nt, nvec, v0, nv, static_cast<float *>(out), accumulate);
+                               ps, nt, nvec, v0, nv, rows, static_cast<float *>(out), accumulate);
         }
         SSA_RETURN_IF_LAUNCH_FAILED();
     }
     return SSA_OK;
+}
+}  // namespace
+
+extern "C" int ssa_biot_savart_multi(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
+                                     const double *tgt_xy, int64_t nt, double dz, int64_t nvec, void *out,
+                                     int accumulate, int dtype, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    return biot_savart_multi_impl(src_xy, src_areas, src_J, ns, tgt_xy, nt, nullptr, 0, dz, nvec, out, accumulate,
+                                  dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssa_biot_savart_multi_rows(const double *src_xy, const void *src_areas, const double *src_J, int64_t ns,
+                                          const double *tgt_xy, int64_t nt, const int64_t *rows, int64_t nr,
+                                          double dz, int64_t nvec, void *out, int accumulate, int dtype,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    if (nr < 0 || (nr > 0 && !rows)) return SSA_ERR_INVALID_ARGUMENT;
+    if (nr == 0) return SSA_OK;
+    return biot_savart_multi_impl(src_xy, src_areas, src_J, ns, tgt_xy, nt, rows, nr, dz, nvec, out, accumulate, dtype,
+                                  workspace, workspace_bytes, stream);
 }

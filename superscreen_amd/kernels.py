@@ -313,10 +313,20 @@ def self_field_multi_rows(xy, w, qdiag, g: torch.Tensor, rows: torch.Tensor, out
 
 
 def biot_savart_multi(src_xy, src_areas, src_J, tgt_xy, dz: float, out: torch.Tensor, *,
-                      accumulate: bool) -> torch.Tensor:
-    """``biot_savart_film_to_film`` for ``src_J [ns, nvec, 2]`` into ``out [nt, nvec]``."""
+                      accumulate: bool, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``biot_savart_film_to_film`` for ``src_J [ns, nvec, 2]`` into ``out [nt, nvec]``; with ``rows`` only
+    those target rows are evaluated and written."""
     lib = load_library()
     ns, nt, nvec = src_xy.shape[0], tgt_xy.shape[0], out.shape[1]
+    if rows is not None:
+        nr = rows.numel()
+        nbytes = lib.ssa_pairwise_multi_workspace_bytes(max(nr, 1))
+        ws = _ws(nbytes, out.device)
+        check(lib.ssa_biot_savart_multi_rows(ptr(src_xy), ptr(src_areas), ptr(src_J), ns, ptr(tgt_xy), nt, ptr(rows),
+                                             nr, float(dz), nvec, ptr(out), int(bool(accumulate)),
+                                             dtype_code(out.dtype), ptr(ws), nbytes, current_stream()),
+              "ssa_biot_savart_multi_rows")
+        return out
     nbytes = lib.ssa_pairwise_multi_workspace_bytes(nt)
     ws = _ws(nbytes, out.device)
     check(lib.ssa_biot_savart_multi(ptr(src_xy), ptr(src_areas), ptr(src_J), ns, ptr(tgt_xy), nt, float(dz), nvec,

@@ -196,8 +196,12 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                 continue
             s, t = fd_of[src], fd_of[tgt]
             b, e = s.src_range  # vertices that can carry current (solver.FilmDeviceData): the rest adds exact zeros
+            # an iterate that is not returned only feeds the next solve: its coupling field is needed on
+            # the unknowns' rows of the target film (h = Hz[ix] - ..., solve_film.py:529) and nowhere else
+            only_unknowns = None if (all_iterations or last) else model.film_systems[tgt].indices_device
             kernels.biot_savart_multi(s.xy[b:e], s.w_t[b:e], results[src][1][b:e], t.xy,
-                                      info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True)
+                                      info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True,
+                                      rows=only_unknowns)
         results = run_pass(other_d, all_iterations or last)
         if return_solutions and (all_iterations or last):
             trace.append(to_host(results, other_d))

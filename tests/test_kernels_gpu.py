@@ -540,6 +540,16 @@ def test_multi_vector_pairwise_kernels(K, disk, dtype, tol, nvec):
     out = base.clone()
     K.biot_savart_multi(xy, w.to(tdt), J, tgt, 0.7, out, accumulate=True)
     out = out.cpu().numpy().astype(np.float64)
+    # a list of target rows: the other rows keep what they held
+    trows = torch.arange(1, n // 2, 3, device="cuda")
+    sub = base.clone()
+    K.biot_savart_multi(xy, w.to(tdt), J, tgt, 0.7, sub, accumulate=True, rows=trows)
+    sub = sub.cpu().numpy().astype(np.float64)
+    tr = trows.cpu().numpy()
+    assert relerr(sub[tr], out[tr]) < tol
+    rest = np.ones(n // 2, dtype=bool)
+    rest[tr] = False
+    assert np.array_equal(sub[rest], base.cpu().numpy().astype(np.float64)[rest])
     for v in range(nvec):
         ref = base[:, v].contiguous().clone()
         K.biot_savart(xy, w.to(tdt), J[:, v, :].contiguous(), tgt, 0.7, ref, accumulate=True)

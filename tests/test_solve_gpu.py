@@ -524,8 +524,10 @@ def test_solve_sweep_equals_looped_solve(method, dtype, tol):
     for sols, (last,) in zip(sweep, final):
         for name in device.films:
             fa, fb = last.film_solutions[name], sols[-1].film_solutions[name]
-            assert np.array_equal(fa.stream, fb.stream) and np.array_equal(fa.self_field, fb.self_field)
-            assert np.array_equal(fa.field_from_other_films, fb.field_from_other_films)
+            # (not bitwise: iterates that are not returned get their coupling field on the unknowns' rows
+            # only, which may group the source slices differently)
+            assert relerr(fa.stream, fb.stream) < 10 * tol and relerr(fa.self_field, fb.self_field) < 10 * tol
+            assert relerr(fa.field_from_other_films, fb.field_from_other_films) < 10 * tol
     # one set of circulating currents per column (the model's own are left alone)
     per_column = [{"hole0": 0.5}, {"hole0": "2 uA"}, {}]
     swept = sc.solve_sweep(model, [0.1, 0.1, 0.3], field_units="mT", iterations=2, all_iterations=False,
