@@ -7,7 +7,7 @@ two-film device of BASELINE.json, on N MI355X GPUs of one node.
 
 Workload ("config H" of SURVEY.md section 8d, the configuration the metric is quoted on):
 washer (z = 0) + shield disk (z = 0.5 um), both on the K = 91 synthetic ring mesh: 25 117
-vertices per film = 50 234 vertices, 20 419 / 18 150 unknowns, Lambda = 0.1 um, uniform
+vertices per film = 50 234 vertices, 18 150 / 20 419 unknowns, Lambda = 0.1 um, uniform
 applied field, float64.
 
 One STEP = one cold self-consistent solve of that device: for both films regenerate the kernel
@@ -17,9 +17,18 @@ solve_film over both films and ITER rounds of inter-film Biot-Savart coupling (J
 10 as in SURVEY config 3), including the per-iteration Solution objects copied to the host.
 Mesh geometry and sparse operators are resident in HBM before the timed region starts.
 
-N > 1: independent applied-field values are sharded over the ranks (no data-path collective;
-weak scaling: every rank runs K steps of the same size); value = total solves / max-over-ranks
-time.
+The headline line is the same at every N: at N > 1 every rank runs K such steps on its own applied
+field (independent solves: weak scaling, no data-path collective); value = total solves /
+max-over-ranks time.  What the other BASELINE configurations do at N GPUs is reported in `extras`
+(all ranks take part; RCCL = torch.distributed backend "nccl"):
+  config4_*   64-value applied-field scan of the config-3 device (2 x 19 927 vertices) through
+              parallel.solve_sweep_sharded: `strong` = 64 values over the N ranks, every rank's own
+              factorization included; `weak` = 64 values per rank.  No collective in the data path.
+  config5_*   cold solve of the 4-film stack (4 x 30 301 vertices, 10 Jacobi iterations) with the
+              films placed on the ranks (parallel.FilmPlacement, N <= 4: one sum all-reduce of the O(n)
+              result vectors per pass) or, when there are more ranks than films (N = 8), with every
+              ordered film pair split by source slice (parallel.CouplingPlan: one fused all-reduce of the
+              coupling vector per iteration).
 
 The JSON line also carries
   roofline      -- the dominant kernel: the MFMA trailing update of the factorization
@@ -28,11 +37,14 @@ The JSON line also carries
                    achieved = sum(algorithmic flops, K M (M + 1) per launch) / sum(kernel time),
                    both measured live with HIP events on the kernel's stream inside the library
                    (ssa_profile_*) over the timed region; `traffic` = memory-side L2 bytes per
-                   launch from the rocprofv3 PMC passes of this same command
-                   (profiles/r01_v7_syrk_pmc.json, corrections in tools/summarize_pmc.py), next to
-                   the algorithmic bytes per launch (C tiles read + written, panel read once)
-  cpu_baseline  -- the CPU oracle (numpy/scipy + OpenMP C ports of the numba kernels) timed on
-                   this box's host cores on a bounded sample, rank 0 at N = 1 only.
+                   launch from the rocprofv3 PMC passes of this same command (profiles/, corrections in
+                   tools/summarize_pmc.py), next to the algorithmic bytes per launch (C tiles read +
+                   written, panel read once).  The PMC summaries record the average launch duration
+                   and flops of the run they were collected in; if the live averages have moved more
+                   than 5 % away from them, `traffic_stale` is true.
+  cpu_baseline  -- the CPU oracle (numpy/scipy + OpenMP C ports of the numba kernels) timed on this
+                   box's host cores ON THE SAME K = 91 DEVICE (no extrapolation), thread count chosen by
+                   a short LU sweep; rank 0 at N = 1 only.
 """
 from __future__ import annotations
 
@@ -50,13 +62,16 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_TRAFFIC_FILES = ("r02_syrk_pmc.json", "r01_v7_syrk_pmc.json")
+PMC_MFMA_FILES = ("r02_syrk_mfma_pmc.json", "r01_v7_syrk_mfma_pmc.json")
 
 
-def syrk_algorithmic_bytes(unknowns, elem=8):
-    """Average algorithmic bytes of one trailing-update launch of the Cholesky schedule
-    (chol.hip potrf_batch): per launch the lower 128 x 128 tiles of the trailing block behind the next
+def chol_schedule(unknowns, elem=8):
+    """The trailing-update launches of the Cholesky schedule (chol.hip potrf_batch) for films with the given
+    numbers of unknowns: per launch the lower 128 x 128 tiles of the trailing block behind the next
     panel are read and written once and the pending panels below them (256 columns, or 512 when the
-    previous step's update was kept pending: large trailing matrices, every other step) are read once."""
+    previous step's update was kept pending: large trailing matrices, every other step) are read once.
+    Returns (average algorithmic bytes per launch, launches per factorization)."""
     total, launches = 0.0, 0
     for n in unknowns:
         npad = -(-n // 256) * 256
@@ -76,29 +91,16 @@ def syrk_algorithmic_bytes(unknowns, elem=8):
     return total / max(1, launches), launches
 
 
-def pmc_traffic():
-    """Memory-side bytes per SYRK launch from the committed rocprofv3 PMC summary (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_v7_syrk_pmc.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def pmc_mfma():
-    """MFMA-pipe busy fraction and effective clock of the SYRK launches from the committed rocprofv3 PMC
-    summary (profiles/r01_v7_syrk_mfma_pmc.json; None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_v7_syrk_mfma_pmc.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return {"mfma_busy_fraction_of_active_cycles": float(d["mfma_busy_fraction_of_active_cycles"]),
-                "effective_clock_GHz": float(d["effective_clock_GHz"]),
-                "source": "profiles/r01_v7_syrk_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES "
-                          "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 pass of this command)"}
-    except (OSError, KeyError, ValueError):
-        return None
+def load_profile(names):
+    """First existing PMC summary of `names` under profiles/ -> (dict, relative path), else (None, None)."""
+    for name in names:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                return json.load(f), "profiles/" + name
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def parse_args():
@@ -108,86 +110,252 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--K", type=int, default=91, help="rings of the synthetic mesh (91 -> 25 117 vertices/film)")
     ap.add_argument("--iterations", type=int, default=10)
-    ap.add_argument("--cpu-sample-K", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=60.0,
+                    help="repeat the CPU phases (median) while the accumulated CPU time stays below this")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
     return ap.parse_args()
 
 
-def cpu_baseline(sample_K: int, target_K: int, iterations: int):
-    """Times the CPU oracle on a K = sample_K two-film device and extrapolates every phase to
-    the benchmark size with its complexity law (Q, A, solve, coupling ~ n^2; LU ~ n_i^3)."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the same device, measured
+# ---------------------------------------------------------------------------------------------------
+def physical_cores():
+    try:
+        cores = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        return len(cores) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(K: int, iterations: int, budget_s: float):
+    """One cold self-consistent solve of the K-ring two-film device by the CPU oracle, phase by phase, on
+    this box's host cores: dense Q in float64 (OpenMP C port of the numba kernel, distance.py:87-115),
+    A = Q[ix, ix] w - Lambda Del2 (solve_film.py:296-305), scipy lu_factor(-A) (:279), then 1 + iterations
+    passes of solve_film (lu_solve, Q @ (w g), sparse gradients; :440-574) and `iterations` rounds of the
+    all-pairs coupling (solve.py:28-73, OpenMP C port).  Nothing is extrapolated."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import build_oracle
     import cpu_kernels
     import scipy.linalg as la
     import superscreen_oracle as orc
     from matplotlib.path import Path
+    from threadpoolctl import threadpool_limits
 
     from superscreen_amd import synthetic
 
     build_oracle.build(verbose=False)
+    logical = os.cpu_count() or 1
+    phys = physical_cores() or logical
+    # thread sweep on a small LU: BLAS oversubscription (one thread per SMT sibling) can halve the rate
+    rng = np.random.default_rng(0)
+    n_probe = 6000
+    probe = rng.standard_normal((n_probe, n_probe)) + n_probe * np.eye(n_probe)
+    sweep = {}
+    for t in sorted({max(1, phys // 4), max(1, phys // 2), phys, logical}):
+        with threadpool_limits(limits=t):
+            la.lu_factor(probe[:1000, :1000])
+            t0 = time.perf_counter()
+            la.lu_factor(probe)
+            sweep[t] = (2 / 3) * n_probe ** 3 / (time.perf_counter() - t0) / 1e9
+    threads = max(sweep, key=sweep.get)
+    del probe
 
-    def sizes(K):
+    def median_timed(fn, spent, cap=3):
+        """Median wall time of up to `cap` runs of fn, stopping early once the CPU budget is used up."""
+        times, out = [], None
+        while len(times) < cap and (not times or spent[0] + times[-1] < budget_s):
+            t0 = time.perf_counter()
+            out = fn()
+            times.append(time.perf_counter() - t0)
+            spent[0] += times[-1]
+        return float(np.median(times)), len(times), out
+
+    spent = [0.0]
+    with threadpool_limits(limits=threads):
+        sites, elements, dr = synthetic.ring_disk_mesh(K)
         Kf = synthetic.film_rings(K)
-        n = synthetic.num_vertices(K)
-        ni_disk = 1 + 3 * Kf * (Kf + 1)
-        Kh = Kf // 3
-        return n, ni_disk, ni_disk - (1 + 3 * Kh * (Kh + 1))
+        mesh = orc.make_mesh(sites, elements, build_Q=False)      # sparse operators: set-up, untimed
+        in_film = Path(synthetic.circle_points((Kf + 0.5) * dr), closed=True).contains_points(sites)
+        in_hole = Path(synthetic.circle_points((Kf // 3 + 0.5) * dr, 201), closed=True).contains_points(sites)
+        C = orc.C_vector(sites)
+        n = len(sites)
 
-    sites, elements, dr = synthetic.ring_disk_mesh(sample_K)
-    Kf = synthetic.film_rings(sample_K)
-    mesh = orc.make_mesh(sites, elements, build_Q=False)      # sparse operators: set-up, untimed
-    in_film = Path(synthetic.circle_points((Kf + 0.5) * dr), closed=True).contains_points(sites)
-    in_hole = Path(synthetic.circle_points((Kf // 3 + 0.5) * dr, 201), closed=True).contains_points(sites)
-    C = orc.C_vector(sites)
-    t = {}
-    t0 = time.perf_counter()
-    q = cpu_kernels.q_matrix(sites)                            # distance.py:87 (OpenMP port)
-    diag = -(C + np.einsum("ij, j -> i", q, mesh.weights)) / mesh.weights
-    np.fill_diagonal(q, diag)
-    mesh.Q = -q                                                # device/mesh.py:453-458
-    t["q_assembly"] = time.perf_counter() - t0
-    films = []
-    t["a_assembly"] = t["lu"] = 0.0
-    for name, holes, z0 in (("washer", {"hole": in_hole}, 0.0), ("disk", {}, 0.5)):
-        t0 = time.perf_counter()
-        f = orc.make_film(name, mesh, z0=z0, Lambda=0.1, in_film=in_film, holes_mask=holes, factorize=False)
-        t["a_assembly"] += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        f.lu_piv = la.lu_factor(-f.A)                          # solver/solve_film.py:279
-        t["lu"] += time.perf_counter() - t0
-        films.append(f)
-    conv = orc.field_conversion_mT_to_uA_per_um()
-    applied = {f.name: conv * np.ones(len(sites)) for f in films}
-    t0 = time.perf_counter()
-    sols = {f.name: orc.solve_film(f, applied[f.name], field_conversion=conv) for f in films}
-    t_pass = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for src, tgt in ((films[0], films[1]), (films[1], films[0])):
-        cpu_kernels.biot_savart_film_to_film(
-            film1_sites=sites, film1_z0=src.z0, film1_areas=src.weights,
-            film1_J=sols[src.name].current_density, film2_sites=sites, film2_z0=tgt.z0)
-    t_cpl = time.perf_counter() - t0
-    ns, nis_d, nis_w = sizes(sample_K)
-    nt, nit_d, nit_w = sizes(target_K)
-    r2 = (nt / ns) ** 2
-    ri2 = (nit_d ** 2 + nit_w ** 2) / (nis_d ** 2 + nis_w ** 2)
-    ri3 = (nit_d ** 3 + nit_w ** 3) / (nis_d ** 3 + nis_w ** 3)
-    # one q_matrix per mesh; both films share the mesh in the sample, the device has 2 meshes
-    est = (2 * t["q_assembly"] * r2 + t["a_assembly"] * ri2 + t["lu"] * ri3
-           + (iterations + 1) * t_pass * (ri2 + r2) / 2 + iterations * t_cpl * r2)
+        def build_Q():
+            q = cpu_kernels.q_matrix(sites)                        # distance.py:87 (OpenMP port)
+            diag = -(C + np.einsum("ij, j -> i", q, mesh.weights)) / mesh.weights
+            np.fill_diagonal(q, diag)
+            np.negative(q, out=q)                                  # device/mesh.py:453-458
+            return q
+
+        t_q, r_q, Q = median_timed(build_Q, spent)
+        mesh.Q = Q
+        films, t_a, t_lu, r_lu, lu_flops = [], 0.0, 0.0, [], 0.0
+        for name, holes, z0 in (("washer", {"hole": in_hole}, 0.0), ("disk", {}, 0.5)):
+            t0 = time.perf_counter()
+            f = orc.make_film(name, mesh, z0=z0, Lambda=0.1, in_film=in_film, holes_mask=holes, factorize=False)
+            t_a += time.perf_counter() - t0
+            spent[0] += time.perf_counter() - t0
+
+            def factor(f=f):
+                return la.lu_factor(-f.A)                          # solver/solve_film.py:279
+
+            t, r, f.lu_piv = median_timed(factor, spent)
+            t_lu += t
+            r_lu.append(r)
+            lu_flops += (2 / 3) * len(f.film_indices) ** 3
+            films.append(f)
+        conv = orc.field_conversion_mT_to_uA_per_um()
+        applied = {f.name: conv * np.ones(n) for f in films}
+        sols = {}
+
+        def one_pass():
+            for f in films:
+                sols[f.name] = orc.solve_film(f, applied[f.name], field_conversion=conv)
+
+        t_pass, r_pass, _ = median_timed(one_pass, spent)
+
+        def coupling_round():
+            for src, tgt in ((films[0], films[1]), (films[1], films[0])):
+                cpu_kernels.biot_savart_film_to_film(
+                    film1_sites=sites, film1_z0=src.z0, film1_areas=src.weights,
+                    film1_J=sols[src.name].current_density, film2_sites=sites, film2_z0=tgt.z0)
+
+        t_cpl, r_cpl, _ = median_timed(coupling_round, spent)
+    # the device has one mesh per film (device.meshes, device/device.py): Q is built per film
+    per_solve = 2 * t_q + t_a + t_lu + (iterations + 1) * t_pass + iterations * t_cpl
     return {
-        "value": 1.0 / est,
+        "value": 1.0 / per_solve,
         "unit": "solves/s",
-        "cores": os.cpu_count(),
+        "cores": threads,
         "kind": "port",
-        "sample": (f"oracle (numpy/scipy LAPACK + OpenMP C ports of the numba kernels) on the K={sample_K} "
-                   f"two-film device (n={ns}/film, n_i={nis_w}+{nis_d}); phases extrapolated to K={target_K} "
-                   f"(n={nt}, n_i={nit_w}+{nit_d}) with n^2 (Q, A, solve, coupling) and n_i^3 (LU) laws"),
-        "sample_seconds": {"q_assembly_x1": t["q_assembly"], "a_assembly": t["a_assembly"], "lu": t["lu"],
-                           "solve_pass": t_pass, "coupling_round": t_cpl},
-        "estimated_seconds_per_solve": est,
+        "measurement": "measured at the benchmark size, no extrapolation",
+        "sample": (f"CPU oracle (numpy/scipy LAPACK + OpenMP C ports of the numba kernels) on the SAME K={K} two-film "
+                   f"device (n={n}/film, n_i={len(films[0].film_indices)}+{len(films[1].film_indices)}), every phase "
+                   f"timed at full size: seconds per solve = 2 x Q + A + LU(both films) + {iterations + 1} passes + "
+                   f"{iterations} coupling rounds; median of up to 3 runs per phase within a {budget_s:.0f} s budget"),
+        "sample_seconds": {"q_assembly_per_film": t_q, "a_assembly_both_films": t_a, "lu_both_films": t_lu,
+                           "solve_pass_both_films": t_pass, "coupling_round": t_cpl},
+        "repeats": {"q_assembly": r_q, "lu_per_film": r_lu, "solve_pass": r_pass, "coupling_round": r_cpl},
+        "seconds_per_solve": per_solve,
+        "lu_GFLOPs": lu_flops / t_lu / 1e9,
+        "threads_used": threads,
+        "logical_cpus": logical,
+        "physical_cores": phys,
+        "lu_thread_sweep_GFLOPs_n6000": {str(k): v for k, v in sweep.items()},
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 on N ranks
+# ---------------------------------------------------------------------------------------------------
+def config4_scan(sc, torch, dist, rank, world, iterations):
+    """64-value applied-field scan of the config-3 device (washer + shield disk, K = 81: 2 x 19 927 vertices)
+    through parallel.solve_sweep_sharded.  Every rank factorizes its own replica inside the timed region."""
+    from superscreen_amd import synthetic
+    from superscreen_amd.parallel import solve_sweep_sharded
+
+    device = synthetic.make_stack_device(81, ("washer", "disk"), solve_dtype="float64")
+    scan = [float(v) for v in np.linspace(0.1, 6.4, 64)]          # mT (SURVEY.md section 8d)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def run(fields, shard):
+        model = sc.factorize_model(device=device, current_units="uA")
+        if shard:
+            out = solve_sweep_sharded(model, fields, rank=rank, world=world, iterations=iterations, all_iterations=False)
+            local = out[2]
+        else:
+            local = sc.solve_sweep(model, fields, iterations=iterations, all_iterations=False)
+        torch.cuda.synchronize()
+        return len(local)
+
+    run(scan[:max(2, 64 // world)], False)                        # warm-up: allocator, lazy initialisation
+    res = {}
+    for label, shard in (("strong", True), ("weak", False)):
+        barrier()
+        t0 = time.perf_counter()
+        n_local = run(scan, shard)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        total = n_local
+        if dist is not None:
+            tt = torch.tensor([elapsed, float(n_local)], dtype=torch.float64, device="cuda")
+            tmax = tt.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            elapsed, total = float(tmax[0].item()), int(round(tt[1].item()))
+        res[f"config4_{label}_fields_total"] = total
+        res[f"config4_{label}_seconds"] = elapsed
+        res[f"config4_{label}_solves_per_s"] = total / elapsed
+    res["config4_note"] = ("config-3 device, 64 fields linspace(0.1, 6.4) mT, 10 iterations, final iterate returned as "
+                           "Solutions; strong = 64 fields over the ranks, weak = 64 fields per rank; each rank's "
+                           "factorization is inside the timed region; no data-path collective")
+    return res
+
+
+def config5_stack(sc, torch, dist, rank, world, iterations, steps=2):
+    """Cold self-consistent solve of the 4-film stack (4 disks on the K = 100 mesh: 4 x 30 301 vertices, z = 0,
+    0.5, 1.0, 1.5 um) on `world` ranks."""
+    from superscreen_amd import synthetic
+    from superscreen_amd.parallel import CouplingPlan, FilmPlacement
+
+    device = synthetic.make_stack_device(100, ("disk",) * 4, z_spacing=0.5, solve_dtype="float64")
+    films = list(device.films)
+    placement = coupling = None
+    if world > 1 and world <= len(films):
+        placement, mode = FilmPlacement(rank=rank, world=world), "FilmPlacement (owner computes; one all-reduce of the result vectors per pass)"
+    elif world > 1:
+        coupling, mode = CouplingPlan(rank=rank, world=world), "CouplingPlan (source slices; one fused all-reduce of the coupling vector per iteration; factor / solve replicated)"
+    else:
+        mode = "single GPU"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        model = sc.factorize_model(device=device, current_units="uA", placement=placement)
+        sols = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=iterations,
+                        placement=placement, coupling=coupling)
+        return model, sols
+
+    model, sols = step()                                           # warm-up
+    model = sols = None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model = sols = None
+        model, sols = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    g = sols[-1].film_solutions[films[0]].stream
+    assert np.isfinite(g).all() and len(sols) == iterations + 1
+    checksum = float(np.abs(g).max())
+    del model, sols
+    torch.cuda.empty_cache()
+    return {"config5_solves_per_s": steps / elapsed, "config5_ms_per_solve": elapsed / steps * 1e3,
+            "config5_mode": mode, "config5_vertices_per_film": len(device.meshes[films[0]].sites),
+            "config5_max_abs_stream_film0": checksum}
 
 
 def main():
@@ -200,7 +368,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path.")
     # BENCH_SHARE_GPU=1 (testing aid for single-GPU boxes): all ranks use cuda:0 and gloo carries the
-    # barrier / max-reduce, so that the N > 1 control flow can be exercised without N GPUs
+    # collectives, so that the N > 1 control flow can be exercised without N GPUs
     share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
@@ -213,6 +381,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        warm = torch.ones(1, device="cuda")
+        dist.all_reduce(warm)                                      # communicator set-up outside every timed region
+        torch.cuda.synchronize()
 
     import superscreen_amd as sc
     from superscreen_amd import _hip, kernels, synthetic
@@ -252,27 +423,31 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = {}
     for kind, label in ((0, "ssa::gemm_kernel<double, true> (NN: LU trailing / in-panel updates)"),
-                        (1, "ssa::gemm_op_kernel<double, 0, 1, true> (SYRK on the lower tiles: Cholesky trailing update)")):
+                        (1, "ssa::gemm_op_kernel<double, 0, 1, true> (SYRK on the lower tiles: Cholesky trailing update)"),
+                        (2, "ssa::gemm_op_kernel<double, 0, 1, false> (Cholesky strips and L21 = A21 W^T panel products)")):
         ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
         _hip.check(lib.ssa_profile_read(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)),
                    "ssa_profile_read")
         prof[label] = (ms.value, fl.value, cnt.value)
     _hip.check(lib.ssa_profile_end(), "ssa_profile_end")
-    dom_label = max(prof, key=lambda k: prof[k][0])
-    gemm_ms, gemm_fl, gemm_n = (ctypes.c_double(prof[dom_label][0]), ctypes.c_double(prof[dom_label][1]),
-                                ctypes.c_int64(prof[dom_label][2]))
+    labels = list(prof)
+    dom_label = max(labels[:2], key=lambda k: prof[k][0])
+    gemm_ms, gemm_fl, gemm_n = prof[dom_label]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     total_solves = args.steps * world
     value = total_solves / elapsed
+    unknowns = [int(len(s.indices)) for s in model.film_systems.values()]
+    used_chol = all(s.chol is not None for s in model.film_systems.values())
 
+    extras = {}
     if rank == 0:
         # sanity: the last step's answer is a converged, finite screening solution
         g = sols[-1].film_solutions["disk1"].stream
         assert np.isfinite(g).all() and len(sols) == args.iterations + 1
-        extras = {}
+    if rank == 0 and not args.no_extras:
         # Q-assembly throughput of one film's dense kernel matrix (not part of the timed step)
         fd = model.film_data["washer0"]
         ld = kernels.padded_ld(n, "float64")
@@ -291,13 +466,39 @@ def main():
         extras["q_assembly_GBps"] = n * n * 8 / tq / 1e9
         extras["q_assembly_ms"] = tq * 1e3
         extras["q_assembly_frac_of_hbm_peak"] = extras["q_assembly_GBps"] / HBM_PEAK_GBPS
+        # the plain fill kernel on the same buffer: what a pure store stream reaches on this box
+        kernels.fill_probe(Q)
+        ts = []
+        for _ in range(5):
+            e0.record()
+            kernels.fill_probe(Q)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        extras["fill_probe_GBps"] = Q.numel() * 8 / float(np.median(ts)) / 1e9
         del Q
+        # the factorization alone (assembly + Cholesky of both films; the step's first phase)
+        tf = []
+        for _ in range(3):
+            model = sols = None
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model = sc.factorize_model(device=device, current_units="uA")
+            torch.cuda.synchronize()
+            tf.append(time.perf_counter() - t1)
+        t_fact = float(np.median(tf))
+        fact_flops = sum(u ** 3 / 3.0 for u in unknowns) if used_chol else sum(2.0 * u ** 3 / 3.0 for u in unknowns)
+        extras["factorization_ms"] = t_fact * 1e3
+        extras["factorization_TFLOPs"] = fact_flops / t_fact / 1e12
+        extras["factorization_frac"] = fact_flops / t_fact / 1e12 / FP64_MFMA_PEAK_TFLOPS
+        extras["step_TFLOPs_factorization_flops_only"] = fact_flops / (elapsed / args.steps) / 1e12
         # what a bare register-only v_mfma_f64 stream (8 waves per SIMD, no memory, no LDS) is held at on
         # this box right now: 45-62 TFLOP/s observed -- the chip lowers its clock under a pure MFMA load,
         # so this is a power-management reading, not a ceiling (the SYRK engine itself reaches 67 TFLOP/s
         # at K = 2048, tools/probes/syrk_k_probe.py); the roofline fraction is priced against 78.6
         extras["fp64_mfma_register_only_TFLOPs"] = kernels.mfma_probe(4000)
         # field map above the device: 512 x 512 image, all-pairs Biot-Savart of one film
+        sols = sc.solve(model=model, applied_field=sc.ConstantField(0.3), iterations=args.iterations)
         gx = torch.linspace(-6.0, 6.0, 512, dtype=torch.float64, device="cuda")
         ev = torch.stack([gx.repeat_interleave(512), gx.repeat(512), torch.full((512 * 512,), 1.0, dtype=torch.float64,
                                                                                 device="cuda")], dim=1).contiguous()
@@ -316,9 +517,8 @@ def main():
             sc.solve(model=model, applied_field=sc.ConstantField(0.3 + i), iterations=args.iterations)
         torch.cuda.synchronize()
         extras["warm_self_consistent_solves_per_s"] = 3 / (time.perf_counter() - t1)
-        # BASELINE config 4: a 64-value applied-field scan of the same device carried as the columns of
-        # one multi-right-hand-side solve (solve_sweep; final iterate of every field returned as
-        # Solutions on the host).  Reported per GPU; scans shard across ranks without a collective.
+        # a 64-value applied-field scan of the SAME (config H) device carried as the columns of one
+        # multi-right-hand-side solve (solve_sweep; final iterate of every field returned as Solutions)
         scan = [0.05 * (k + 1) for k in range(64)]
         sc.solve_sweep(model, scan[:8], iterations=args.iterations, all_iterations=False)
         torch.cuda.synchronize()
@@ -337,7 +537,35 @@ def main():
         conv = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=200, tolerance=1e-8,
                         return_solutions=True)
         extras["iterations_to_1e-8"] = len(conv) - 1
-        achieved = gemm_fl.value / (gemm_ms.value * 1e-3) / 1e12 if gemm_ms.value > 0 else 0.0
+        del conv
+    model = sols = None
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        # BASELINE configs 4 and 5 on all ranks (collective calls: every rank takes part)
+        for fn in (config4_scan, config5_stack):
+            res = fn(sc, torch, dist, rank, world, args.iterations)
+            if rank == 0:
+                extras.update(res)
+            torch.cuda.empty_cache()
+
+    if rank == 0:
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        avg_us = gemm_ms * 1e3 / max(1, gemm_n)
+        avg_gflop = gemm_fl / max(1, gemm_n) / 1e9
+        is_syrk = "gemm_op_kernel" in dom_label
+        traffic_doc, traffic_src = load_profile(PMC_TRAFFIC_FILES) if is_syrk else (None, None)
+        mfma_doc, mfma_src = load_profile(PMC_MFMA_FILES) if is_syrk else (None, None)
+        traffic = float(traffic_doc["traffic_bytes_per_launch"]) if traffic_doc else None
+        stale = None
+        if traffic_doc is not None:
+            # the PMC summary records what the profiled run looked like; a kernel that has changed since
+            # shows up as a different average launch (duration or flops)
+            ref_us, ref_gf = traffic_doc.get("avg_launch_us"), traffic_doc.get("avg_launch_gflop")
+            if ref_us is None or ref_gf is None:
+                stale = True
+            else:
+                stale = bool(abs(avg_us / ref_us - 1) > 0.05 or abs(avg_gflop / ref_gf - 1) > 0.05)
+        strip_ms, strip_fl, strip_n = prof[labels[2]]
         out = {
             "metric": "self_consistent_solves_per_sec",
             "value": value,
@@ -356,9 +584,9 @@ def main():
                              f"mesh, {n} vertices/film ({2 * n} total), Lambda=0.1 um, uniform field, "
                              f"{args.iterations} Jacobi iterations, factorization included in every step"),
                 "vertices_per_film": n,
-                "unknowns": [int(len(s.indices)) for s in model.film_systems.values()],
+                "unknowns": unknowns,
                 "iterations": args.iterations,
-                "parallelism": f"field-sweep sharding x{world} (no data-path collective)",
+                "parallelism": f"independent solves x{world} (one per rank and step; no data-path collective)",
             },
             "roofline": {
                 "kernel": dom_label + ", v_mfma_f64_16x16x4_f64",
@@ -367,20 +595,28 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic() if "gemm_op_kernel" in dom_label else None,
-                "traffic_source": "profiles/r01_v7_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                  "this command; bytes per launch, fetch x2 per MI355X_MICROARCH.md)",
-                "algorithmic_bytes_per_launch": syrk_algorithmic_bytes(
-                    [int(len(s.indices)) for s in model.film_systems.values()])[0],
-                "launches": int(gemm_n.value),
-                "avg_launch_us": gemm_ms.value * 1e3 / max(1, gemm_n.value),
-                "avg_launch_gflop": gemm_fl.value / max(1, gemm_n.value) / 1e9,
-                "mfma_pipe": pmc_mfma() if "gemm_op_kernel" in dom_label else None,
+                "traffic": traffic,
+                "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; "
+                                   "bytes per launch, fetch x2 per MI355X_MICROARCH.md)") if traffic_src else None,
+                "traffic_stale": stale,
+                "algorithmic_bytes_per_launch": chol_schedule(unknowns)[0],
+                "launches": int(gemm_n),
+                "avg_launch_us": avg_us,
+                "avg_launch_gflop": avg_gflop,
+                "mfma_pipe": ({"mfma_busy_fraction_of_active_cycles": float(mfma_doc["mfma_busy_fraction_of_active_cycles"]),
+                               "effective_clock_GHz": float(mfma_doc["effective_clock_GHz"]),
+                               "source": f"{mfma_src} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                                         "SQ_INSTS_VALU_MFMA_MOPS_F64 pass of this command)"} if mfma_doc else None),
+                "factorization_frac": extras.get("factorization_frac"),
+                "other_kernels": {
+                    labels[2]: {"launches": int(strip_n), "avg_launch_us": strip_ms * 1e3 / max(1, strip_n),
+                                "TFLOPs": (strip_fl / (strip_ms * 1e-3) / 1e12) if strip_ms > 0 else 0.0},
+                },
             },
             "extras": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_K, args.K, args.iterations)
+            out["cpu_baseline"] = cpu_baseline(args.K, args.iterations, args.cpu_budget_s)
             out["extras"]["gpu_over_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -45,6 +45,7 @@ extern "C" {
 #define SSA_ERR_HIP (-2)
 #define SSA_ERR_WORKSPACE_TOO_SMALL (-3)
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
+#define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
 #define SSA_ABI_VERSION 1
 
@@ -327,8 +328,10 @@ int ssa_gemm_ex(int opA, int opB, int lower_only, int64_t M, int64_t N, int64_t 
  * ssa_profile_read(kind, ...) waits for the recorded events of one kernel kind and returns the
  * summed kernel time [ms], the summed algorithmic flops and the launch count:
  *   kind 0: gemm_kernel<double, true>                 (LU trailing / in-panel updates, 2 M N K)
- *   kind 1: gemm_op_kernel<double, N, T>, lower_only  (Cholesky trailing SYRK; flops of the
- *           tiles actually computed: K * M * (M + 128))
+ *   kind 1: gemm_op_kernel<double, N, T>, lower_only  (Cholesky trailing SYRK; algorithmic flops of the
+ *           entries on / below the diagonal: K * M * (M + 1))
+ *   kind 2: gemm_op_kernel<double, N, T>, all tiles   (the Cholesky chain's strips and L21 = A21 W^T
+ *           panel products; 2 M N K)
  */
 int ssa_profile_begin(void);
 int ssa_profile_read(int kind, double *ms, double *flops, int64_t *launches);
@@ -370,6 +373,44 @@ int ssa_fill_probe(void *dst, size_t bytes, void *stream);
  * the practical ceiling next to the nominal 78.6 TFLOP/s.  sink: >= 8 bytes of device memory.
  */
 int ssa_mfma_probe(int iters, void *sink, double *flops_out, void *stream);
+
+/* ---------------------------------------------------------------------------------- */
+/* (7) Inter-film coupling across GPUs: RCCL all-reduce of the coupling vector         */
+/* ---------------------------------------------------------------------------------- */
+
+/*
+ * The reference sums the field of every other film into other_screening_fields[film] in one process
+ * (solver/solve.py:491-515).  With the ordered film pairs split by SOURCE SLICE over the ranks of a node
+ * (ssa_biot_savart's src_begin / src_end), every rank holds a partial sum of the concatenated coupling
+ * vector [sum_f n_f]; ONE in-place sum all-reduce per Jacobi iteration completes it (0.97 MB for the
+ * 4 x 30 301 stack of BASELINE config 5: a single latency-bound ring pass over xGMI).
+ *
+ *   ssa_coupling_allreduce   buf <- sum over ranks of buf, in place, on `stream` (enqueue only).
+ *       buf [count] dtype (device), rccl_comm: an ncclComm_t (from ssa_rccl_comm_create, or any
+ *       communicator the caller already owns: RCCL's own handle type, passed as void*).
+ *
+ * Communicator helpers for callers that have no RCCL binding of their own (one process per GPU; the
+ * 128-byte id travels from rank 0 to the others by whatever channel the caller has -- MPI, a file,
+ * torch.distributed's store):
+ *   ssa_rccl_unique_id      id_out: 128 bytes of HOST memory                    (ncclGetUniqueId)
+ *   ssa_rccl_comm_create    collective over all ranks; uses the current device  (ncclCommInitRank)
+ *   ssa_rccl_comm_destroy                                                       (ncclCommDestroy)
+ * librccl.so is opened on first use (dlopen), so the library loads on machines without RCCL; these
+ * calls then return SSA_ERR_RCCL.
+ */
+#define SSA_RCCL_UNIQUE_ID_BYTES 128
+int ssa_rccl_unique_id(void *id_out);
+int ssa_rccl_comm_create(void **comm_out, int nranks, int rank, const void *id);
+int ssa_rccl_comm_destroy(void *comm);
+int ssa_coupling_allreduce(void *buf, int64_t count, int dtype, void *rccl_comm, void *stream);
+
+/*
+ * Releases what the library created behind the caller's back on every device of the process: the
+ * look-ahead side streams and events of the factorization schedules (created on first use, reused by
+ * every later call) and the events of ssa_profile_*.  Waits for the side streams first.  The library
+ * stays usable: the next factorization creates its lanes again.
+ */
+int ssa_shutdown(void);
 
 #ifdef __cplusplus
 }

@@ -427,6 +427,142 @@ def sheet_field_fixture(fname):
     print("wrote", fname)
 
 
+# ---- a small working quantity type, for the two Solution methods that do unit arithmetic -------------
+# ``Solution.vector_potential_at_position`` / ``polygon_flux`` (solution.py:833-934, 430-482) multiply
+# arrays by ``device.ureg(...)`` quantities and call ``.to(units)``.  pint is absent here, so for THESE
+# two calls the fixture script hands the reference a stand-in registry that really does the arithmetic:
+# magnitudes times an SI scale with exponents over (length, current, mass, time).  The constants are
+# written out here (pint's CODATA 2018 mu_0); nothing of the product package is involved.
+class _Dim(dict):
+    """Dimensionality with pint's two uses in convert_field: ``==`` and ``"[length]" in``."""
+
+
+class MiniQ:
+    __array_ufunc__ = None  # ndarray * MiniQ -> MiniQ.__rmul__
+
+    def __init__(self, magnitude, scale=1.0, dims=(0, 0, 0, 0)):
+        self.magnitude, self.scale, self.dims = magnitude, float(scale), tuple(dims)
+
+    @property
+    def units(self):
+        return MiniQ(1.0, self.scale, self.dims)
+
+    @property
+    def dimensionality(self):
+        names = ("[length]", "[current]", "[mass]", "[time]")
+        return _Dim({n: e for n, e in zip(names, self.dims) if e})
+
+    def _coerce(self, other):
+        return other if isinstance(other, MiniQ) else MiniQ(other)
+
+    def __mul__(self, other):
+        o = self._coerce(other)
+        return MiniQ(self.magnitude * o.magnitude, self.scale * o.scale, tuple(a + b for a, b in zip(self.dims, o.dims)))
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        o = self._coerce(other)
+        return MiniQ(self.magnitude / o.magnitude, self.scale / o.scale, tuple(a - b for a, b in zip(self.dims, o.dims)))
+
+    def __rtruediv__(self, other):
+        return self._coerce(other) / self
+
+    def __pow__(self, k):
+        return MiniQ(self.magnitude ** k, self.scale ** k, tuple(a * k for a in self.dims))
+
+    def __add__(self, other):
+        o = self._coerce(other)
+        if isinstance(other, (int, float)) and other == 0:  # sum() starts from 0
+            return self
+        assert o.dims == self.dims
+        return MiniQ(self.magnitude + o.magnitude * (o.scale / self.scale), self.scale, self.dims)
+
+    __radd__ = __add__
+
+    def __getitem__(self, ix):
+        return MiniQ(self.magnitude[ix], self.scale, self.dims)
+
+    def to(self, units):
+        u = units if isinstance(units, MiniQ) else mini_ureg(units)
+        assert u.dims == self.dims, (u.dims, self.dims)
+        return MiniQ(self.magnitude * (self.scale / u.scale) / u.magnitude, u.scale, u.dims)
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.einsum:  # polygon_flux: np.einsum("i, i -> ", field, area)
+            ops = [MiniQ(a) if not isinstance(a, MiniQ) else a for a in args[1:]]
+            out = MiniQ(1.0)
+            for o in ops:
+                out = out * MiniQ(1.0, o.scale, o.dims)
+            return MiniQ(np.einsum(args[0], *[o.magnitude for o in ops]), out.scale, out.dims)
+        return NotImplemented
+
+
+_L, _I, _M, _T = (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)
+_TESLA = (0, -1, 1, -2)                       # kg / (A s^2)
+_MINI_UNITS = {
+    "m": MiniQ(1.0, 1.0, _L), "um": MiniQ(1.0, 1e-6, _L), "A": MiniQ(1.0, 1.0, _I), "uA": MiniQ(1.0, 1e-6, _I),
+    "T": MiniQ(1.0, 1.0, _TESLA), "mT": MiniQ(1.0, 1e-3, _TESLA),
+    "mu_0": MiniQ(1.0, MU_0, (1, -2, 1, -2)), "mu0": MiniQ(1.0, MU_0, (1, -2, 1, -2)),   # T m / A
+}
+
+
+def mini_ureg(expr):
+    """``ureg("mT * um**2")``: the handful of unit expressions the two methods use."""
+    return eval(expr, {"__builtins__": {}}, dict(_MINI_UNITS))  # noqa: S307 (fixed table, test infrastructure)
+
+
+class PolygonStub(TerminalStub):
+    def __init__(self, name, layer, points):
+        super().__init__(name, points)
+        self.layer = layer
+
+
+def potential_and_flux_fixture(fname):
+    """``Solution.vector_potential_at_position`` (solution.py:833-934) and ``Solution.polygon_flux``
+    (:430-482), the reference's methods themselves, called on a stand-in ``self`` that carries what they
+    read: device (layers, films, holes, meshes, ureg), units, and per-film ``current_density`` /
+    ``total_field`` arrays (random: the methods are linear maps of them)."""
+    import pint  # the stub module installed by _ref_stubs
+
+    from superscreen.solution import Solution  # the reference
+
+    pint.Quantity = MiniQ  # convert_field (solver/utils.py:378-393) tests isinstance(value, pint.Quantity)
+    rng = np.random.default_rng(11)
+    K = 9
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = Mesh.from_triangulation(sites, elements)
+    Kf = synthetic.film_rings(K)
+    film_poly = synthetic.circle_points((Kf + 0.5) * dr)
+    hole_poly = synthetic.circle_points((Kf // 3 + 0.5) * dr, 201)
+    names, z0s = ["washer0", "disk1"], [0.0, 0.5]
+    films = {nm: PolygonStub(nm, f"layer{i}", film_poly) for i, nm in enumerate(names)}
+    holes = {"hole0": PolygonStub("hole0", "layer0", hole_poly)}
+    device = SimpleNamespace(
+        layers={f"layer{i}": SimpleNamespace(z0=z) for i, z in enumerate(z0s)}, films=films, holes=holes,
+        meshes={nm: mesh for nm in names}, solve_dtype=np.dtype("float64"), ureg=mini_ureg, length_units="um",
+        get_polygons=lambda include_terminals=True: list(films.values()) + list(holes.values()))
+    n = len(sites)
+    J = {nm: rng.standard_normal((n, 2)) for nm in names}
+    total_field = {nm: rng.standard_normal(n) for nm in names}
+    me = SimpleNamespace(device=device, field_units="mT", current_units="uA",
+                         film_solutions={nm: SimpleNamespace(current_density=J[nm], total_field=total_field[nm])
+                                         for nm in names})
+    pts = np.concatenate([
+        np.column_stack([rng.uniform(-7, 7, 40), rng.uniform(-7, 7, 40), rng.uniform(0.7, 3.0, 40)]),
+        np.column_stack([rng.uniform(-4, 4, 8), rng.uniform(-4, 4, 8), rng.uniform(-2.0, -0.2, 8)])])
+    A = Solution.vector_potential_at_position(me, pts, units="mT * um", with_units=False, return_sum=False)
+    A_sum = Solution.vector_potential_at_position(me, pts[:, :2], zs=1.25, units="mT * um", with_units=False)
+    out = dict(K=K, names=np.array(names), z0s=np.asarray(z0s), eval_xyz=pts, zs_plane=1.25, A_sum_plane=A_sum)
+    for nm in names:
+        out[f"J_{nm}"], out[f"total_field_{nm}"], out[f"A_{nm}"] = J[nm], total_field[nm], A[nm]
+    for poly in ("washer0", "disk1", "hole0"):
+        out[f"flux_{poly}_mT_um2"] = float(Solution.polygon_flux(me, poly, with_units=False))
+        out[f"flux_{poly}_T_m2"] = float(Solution.polygon_flux(me, poly, units="T * m**2", with_units=False))
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, {k: v for k, v in out.items() if k.startswith("flux_")})
+
+
 def mutual_fixture(K, kinds, z0s, Lambda, iterations, fname, I_circ=1000.0):
     """Raw fluxoid parts behind ``Device.mutual_inductance_matrix`` (device/device.py:538-648):
     for every hole j, a circulating current I_circ (uA) in hole j only, no applied field, the Jacobi
@@ -524,6 +660,9 @@ if __name__ == "__main__":
     if "--only-sheet-field" in sys.argv:
         sheet_field_fixture("sheet_field.npz")
         sys.exit(0)
+    if "--only-potential" in sys.argv:
+        potential_and_flux_fixture("potential_flux.npz")
+        sys.exit(0)
     single_film_fixture(10, False, [0.0, 0.1, 1.0], [0.0], "disk_K10.npz", full_Q=True)
     single_film_fixture(26, False, [0.1], [0.0], "disk_K26.npz", full_Q=False)
     single_film_fixture(17, True, [0.1, 1.0], [0.0, 1.0], "washer_K17.npz", full_Q=False)
@@ -533,6 +672,7 @@ if __name__ == "__main__":
     biot_savart_fixture("biot_savart.npz")
     mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
     sheet_field_fixture("sheet_field.npz")
+    potential_and_flux_fixture("potential_flux.npz")
     vortex_fixture(13, False, "vortex_disk_K13.npz")
     vortex_fixture(13, True, "vortex_washer_K13.npz")
     inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")

@@ -674,3 +674,21 @@ def biot_savart_2d(x, y, z, *, positions, current_densities, z0=0.0, areas, leng
     if not vector:
         return Bz
     return np.stack([np.sum(pref * Jy * dz, axis=1), -np.sum(pref * Jx * dz, axis=1), Bz], axis=1)
+
+
+def vector_potential(positions_xyz, *, sites, z0, areas, J, current_to_A=1e-6, out_T_m_to=1e3 * 1e6) -> np.ndarray:
+    """solution.py:900-931 for one film: ``A = mu_0 / (4 pi) sum_j a_j J_j / rho_ij``, rho including dz;
+    J in uA/um and lengths in um give a current in uA; result converted T m -> mT um by default.
+    Returns ``(m, 3)`` with ``A_z = 0``."""
+    positions_xyz = np.atleast_2d(np.asarray(positions_xyz, dtype=float))
+    d2 = ((positions_xyz[:, None, :2] - sites[None, :, :]) ** 2).sum(axis=2)
+    rho = np.sqrt(d2 + (positions_xyz[:, 2, None] - z0) ** 2)[:, :, None]
+    Axy = np.einsum("ijk, j -> ik", J / rho, areas)
+    A = np.concatenate([Axy, np.zeros_like(Axy[:, :1])], axis=1)
+    return MU_0 / (4 * np.pi) * A * current_to_A * out_T_m_to
+
+
+def polygon_flux_raw(total_field, vertex_areas, in_polygon) -> float:
+    """solution.py:470-478 in raw units (field_units * length_units^2): ``sum_{i in polygon} B_i a_i``."""
+    ix = np.where(in_polygon)[0]
+    return float(np.einsum("i, i -> ", total_field[ix], vertex_areas[ix]))

@@ -76,6 +76,11 @@ SIGNATURES = {
     "ssa_mfma_probe": (c_int, [c_int, P, P, P]),
     "ssa_profile_begin": (c_int, []),
     "ssa_profile_end": (c_int, []),
+    "ssa_rccl_unique_id": (c_int, [P]),
+    "ssa_rccl_comm_create": (c_int, [P, c_int, c_int, P]),
+    "ssa_rccl_comm_destroy": (c_int, [P]),
+    "ssa_coupling_allreduce": (c_int, [P, I64, c_int, P, P]),
+    "ssa_shutdown": (c_int, []),
 }
 
 _lib: Optional[ctypes.CDLL] = None

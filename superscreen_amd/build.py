@@ -22,7 +22,7 @@ OBJDIR = os.path.join(PKG, "build")
 LIBNAME = "libsuperscreen_hip.so"
 ARCH = "gfx950"
 SOURCES = ["capi.hip", "assemble.hip", "pairwise.hip", "pairwise_multi.hip", "blas1.hip", "gemm.hip", "gemm_ops.hip",
-           "lu.hip", "chol.hip"]
+           "lu.hip", "chol.hip", "collective.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 
@@ -66,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs = list(ex.map(compile_one, SOURCES))
     out = lib_path()
     if force or not _newer(out, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

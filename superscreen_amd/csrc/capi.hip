@@ -1,7 +1,11 @@
 // Library-level entry points of libsuperscreen_hip.so (version, error strings, device info).
 #include <string.h>
 
-#include "common.hpp"
+#include "gemm_profile.hpp"
+
+namespace ssa {
+int chol_shutdown();
+}
 
 extern "C" int ssa_abi_version(void) { return SSA_ABI_VERSION; }
 
@@ -12,6 +16,7 @@ extern "C" const char *ssa_error_string(int status) {
         case SSA_ERR_HIP: return "HIP runtime error (launch or API call failed)";
         case SSA_ERR_WORKSPACE_TOO_SMALL: return "workspace missing or too small";
         case SSA_ERR_UNSUPPORTED_SIZE: return "problem size not supported by this build";
+        case SSA_ERR_RCCL: return "RCCL not available (librccl.so could not be opened) or an RCCL call failed";
         default: return "unknown status";
     }
 }
@@ -29,4 +34,10 @@ extern "C" int ssa_device_info(int *num_cus, size_t *hbm_bytes, char *arch_name,
         arch_name[arch_name_len - 1] = '\0';
     }
     return SSA_OK;
+}
+
+extern "C" int ssa_shutdown(void) {
+    const int a = ssa::chol_shutdown();
+    const int b = ssa::profile_shutdown();
+    return a != SSA_OK ? a : b;
 }

@@ -196,14 +196,21 @@ struct CholLane {
 };
 constexpr int kMaxLanes = 16;
 
-inline int get_lanes(int count, CholLane **out) {
-    constexpr int kMaxDevices = 32;
-    static CholLane per_device[kMaxDevices][kMaxLanes];  // streams belong to the device they were made on
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
+// The lanes of one device and the mutex that serialises schedules on that device (the lanes are the
+// schedule's streams and events; other devices of the process enqueue concurrently).  Created on first
+// use, destroyed by ssa_shutdown().
+struct LaneSet {
+    CholLane lanes[kMaxLanes];
+    std::mutex enqueue;
+};
+LaneSet g_lane_sets[kMaxDevices];
+std::mutex g_lane_create_mutex;
+
+inline int get_lanes(int count, LaneSet **out) {
+    std::lock_guard<std::mutex> lock(g_lane_create_mutex);
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return SSA_ERR_HIP;
-    CholLane *lanes = per_device[dev];
+    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
+    CholLane *lanes = g_lane_sets[dev].lanes;  // streams belong to the device they were made on
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
     for (int i = 0; i < count; ++i) {
@@ -217,8 +224,27 @@ inline int get_lanes(int count, CholLane **out) {
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
-    *out = lanes;
+    *out = &g_lane_sets[dev];
     return SSA_OK;
+}
+
+// Destroys every lane of every device (ssa_shutdown): waits for the side streams first.
+inline int destroy_lanes() {
+    std::lock_guard<std::mutex> lock(g_lane_create_mutex);
+    int rc = SSA_OK;
+    for (int d = 0; d < kMaxDevices; ++d) {
+        std::lock_guard<std::mutex> enq(g_lane_sets[d].enqueue);
+        for (CholLane &ln : g_lane_sets[d].lanes) {
+            if (ln.side == nullptr) continue;
+            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.finish) != hipSuccess) rc = SSA_ERR_HIP;
+            hipEvent_t evs[5] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk};
+            for (hipEvent_t e : evs)
+                if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
+            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.finish) != hipSuccess) rc = SSA_ERR_HIP;
+            ln = CholLane{};
+        }
+    }
+    return rc;
 }
 
 template <typename T>
@@ -240,14 +266,10 @@ int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     T *scratch = J.aux + aux_layout(n).scratch;
     T *W = J.aux + (k0 / SNB) * SNB * SNB + (k0 % SNB) * (SNB + 1);
     if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(sizeof(cholk::Ge64Smem<T>))) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
-    }
+    static DeviceFlags lds_flags;  // > 64 KB of dynamic LDS needs an explicit opt-in, per device
+    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<T>),
+                                       sizeof(cholk::Ge64Smem<T>)}}) != SSA_OK)
+        return SSA_ERR_HIP;
     hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), sizeof(cholk::Ge64Smem<T>), s,
                        J.A + k0 * (lda + 1),
                        static_cast<int>(lda), W, static_cast<int>(SNB), scratch, J.info, static_cast<int>(k0 + 1));
@@ -383,12 +405,12 @@ struct FinishPlan {
 template <typename T>
 int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
-    // the lanes (side streams + events) are shared per process: one schedule is enqueued at a time
-    static std::mutex enqueue_mutex;
-    std::lock_guard<std::mutex> enqueue_lock(enqueue_mutex);
-    CholLane *lanes = nullptr;
-    int rc = get_lanes(count, &lanes);
+    // the lanes (side streams + events) are shared per device: one schedule per device is enqueued at a time
+    LaneSet *lane_set = nullptr;
+    int rc = get_lanes(count, &lane_set);
     if (rc != SSA_OK) return rc;
+    std::lock_guard<std::mutex> enqueue_lock(lane_set->enqueue);
+    CholLane *lanes = lane_set->lanes;
     // outer steps (per matrix) that are chain bound: the last ~6k columns at this panel speed
     constexpr int64_t kTailCols = 6144;
     FinishPlan<T> plans[kMaxLanes];
@@ -542,6 +564,10 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
 }  // namespace ssa
 
 using namespace ssa;
+
+namespace ssa {
+int chol_shutdown() { return destroy_lanes(); }
+}  // namespace ssa
 
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
     const int64_t np = ceil_div(n, CNB) * CNB;

@@ -4,6 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <initializer_list>
+#include <utility>
+
 #include "../../include/superscreen_hip.h"
 
 namespace ssa {
@@ -18,6 +21,29 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
             return SSA_ERR_HIP;                       \
         }                                             \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) (the opt-in above 64 KiB of dynamic LDS) applies to the
+// CURRENT device only: one flag per call site and device, so that a process that drives several GPUs
+// raises the limit on each of them.
+constexpr int kMaxDevices = 64;
+struct DeviceFlags {
+    bool set[kMaxDevices] = {};
+};
+inline int current_device(int *dev) {
+    if (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= kMaxDevices) return SSA_ERR_HIP;
+    return SSA_OK;
+}
+inline int raise_dynamic_lds(DeviceFlags &flags, std::initializer_list<std::pair<const void *, size_t>> kernels) {
+    int dev = 0;
+    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
+    if (flags.set[dev]) return SSA_OK;
+    for (const auto &k : kernels)
+        if (hipFuncSetAttribute(k.first, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(k.second)) !=
+            hipSuccess)
+            return SSA_ERR_HIP;
+    flags.set[dev] = true;
+    return SSA_OK;
+}
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -366,17 +366,10 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, in
                          ((bs.b1 * sizeof(T)) % 16 == 0) && ((bs.b2 * sizeof(T)) % 16 == 0);
     const dim3 grid(static_cast<unsigned>(ntm * ntn), static_cast<unsigned>(batch1),
                     static_cast<unsigned>(batch2));
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(smem)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(smem)) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
-    }
+    static DeviceFlags lds_flags;  // > 64 KiB of dynamic LDS needs an explicit opt-in, per device
+    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&gemm_kernel<T, true>), smem},
+                                      {reinterpret_cast<const void *>(&gemm_kernel<T, false>), smem}}) != SSA_OK)
+        return SSA_ERR_HIP;
     ProfileScope scope(aligned && sizeof(T) == 8 && bs.tri == 0, kProfileGemmNN, 2.0 * M * N * K * batch1 * batch2, st);
     if (aligned) {
         hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(kGemmThreads), smem, st, M, N, K,

@@ -380,18 +380,14 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
     const int aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
                         ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
     const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB, LOWER>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(smem)) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
-    }
+    static DeviceFlags lds_flags;
+    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB, LOWER>), smem}}) !=
+        SSA_OK)
+        return SSA_ERR_HIP;
     // algorithmic flops (lower: the M (M + 1) / 2 entries on/below the diagonal)
     const double flops = 2.0 * static_cast<double>(K) * (lower ? 0.5 * static_cast<double>(M) * (M + 1)
                                                                 : static_cast<double>(M) * N);
-    ProfileScope scope(aligned && sizeof(T) == 8 && lower && TA == OP_N && TB == OP_T, kProfileSyrkLower,
+    ProfileScope scope(aligned && sizeof(T) == 8 && TA == OP_N && TB == OP_T, lower ? kProfileSyrkLower : kProfileOpNT,
                        flops, st);
     hipLaunchKernelGGL((gemm_op_kernel<T, TA, TB, LOWER>), dim3(static_cast<unsigned>(nwg)),
                        dim3(kGemmThreads), smem, st, M, N, K, static_cast<T>(alpha), A, lda, B, ldb,

@@ -11,7 +11,8 @@ namespace ssa {
 enum ProfileKind : int {
     kProfileGemmNN = 0,    // gemm_kernel<double, true>            (LU trailing / in-panel updates)
     kProfileSyrkLower = 1, // gemm_op_kernel<double, N, T, lower>  (Cholesky trailing update)
-    kProfileKinds = 2
+    kProfileOpNT = 2,      // gemm_op_kernel<double, N, T, all tiles> (Cholesky strips and panel products)
+    kProfileKinds = 3
 };
 
 struct GemmProfile {
@@ -48,5 +49,20 @@ struct ProfileScope {
         }
     }
 };
+
+// ssa_shutdown(): the events of the instrumentation
+inline int profile_shutdown() {
+    int rc = SSA_OK;
+    g_prof.enabled = false;
+    for (size_t i = 0; i < g_prof.start.size(); ++i)
+        if (hipEventDestroy(g_prof.start[i]) != hipSuccess || hipEventDestroy(g_prof.stop[i]) != hipSuccess)
+            rc = SSA_ERR_HIP;
+    g_prof.start.clear();
+    g_prof.stop.clear();
+    g_prof.flops.clear();
+    g_prof.kind.clear();
+    g_prof.used = 0;
+    return rc;
+}
 
 }  // namespace ssa

@@ -298,7 +298,9 @@ __global__ __launch_bounds__(kPanelThreads) void lu_panel_kernel(PanelArgs<T> a)
         }
         __syncthreads();  // #2
         if (bk[3]) {      // a peer never arrived: give up loudly (info = -1), never hang
-            if (g == 0 && tid == 0) *a.info = -1;
+            // EVERY workgroup that gives up reports it (a late peer may let workgroup 0 finish the last
+            // column while this one has not written its slab back: the factors are then not the LU)
+            if (tid == 0) __hip_atomic_store(a.info, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         // (3) global winner: thread t inspects workgroup t's header
@@ -503,14 +505,10 @@ template <typename T, bool UPPER, bool IDENT, bool UNITDIAG = true>
 int launch_trsm(const T *Tri, int64_t ldt, int64_t tri_bs, T *B, int64_t ldb, int64_t b_bs, int kb,
                 int64_t N, int batch, hipStream_t st) {
     if (kb <= 0 || N <= 0 || batch <= 0) return SSA_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_block_kernel<T, UPPER, IDENT, UNITDIAG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(trsm_smem_bytes<T>())) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
-    }
+    static DeviceFlags lds_flags;
+    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&trsm_block_kernel<T, UPPER, IDENT, UNITDIAG>),
+                                       trsm_smem_bytes<T>()}}) != SSA_OK)
+        return SSA_ERR_HIP;
     const dim3 grid(static_cast<unsigned>(ceil_div(N, TS)), static_cast<unsigned>(batch));
     hipLaunchKernelGGL((trsm_block_kernel<T, UPPER, IDENT, UNITDIAG>), grid, dim3(256), trsm_smem_bytes<T>(), st,
                        Tri, ldt, tri_bs, B, ldb, b_bs, kb, N);
@@ -634,14 +632,15 @@ int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_
 template <typename T>
 int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, void *workspace,
           hipStream_t st) {
-    static int num_cus = 0;  // co-residency bound for the cooperative panel kernel
-    if (num_cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return SSA_ERR_HIP;
-        num_cus = v;
+    static int cus_of_device[kMaxDevices] = {};  // co-residency bound for the cooperative panel kernel
+    int dev = 0;
+    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
+    if (cus_of_device[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return SSA_ERR_HIP;
+        cus_of_device[dev] = v;
     }
+    const int num_cus = cus_of_device[dev];
     const int max_groups = min(num_cus, kMaxPanelGroups);
     if (ceil_div(n, kPanelThreads) > max_groups) return SSA_ERR_UNSUPPORTED_SIZE;
 
@@ -656,20 +655,13 @@ int getrf(T *A, int64_t n, int64_t lda, int32_t *ipiv, int32_t *info, T *aux, vo
     T *dinv = cv.take<T>(static_cast<size_t>(NB / PW) * 64 * 64);  // inv(L11) of the sub-panels
     T *top = cv.take<T>(64 * 64);                                   // factored diagonal block in transit
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_panel_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(panel_smem_bytes<T>())) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_panel_spec3_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(spec3_smem_bytes<T>())) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_lower_inv_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(trsm_inv_smem_bytes<T>())) != hipSuccess)
-            return SSA_ERR_HIP;
-        attr_set = true;
-    }
+    static DeviceFlags lds_flags;
+    if (raise_dynamic_lds(lds_flags,
+                          {{reinterpret_cast<const void *>(&lu_panel_kernel<T>), panel_smem_bytes<T>()},
+                           {reinterpret_cast<const void *>(&lu_panel_spec3_kernel<T>), spec3_smem_bytes<T>()},
+                           {reinterpret_cast<const void *>(&trsm_lower_inv_kernel<T>), trsm_inv_smem_bytes<T>()}}) !=
+        SSA_OK)
+        return SSA_ERR_HIP;
     if (hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return SSA_ERR_HIP;
     if (hipMemsetAsync(flags, 0, 2 * nsub * sizeof(int), st) != hipSuccess) return SSA_ERR_HIP;
 

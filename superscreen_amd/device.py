@@ -446,7 +446,10 @@ class Device:
             if not Polygon(points=polygon).contains_points(holes[hole_name].points).all():
                 raise ValueError(f"Hole '{hole_name}' is not completely contained within the given polygon.")
         solve_kwargs = dict(solve_kwargs)
+        # bookkeeping default as in the reference (device.py:594); what is SOLVED follows ``solve``'s own
+        # default, ``iterations = 0`` (solver/solve.py:303), since the reference forwards ``solve_kwargs``
         iterations = solve_kwargs.get("iterations", 1)
+        solve_iterations = solve_kwargs.get("iterations", 0)
         solve_kwargs["progress_bar"] = False
         solve_kwargs.pop("current_units", None)
         I_circ_A = 1e-3  # 1 mA; the magnitude is not important (device.py:597)
@@ -461,6 +464,9 @@ class Device:
         to_units = PHI_0 / I_circ_A / parse_units(units).scale  # (Phi_0 / I) -> `units`
         if parse_units(units).dims != parse_units("H").dims:
             raise ValueError(f"{units!r} is not a unit of inductance.")
+        if not hole_names:  # the reference's loop over holes never runs: empty matrices
+            result = [Quantity(m, units) for m in mutual]
+            return result if all_iterations else result[0]
         model = factorize_model(device=self, current_units="mA", circulating_currents={hole_names[0]: "1 mA"})
         I_circ_val = model.circulating_currents[hole_names[0]]
         plain = set(solve_kwargs) <= {"applied_field", "field_units", "iterations", "progress_bar", "return_solutions"}
@@ -473,7 +479,7 @@ class Device:
             field = solve_kwargs.get("applied_field") or ConstantField(0)
             logger.info(f"Evaluating the {n_holes} columns of the {self.name!r} mutual inductance matrix at once.")
             columns = solve_sweep(model, [field] * len(hole_names), field_units=solve_kwargs.get("field_units", "mT"),
-                                  iterations=iterations, all_iterations=all_iterations,
+                                  iterations=solve_iterations, all_iterations=all_iterations,
                                   circulating_currents=[{name: I_circ_val} for name in hole_names])
         else:
             columns = []

@@ -21,8 +21,9 @@ The reference is single-process; this decomposition is n
 * **Owner-computes film placement** (:class:`FilmPlacement`, SURVEY.md section 8e "films of one
   device"): film f lives on rank ``f mod world``; a rank assembles, factors and solves only its own
   films and evaluates the complete coupling field of its own TARGET films.  After every pass the
-  owners broadcast their films' small result vectors (g, J, self-field, coupling field:
-  5 n values, 1 MB for a 25k-vertex film), so every rank holds every iterate and returns the same
+  owners' small result vectors (g, J, self-field, coupling field: 5 n values, 1 MB for a 25k-vertex
+  film) are exchanged with ONE collective (a sum all-reduce of a flat buffer in which every vector has
+  its place and only the owner writes), so every rank holds every iterate and returns the same
   Solutions; nothing of size n^2 ever moves.  With at least as many films as ranks, factorization
   and solve time divide by the number of ranks.
 """
@@ -52,6 +53,65 @@ def _dist():
     return dist
 
 
+class RcclCommunicator:
+    """An RCCL communicator owned through the C ABI (``ssa_rccl_*``, ``include/superscreen_hip.h`` section 7),
+    for callers that want the coupling all-reduce without ``torch.distributed`` in the data path.  One
+    process per GPU; rank 0 draws the 128-byte id and every rank passes the same id.
+
+    ``RcclCommunicator.from_torch_group()`` bootstraps from an existing ``torch.distributed`` group (any
+    backend: the id travels through ``broadcast_object_list``); ``RcclCommunicator(id, rank, world)`` takes an
+    id distributed by other means."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        import ctypes
+
+        from . import _hip
+
+        lib = _hip.load_library()
+        if len(unique_id) != 128:
+            raise ValueError("An RCCL unique id has 128 bytes.")
+        handle = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _hip.check(lib.ssa_rccl_comm_create(ctypes.byref(handle), world, rank, buf), "ssa_rccl_comm_create")
+        self.handle, self.rank, self.world = handle, rank, world
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        import ctypes
+
+        from . import _hip
+
+        buf = ctypes.create_string_buffer(128)
+        _hip.check(_hip.load_library().ssa_rccl_unique_id(buf), "ssa_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, group=None) -> "RcclCommunicator":
+        dist = _dist()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        if world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+        return cls(box[0], rank, world)
+
+    def all_reduce_sum_(self, flat) -> None:
+        """In-place sum over the ranks of a contiguous float32 / float64 device tensor, enqueued on the
+        current stream (``ssa_coupling_allreduce``)."""
+        from . import _hip
+
+        _hip.check(_hip.load_library().ssa_coupling_allreduce(
+            _hip.ptr(flat), flat.numel(), _hip.dtype_code(flat.dtype), self.handle, _hip.current_stream()),
+            "ssa_coupling_allreduce")
+
+    def destroy(self) -> None:
+        from . import _hip
+
+        if self.handle is not None:
+            _hip.check(_hip.load_library().ssa_rccl_comm_destroy(self.handle), "ssa_rccl_comm_destroy")
+            self.handle = None
+
+
 class CouplingPlan:
     """Distributes the inter-film coupling sums of one Jacobi iteration over the ranks of a
     process group and completes them with a single all-reduce.
@@ -59,10 +119,14 @@ class CouplingPlan:
     ``pair_kernel(src, tgt, begin, end, out)`` must ADD into ``out`` the field at film ``tgt`` due
     to sources ``[begin, end)`` of film ``src``.  The default (``None``) is the HIP kernel
     ``ssa_biot_savart`` on the model's device-resident data; the CPU tests inject the oracle.
+    ``comm``: an :class:`RcclCommunicator`; the all-reduce then goes through the C ABI
+    (``ssa_coupling_allreduce``) instead of ``torch.distributed``.
     """
 
     def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None,
-                 pair_kernel: Optional[Callable] = None):
+                 pair_kernel: Optional[Callable] = None, comm: Optional[RcclCommunicator] = None):
+        if comm is not None:
+            rank, world = comm.rank, comm.world
         dist = _dist()
         if rank is None or world is None:
             if not dist.is_initialized():
@@ -70,19 +134,24 @@ class CouplingPlan:
             rank, world = dist.get_rank(group), dist.get_world_size(group)
         self.rank, self.world, self.group = rank, world, group
         self.pair_kernel = pair_kernel
+        self.comm = comm
 
     # -- pure bookkeeping (unit-tested without any process group) --------------------------
     @staticmethod
-    def tasks(films: Sequence[str], sizes: Dict[str, int], rank: int, world: int):
+    def tasks(films: Sequence[str], sizes: Dict[str, int], rank: int, world: int,
+              ranges: Optional[Dict[str, Tuple[int, int]]] = None):
         """``(src, tgt, begin, end)`` work items of ``rank``: every ordered pair, this rank's
-        source slice (ordering = ``itertools.product(films, repeat=2)``, ``solve.py:499``)."""
+        source slice (ordering = ``itertools.product(films, repeat=2)``, ``solve.py:499``).
+        ``ranges[src] = (lo, hi)``: only the sources ``[lo, hi)`` of a film are split (the vertices that
+        can carry a sheet current; the others contribute exact zeros); default: all ``sizes[src]``."""
         out = []
         for src, tgt in itertools.product(films, repeat=2):
             if src == tgt:
                 continue
-            b, e = shard_range(sizes[src], rank, world)
+            lo, hi = ranges[src] if ranges is not None else (0, sizes[src])
+            b, e = shard_range(hi - lo, rank, world)
             if e > b:
-                out.append((src, tgt, b, e))
+                out.append((src, tgt, lo + b, lo + e))
         return out
 
     # -- execution --------------------------------------------------------------------------
@@ -90,10 +159,13 @@ class CouplingPlan:
         """In-place SUM all-reduce of all films' partial fields as ONE flat buffer."""
         import torch
 
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             return
         flat = torch.cat([other[f].reshape(-1) for f in films])
-        _dist().all_reduce(flat, op=_dist().ReduceOp.SUM, group=self.group)
+        if self.comm is not None:
+            self.comm.all_reduce_sum_(flat)
+        else:
+            _dist().all_reduce(flat, op=_dist().ReduceOp.SUM, group=self.group)
         off = 0
         for f in films:
             k = other[f].numel()
@@ -106,7 +178,8 @@ class CouplingPlan:
         films = list(model.device.films)
         sizes = {f: model.film_data[f].n for f in films}
         kernel = self.pair_kernel or self._hip_pair_kernel(model, results)
-        for src, tgt, b, e in self.tasks(films, sizes, self.rank, self.world):
+        ranges = {f: getattr(model.film_data[f], "src_range", (0, sizes[f])) for f in films}
+        for src, tgt, b, e in self.tasks(films, sizes, self.rank, self.world, ranges):
             kernel(src, tgt, b, e, other_d[tgt])
         self.reduce_fields(films, other_d)
 
@@ -127,10 +200,13 @@ class FilmPlacement:
     """Owner-computes placement of the films of a coupled stack (see the module docstring).
 
     Pass it to :func:`superscreen_amd.factorize_model` (the rank then factors only its films) and to
-    :func:`superscreen_amd.solve`.  The process group must already exist; tensors travel with
-    ``torch.distributed.broadcast`` (RCCL on GPUs)."""
+    :func:`superscreen_amd.solve`.  The process group (or the :class:`RcclCommunicator` ``comm``) must
+    already exist; the result vectors travel in one sum all-reduce per pass (:meth:`share`)."""
 
-    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                 comm: Optional[RcclCommunicator] = None):
+        if comm is not None:
+            rank, world = comm.rank, comm.world
         dist = _dist()
         if rank is None or world is None:
             if not dist.is_initialized():
@@ -138,7 +214,7 @@ class FilmPlacement:
             rank, world = dist.get_rank(group), dist.get_world_size(group)
         if world < 1 or not (0 <= rank < world):
             raise ValueError(f"Invalid rank {rank} for world size {world}.")
-        self.rank, self.world, self.group = rank, world, group
+        self.rank, self.world, self.group, self.comm = rank, world, group, comm
 
     def owners(self, films: Sequence[str]) -> Dict[str, int]:
         """``{film: owning rank}``: round-robin in device order."""
@@ -156,18 +232,43 @@ class FilmPlacement:
 
     def share(self, films: Sequence[str], tensors: Dict[str, Dict[str, "object"]],
               shapes: Dict[str, Dict[str, tuple]], dtypes: Dict[str, Dict[str, "object"]], device) -> None:
-        """Completes ``tensors[film][key]`` on every rank: the owner broadcasts, the others receive
-        into freshly allocated tensors of the given shape / dtype.  Deterministic order."""
+        """Completes ``tensors[film][key]`` on every rank with ONE collective per pass: the vectors of all
+        films have fixed places in one flat float64 buffer (float32 values widen exactly); a rank writes
+        the vectors of the films it owns and leaves zeros elsewhere, so a single sum all-reduce (x + 0 is
+        exact) hands every rank every vector; the other ranks' films are unpacked into fresh tensors of
+        the given shape / dtype.  About 5 n values per film (1 MB for a 25k-vertex film): the exchange is
+        latency-bound, one collective instead of one broadcast per (film, key) is what counts, and it is
+        the same all-reduce the coupling plan uses (``ssa_coupling_allreduce`` with ``self.comm``,
+        else ``torch.distributed``: RCCL on GPUs, gloo in the CPU tests)."""
+        import math
+
         import torch
 
+        if self.world == 1:
+            return
         own = self.owners(films)
+        keys = {f: sorted(shapes[f]) for f in films}
+        total = sum(math.prod(shapes[f][k]) for f in films for k in keys[f])
+        flat = torch.zeros(total, dtype=torch.float64, device=device)
+        off = 0
+        for f in films:
+            for k in keys[f]:
+                cnt = math.prod(shapes[f][k])
+                if own[f] == self.rank:
+                    flat[off:off + cnt].copy_(tensors[f][k].reshape(-1))
+                off += cnt
+        if self.comm is not None:
+            self.comm.all_reduce_sum_(flat)
+        else:
+            _dist().all_reduce(flat, op=_dist().ReduceOp.SUM, group=self.group)
+        off = 0
         for f in films:
             bucket = tensors.setdefault(f, {})
-            for key in sorted(shapes[f]):
+            for k in keys[f]:
+                cnt = math.prod(shapes[f][k])
                 if own[f] != self.rank:
-                    bucket[key] = torch.empty(shapes[f][key], dtype=dtypes[f][key], device=device)
-                if self.world > 1:
-                    _dist().broadcast(bucket[key], src=self._global_rank(own[f]), group=self.group)
+                    bucket[k] = flat[off:off + cnt].to(dtypes[f][k]).reshape(shapes[f][k]).contiguous()
+                off += cnt
 
 
 def solve_sweep_sharded(model, applied_fields: Sequence, *, rank: Optional[int] = None, world: Optional[int] = None,

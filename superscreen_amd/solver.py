@@ -360,6 +360,11 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
         hole_systems[name] = {}
         for hole_name, indices in info.hole_indices.items():
             ix_d = torch.from_numpy(indices.astype(np.int64)).to(dev)
+            if len(indices) == 0:  # a hole that contains no mesh vertex: an empty system, nothing to assemble
+                hole_systems[name][hole_name] = LinearSystem(
+                    indices=indices, indices_device=ix_d, grad_Lambda_term=grad_Lambda_term,
+                    _assemble=lambda n=fd.n: np.zeros((n, 0), dtype=dtype))
+                continue
             A_h = assemble(None, ix_d, 1.0)  # [n, ld]
             hole_systems[name][hole_name] = LinearSystem(
                 indices=indices, A_device=A_h, indices_device=ix_d, grad_Lambda_term=grad_Lambda_term,
@@ -399,6 +404,10 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
                 return assemble(ix_d, ix_d, 1.0)[:, :ni].cpu().numpy()
 
             S = None
+            if ni == 0:  # no unknowns (e.g. every film vertex lies on the mesh boundary): empty system
+                pending.append(((name, role), interior, ix_d, 0, None, None, lambda: np.zeros((0, 0), dtype=dtype), fd,
+                                grad_Lambda_term))
+                continue
             if inhomogeneous and method == "cholesky":
                 raise ValueError(f"Film {name!r}: Lambda(x, y) makes diag(w) A non-symmetric; "
                                  "use method='auto' or 'lu'.")
@@ -431,6 +440,9 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
                 logger.warning(f"Film {name!r}: Cholesky pivot not positive, falling back to LU.")
                 del chols[key]
                 del S, chol
+        if system is None and ni == 0:
+            system = LinearSystem(indices=interior, indices_device=ix_d, grad_Lambda_term=grad_Lambda_term,
+                                  _assemble=host_A)
         if system is None:
             factors = lu_route()
             system = LinearSystem(indices=interior, factors=factors, indices_device=ix_d,
@@ -734,6 +746,8 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
     ha_eff = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
     for hole_name, hs in model.hole_systems[name].items():
         current = info.circulating_currents.get(hole_name, 0)
+        if len(hs.indices) == 0:
+            continue
         kernels.index_add_scalar(g, hs.indices_device, current)        # g[hole] += I_circ
         kernels.gemv(hs.A_device, fd.n, len(hs.indices), g, xidx=hs.indices_device,
                      y=ha_eff, alpha=-1.0, beta=1.0)                      # Ha_eff += -(A @ g[ix])
@@ -742,7 +756,9 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
         g_transport, ha_transport = _terminal_transport(model, name)
         g += g_transport
         ha_eff += ha_transport
-    if system.chol is not None:
+    if len(system.indices) == 0:
+        gf = None
+    elif system.chol is not None:
         h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
         gf = kernels.chol_solve(system.chol, kernels.row_scale(h_nat, system.neg_w_device))
     else:
@@ -750,13 +766,14 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
         if check_inversion:
             h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
         gf = kernels.lu_solve_permuted(system.factors, h)                # = lu_solve(lu_piv, h)
-    if check_inversion:  # solve_film.py:533-540: warn, never raise
+    if check_inversion and gf is not None:  # solve_film.py:533-540: warn, never raise
         A = torch.from_numpy(system.A).to(fd.device)
         hsim = -(kernels.gemv(A, len(system.indices), len(system.indices), gf))
         if not np.allclose(hsim.cpu().numpy(), h_nat.cpu().numpy()):
             err = (hsim - h_nat).abs().max().item()
             logger.warning(f"Unable to solve for stream function in {name!r}), maximum error {err:.3e}.")
-    kernels.scatter_add(g, system.indices_device, gf)
+    if gf is not None:
+        kernels.scatter_add(g, system.indices_device, gf)
     if info.vortices:  # solve_film.py:541-554, Eq. 28 in [Brandt]
         mesh = model.device.meshes[name]
         points = mesh.sites
@@ -779,7 +796,7 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
     elif model.self_field_mode == "dense":
         sf = kernels.gemv(fd.Q, fd.n, fd.n, g, xscale=fd.w_t)
     elif (model.self_field_mode in ("auto", "london") and fd.tdtype == torch.float64 and not info.vortices
-          and not info.lambda_info.inhomogeneous):
+          and not info.lambda_info.inhomogeneous and len(system.indices) > 0):
         # interior rows: the solved system is the London equation, H_applied + H_other + H_self =
         # Laplacian(Lambda g), i.e. the self field costs one sparse product there; the all-pairs sum
         # Q @ (w g) is only needed on the rows that are not unknowns (boundary, buffer, holes)
@@ -949,22 +966,31 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                     other_d[f] = payload[f]["other"]
         return results
 
-    keep = return_solutions or save_path is not None
+    # with a placement every rank computes the same Solutions; only rank 0 writes them
+    writes = save_path is not None and (placement is None or placement.rank == 0)
+    keep = return_solutions or writes
     n_saved = [0]
+    h5file = [None]
+
+    def close_file():
+        if h5file[0] is not None:
+            h5file[0].close()
+            h5file[0] = None
 
     def package(staged: _StagedPass):
         """Builds the iteration's Solution on the host; with ``save_path`` it also goes to the file:
         the device once in the root group, every iterate in a group named after its index
-        (``solver/solve.py:474-483, 539-547``; read back by ``Solution.load_solutions``)."""
+        (``solver/solve.py:474-483, 539-547``; read back by ``Solution.load_solutions``).  The file
+        stays open for the whole solve and is written out once, when it is closed."""
         fs = {name: staged.film_solution(name, applied_h[name], conv) for name in films}
         solution = Solution(device=device, film_solutions=fs, **solution_kwargs)
-        if save_path is not None:
+        if writes:
             from . import io
 
-            with io.open_file(save_path, "x" if n_saved[0] == 0 else "r+") as h5file:
-                if n_saved[0] == 0:
-                    device.to_hdf5(h5file.create_group("device"))
-                solution.to_hdf5(h5file.create_group(str(n_saved[0])), device_path="/device")
+            if h5file[0] is None:
+                h5file[0] = io.open_file(save_path, "x")
+                device.to_hdf5(h5file[0].create_group("device"))
+            solution.to_hdf5(h5file[0].create_group(str(n_saved[0])), device_path="/device")
             n_saved[0] += 1
         if return_solutions:
             solutions.append(solution)
@@ -972,36 +998,42 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     results = run_pass(None)
     pending = _StagedPass(results, None, films) if keep else None
     if len(films) < 2 or iterations < 1:
-        if keep:
-            package(pending)
+        try:
+            if keep:
+                package(pending)
+        finally:
+            close_file()
         return solutions if return_solutions else None
 
-    for it in range(iterations):
-        other_d = {name: torch.zeros(model.film_data[name].n, dtype=model.film_data[name].tdtype,
-                                     device=model.film_data[name].device) for name in films}
-        if coupling is not None:
-            coupling.accumulate(model, results, other_d)
-        else:
-            for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
-                if src == tgt or tgt not in mine:  # owner-computes: only this rank's target films
-                    continue
-                s, t = model.film_data[src], model.film_data[tgt]
-                kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,
-                                    film_info[tgt].z0 - film_info[src].z0, other_d[tgt],
-                                    accumulate=True, src_begin=s.src_range[0], src_end=s.src_range[1])
-        prev = results
-        results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
+    try:
+        for it in range(iterations):
+            other_d = {name: torch.zeros(model.film_data[name].n, dtype=model.film_data[name].tdtype,
+                                         device=model.film_data[name].device) for name in films}
+            if coupling is not None:
+                coupling.accumulate(model, results, other_d)
+            else:
+                for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
+                    if src == tgt or tgt not in mine:  # owner-computes: only this rank's target films
+                        continue
+                    s, t = model.film_data[src], model.film_data[tgt]
+                    kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,
+                                        film_info[tgt].z0 - film_info[src].z0, other_d[tgt],
+                                        accumulate=True, src_begin=s.src_range[0], src_end=s.src_range[1])
+            prev = results
+            results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
+            if keep:
+                # the previous iterate is unpacked on the host while the GPU works on this one
+                staged = _StagedPass(results, other_d, films)
+                package(pending)
+                pending = staged
+            if tolerance is not None:
+                change = max(((results[n].g - prev[n].g).abs().max() / results[n].g.abs().max()).item()
+                             for n in films)
+                logger.debug(f"iteration {it + 1}: relative change {change:.3e}")
+                if change < tolerance:
+                    break
         if keep:
-            # the previous iterate is unpacked on the host while the GPU works on this one
-            staged = _StagedPass(results, other_d, films)
             package(pending)
-            pending = staged
-        if tolerance is not None:
-            change = max(((results[n].g - prev[n].g).abs().max() / results[n].g.abs().max()).item()
-                         for n in films)
-            logger.debug(f"iteration {it + 1}: relative change {change:.3e}")
-            if change < tolerance:
-                break
-    if keep:
-        package(pending)
+    finally:
+        close_file()
     return solutions if return_solutions else None

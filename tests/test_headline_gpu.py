@@ -1,0 +1,269 @@
+"""Parity and size-independent properties at the sizes the headline numbers are measured on.
+
+The reference fixtures stop at n = 2 107 vertices (the reference's numba kernels run as Python loops
+under the import stubs) and fit inside one 4096-row solve block.  The schedule that produces the bench
+numbers only exists above that: two-panel (K = 512) trailing updates start at 8 192 trailing columns
+(``chol.hip``, ``kDelayMinCols``), the triangular solves walk several 4096-row blocks, two films of
+different order share one look-ahead schedule, the smaller film hands its finishing passes to a
+low-priority stream.  Here
+
+* ``test_two_film_vs_oracle_above_two_panel_threshold`` compares ``solve()`` with the CPU oracle
+  (scipy LU of the reference's ``-A``, ``solver/solve_film.py:276-281, 526-531``) on a washer + disk
+  device with 9 126 / 10 267 unknowns, float64 and float32, Cholesky and LU route, every iterate;
+* ``test_full_size_london_system`` runs BASELINE.json's configs 2, 3, H and the 4-film stack of config 5
+  at FULL size on one GPU and checks what needs no O(n^3) host work: the reference's own
+  ``check_inversion`` residual (``solver/solve_film.py:533-540``) on the assembled London system
+  ``A g_f + A_h g_hole + H_z = 0``, the London-equation self field against the all-pairs sum
+  ``Q (w g)`` (``:565``), linearity in the applied field, and bit-identical results of three cold
+  factorizations;
+* ``test_solve_sweep_64_fields_vs_oracle`` pins config 4's own kernel set (>= 13 columns: MFMA pair
+  kernels, skinny multi-right-hand-side solves) to the oracle, field by field.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import superscreen_oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import superscreen_amd
+
+    return superscreen_amd
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def oracle_stack(K, kinds, z_spacing, Lambda, dtype, mesh=None):
+    from matplotlib.path import Path
+
+    from superscreen_amd import synthetic
+
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = mesh or orc.make_mesh(sites, elements)
+    Kf = synthetic.film_rings(K)
+    in_film = Path(synthetic.circle_points((Kf + 0.5) * dr), closed=True).contains_points(sites)
+    in_hole = Path(synthetic.circle_points((Kf // 3 + 0.5) * dr, 201), closed=True).contains_points(sites)
+    films = []
+    for i, kind in enumerate(kinds):
+        holes = {f"hole{i}": in_hole} if kind == "washer" else {}
+        films.append(orc.make_film(f"{kind}{i}", mesh, z0=i * z_spacing, Lambda=Lambda, in_film=in_film,
+                                   holes_mask=holes, dtype=dtype))
+    return films, mesh
+
+
+# ------------------------------------------------------------------------------------------------
+# (a) oracle comparison above the two-panel threshold
+# ------------------------------------------------------------------------------------------------
+K_BIG = 64          # n = 12 481 vertices per film; unknowns 9 126 (washer) / 10 267 (disk): both > 8 448
+ITER_BIG = 2
+
+
+@pytest.fixture(scope="module")
+def oracle_big():
+    """Oracle traces of the K = 64 device, computed once per dtype (the mesh operators are shared)."""
+    cache = {}
+
+    def get(dtype):
+        if dtype not in cache:
+            films, mesh = oracle_stack(K_BIG, ("washer", "disk"), 0.5, 0.1, dtype, mesh=cache.get("mesh"))
+            cache["mesh"] = mesh
+            assert min(len(f.film_indices) for f in films) > 8448
+            cache[dtype] = orc.solve(films, 0.7, iterations=ITER_BIG, circulating_currents={"hole0": 3.0})
+            del films
+        return cache[dtype]
+
+    return get
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 5e-3)])
+@pytest.mark.parametrize("method", ["auto", "lu"])
+def test_two_film_vs_oracle_above_two_panel_threshold(sc, oracle_big, dtype, tol, method):
+    from superscreen_amd import kernels, synthetic
+
+    device = synthetic.make_stack_device(K_BIG, ("washer", "disk"), solve_dtype=dtype)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": "3 uA"},
+                               method=method)
+    for name, system in model.film_systems.items():
+        ni = len(system.indices)
+        assert ni > 8448 and kernels.chol_padded_n(ni) - 256 > 8192   # K = 512 updates, 3 solve blocks
+        assert (system.chol is not None) == (method == "auto")
+    sols = sc.solve(model=model, applied_field=sc.ConstantField(0.7), iterations=ITER_BIG)
+    trace = oracle_big(dtype)
+    assert len(sols) == len(trace) == ITER_BIG + 1
+    for it, (sol, ref) in enumerate(zip(sols, trace)):
+        for nm in device.films:
+            fs = sol.film_solutions[nm]
+            assert fs.stream.dtype == np.dtype(dtype)
+            assert relerr(fs.stream, ref[nm].stream) < tol, (it, nm)
+            assert relerr(fs.self_field, ref[nm].self_field) < tol, (it, nm)
+            assert relerr(fs.current_density, ref[nm].current_density) < tol * 10, (it, nm)
+            if it:
+                assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < tol, (it, nm)
+
+
+# ------------------------------------------------------------------------------------------------
+# (b) full-size properties of BASELINE.json's configurations
+# ------------------------------------------------------------------------------------------------
+FULL_SIZE = [
+    # id, rings, films, z spacing, Jacobi iterations
+    ("config2_single_disk_50311", 129, ("disk",), 0.5, 0),
+    ("config3_washer_shield_2x19927", 81, ("washer", "disk"), 0.5, 3),
+    ("configH_washer_shield_2x25117", 91, ("washer", "disk"), 0.5, 3),
+    ("config5_stack_4x30301", 100, ("disk", "disk", "disk", "disk"), 0.5, 2),
+]
+
+
+def london_residual(model, solution, field_mT):
+    """max_i |A[ix, ix] g[ix] + A_h[ix, :] g[hole] + H_z[ix]| / max|H_z| per film, with
+    ``A = Q w - Lambda Del2`` assembled by ``ssa_system_assemble`` for the columns ``ix + holes`` --
+    what ``check_inversion`` evaluates in the reference (there with the unknowns' columns only, the
+    hole columns having been moved to the right-hand side, ``solve_film.py:498-503, 526-540``)."""
+    from superscreen_amd import kernels
+    from superscreen_amd.units import field_conversion_factor
+
+    conv = field_conversion_factor("mT", model.current_units, length_units=model.device.length_units)
+    out = {}
+    for name, system in model.film_systems.items():
+        fd, info = model.film_data[name], model.film_info[name]
+        fs = solution.film_solutions[name]
+        cols = np.concatenate([system.indices] + [np.asarray(ix) for ix in info.hole_indices.values()])
+        cols_d = torch.from_numpy(cols.astype(np.int64)).to(fd.device)
+        A = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, system.indices_device, cols_d,
+                                    sign=1.0, dtype="float64")
+        g = torch.from_numpy(np.ascontiguousarray(fs.stream[cols], dtype=np.float64)).to(fd.device)
+        Hz = field_mT * conv * np.ones(fd.n)
+        if fs.field_from_other_films is not None:
+            Hz = Hz + fs.field_from_other_films * conv
+        r = kernels.gemv(A, len(system.indices), len(cols), g).cpu().numpy() + Hz[system.indices]
+        out[name] = float(np.max(np.abs(r)) / np.max(np.abs(Hz)))
+        del A
+    return out
+
+
+@pytest.mark.parametrize("label,K,kinds,dz,iters", FULL_SIZE, ids=[c[0] for c in FULL_SIZE])
+def test_full_size_london_system(sc, label, K, kinds, dz, iters):
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(K, kinds, z_spacing=dz, solve_dtype="float64")
+    cc = {f"hole{i}": 2.0 for i, k in enumerate(kinds) if k == "washer"}
+    field = 1.0
+    first = None
+    for rep in range(3):                                    # three COLD factorizations, bit-identical
+        model = sc.factorize_model(device=device, current_units="uA", circulating_currents=cc)
+        assert all(s.chol is not None and s.chol.info == 0 for s in model.film_systems.values())
+        sols = sc.solve(model=model, applied_field=sc.ConstantField(field), iterations=iters)
+        streams = {nm: sols[-1].film_solutions[nm].stream for nm in device.films}
+        if first is None:
+            first = streams
+            res = london_residual(model, sols[-1], field)
+            assert max(res.values()) < 1e-10, res
+            # linearity in the applied field (no circulating currents: the hole term is affine)
+            if not cc:
+                b = sc.solve(model=model, applied_field=sc.ConstantField(2.5 * field), iterations=iters)[-1]
+                for nm in device.films:
+                    assert relerr(b.film_solutions[nm].stream, 2.5 * streams[nm]) < 1e-12
+            else:
+                model.set_circulating_currents({})
+                a0 = sc.solve(model=model, applied_field=sc.ConstantField(field), iterations=iters)[-1]
+                b0 = sc.solve(model=model, applied_field=sc.ConstantField(2.5 * field), iterations=iters)[-1]
+                for nm in device.films:
+                    assert relerr(b0.film_solutions[nm].stream, 2.5 * a0.film_solutions[nm].stream) < 1e-12
+                model.set_circulating_currents(cc)
+            self_london = {nm: sols[-1].film_solutions[nm].self_field for nm in device.films}
+        else:
+            for nm in device.films:
+                assert np.array_equal(streams[nm], first[nm]), (label, rep, nm)
+        del model, sols
+        torch.cuda.empty_cache()
+    # London-equation self field (default for float64) vs the all-pairs sum Q (w g) on every row
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents=cc,
+                               self_field="matrix_free")
+    sols = sc.solve(model=model, applied_field=sc.ConstantField(field), iterations=iters)
+    for nm in device.films:
+        assert np.array_equal(sols[-1].film_solutions[nm].stream, first[nm])
+        assert relerr(self_london[nm], sols[-1].film_solutions[nm].self_field) < 1e-10, nm
+    del model, sols
+    torch.cuda.empty_cache()
+
+
+def test_full_size_float32_and_lu_routes_agree_with_float64(sc):
+    """Config H in float32 (the reference's default ``solve_dtype``, ``device/device.py:57``) and through
+    the LU route (the reference's own algorithm) against the float64 Cholesky answer at full size."""
+    from superscreen_amd import synthetic
+
+    K, kinds = 91, ("washer", "disk")
+    ref = sc.solve(synthetic.make_stack_device(K, kinds, solve_dtype="float64"), applied_field=sc.ConstantField(1.0),
+                   circulating_currents={"hole0": 2.0}, iterations=2)
+    dev32 = synthetic.make_stack_device(K, kinds, solve_dtype="float32")
+    got32 = sc.solve(dev32, applied_field=sc.ConstantField(1.0), circulating_currents={"hole0": 2.0}, iterations=2)
+    dev64 = synthetic.make_stack_device(K, kinds, solve_dtype="float64")
+    model = sc.factorize_model(device=dev64, current_units="uA", circulating_currents={"hole0": 2.0}, method="lu")
+    lu = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=2)
+    for f in model.film_systems.values():
+        assert np.array_equal(f.factors.ipiv.cpu().numpy(), np.arange(len(f.indices)))  # diagonally dominant
+    for a, b, c in zip(ref, got32, lu):
+        for nm in dev64.films:
+            assert relerr(b.film_solutions[nm].stream, a.film_solutions[nm].stream) < 5e-3
+            assert relerr(c.film_solutions[nm].stream, a.film_solutions[nm].stream) < 1e-10
+            assert relerr(c.film_solutions[nm].current_density, a.film_solutions[nm].current_density) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# (c) config 4's kernel set against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 5e-3)])
+def test_solve_sweep_64_fields_vs_oracle(sc, dtype, tol):
+    from superscreen_amd import synthetic
+
+    K, kinds, iters = 25, ("washer", "disk"), 3
+    fields = [0.1 * (k + 1) * (-1) ** k for k in range(64)]
+    device = synthetic.make_stack_device(K, kinds, solve_dtype=dtype)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": 1.5})
+    swept = sc.solve_sweep(model, fields, iterations=iters)
+    assert len(swept) == 64 and all(len(s) == iters + 1 for s in swept)
+    films, _ = oracle_stack(K, kinds, 0.5, 0.1, dtype)
+    # the oracle is affine in the field for fixed circulating currents: two oracle solves span the scan
+    # in exact arithmetic, but every field is solved on its own so that nothing is assumed
+    for k, field in enumerate(fields):
+        trace = orc.solve(films, field, iterations=iters, circulating_currents={"hole0": 1.5})
+        for it, ref in enumerate(trace):
+            for nm in device.films:
+                fs = swept[k][it].film_solutions[nm]
+                scale = max(np.max(np.abs(ref[nm].stream)), 1e-300)
+                assert np.max(np.abs(fs.stream - ref[nm].stream)) / scale < tol, (k, it, nm)
+                assert relerr(fs.current_density, ref[nm].current_density) < 10 * tol, (k, it, nm)
+                assert relerr(fs.self_field, ref[nm].self_field) < tol, (k, it, nm)
+                if it:
+                    assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < tol, (k, it, nm)
+
+
+def test_four_film_stack_vs_oracle(sc):
+    """BASELINE config 5's device shape (4 coaxial films) at a size the oracle finishes in seconds: every
+    iterate of the 12-ordered-pair Jacobi loop (``solver/solve.py:499-515``)."""
+    from superscreen_amd import synthetic
+
+    K, kinds, iters = 20, ("disk", "washer", "disk", "washer"), 4
+    device = synthetic.make_stack_device(K, kinds, solve_dtype="float64")
+    cc = {"hole1": 1.0, "hole3": -2.0}
+    sols = sc.solve(device, applied_field=sc.ConstantField(0.9), circulating_currents=cc, iterations=iters)
+    films, _ = oracle_stack(K, kinds, 0.5, 0.1, "float64")
+    trace = orc.solve(films, 0.9, iterations=iters, circulating_currents=cc)
+    assert len(sols) == iters + 1
+    for it, (sol, ref) in enumerate(zip(sols, trace)):
+        for nm in device.films:
+            fs = sol.film_solutions[nm]
+            assert relerr(fs.stream, ref[nm].stream) < 1e-9, (it, nm)
+            assert relerr(fs.self_field, ref[nm].self_field) < 1e-9, (it, nm)
+            if it:
+                assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < 1e-9, (it, nm)

@@ -554,3 +554,43 @@ def test_multi_vector_pairwise_kernels(K, disk, dtype, tol, nvec):
         ref = base[:, v].contiguous().clone()
         K.biot_savart(xy, w.to(tdt), J[:, v, :].contiguous(), tgt, 0.7, ref, accumulate=True)
         assert relerr(out[:, v], ref.cpu().numpy().astype(np.float64)) < tol
+
+
+def test_coupling_allreduce_c_abi_and_shutdown(K):
+    """Section 7 of the C ABI on one GPU: a single-rank RCCL communicator made by ``ssa_rccl_*`` (the only
+    communicator a 1-GPU box can hold), ``ssa_coupling_allreduce`` through it (a sum over one rank leaves
+    the buffer unchanged, in float64 and float32), the same communicator driving a CouplingPlan inside
+    ``solve``; then ``ssa_shutdown`` releases the library's side streams and the next factorization
+    re-creates them."""
+    import ctypes
+
+    import superscreen_amd as sc
+    from superscreen_amd import _hip, synthetic
+    from superscreen_amd.parallel import CouplingPlan, RcclCommunicator
+
+    lib = _hip.load_library()
+    comm = RcclCommunicator(RcclCommunicator.new_unique_id(), 0, 1)
+    for dt in (torch.float64, torch.float32):
+        x = torch.randn(121204, dtype=dt, device="cuda")          # the 4 x 30 301 coupling vector of config 5
+        y = x.clone()
+        comm.all_reduce_sum_(y)
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    assert lib.ssa_coupling_allreduce(None, 4, _hip.SSA_F64, comm.handle, None) == -1
+    assert lib.ssa_coupling_allreduce(ctypes.c_void_p(x.data_ptr()), 4, 7, comm.handle, None) == -1
+    assert lib.ssa_coupling_allreduce(ctypes.c_void_p(x.data_ptr()), 4, _hip.SSA_F64, None, None) == -1
+    device = synthetic.make_stack_device(12, ("washer", "disk", "disk"), solve_dtype="float64")
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole0": 1.0})
+    base = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=2)
+    dist_ = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=2, coupling=CouplingPlan(comm=comm))
+    for a, b in zip(base, dist_):
+        for nm in device.films:
+            assert np.array_equal(a.film_solutions[nm].stream, b.film_solutions[nm].stream)
+    comm.destroy()
+    torch.cuda.synchronize()
+    assert lib.ssa_shutdown() == 0
+    assert lib.ssa_shutdown() == 0                                  # idempotent
+    again = sc.solve(device, applied_field=sc.ConstantField(1.0), circulating_currents={"hole0": 1.0}, iterations=2)
+    for a, b in zip(base, again):
+        for nm in device.films:
+            assert np.array_equal(a.film_solutions[nm].stream, b.film_solutions[nm].stream)

@@ -156,3 +156,57 @@ def test_film_placement_bookkeeping():
         assert sorted(owned) == films          # every film exactly once
     with pytest.raises(ValueError):
         FilmPlacement(rank=2, world=2)
+
+
+def _share_worker(rank, world, port, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+
+    from superscreen_amd.parallel import FilmPlacement
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        films = ["a", "b", "c"]                       # 3 films on 2 ranks: rank 0 owns a and c
+        n = {"a": 11, "b": 7, "c": 5}
+        gen = torch.Generator().manual_seed(3)        # same numbers on every rank
+        full = {f: {"g": torch.randn(n[f], generator=gen, dtype=torch.float32),
+                    "J": torch.randn(n[f], 2, generator=gen, dtype=torch.float64),
+                    "other": torch.randn(n[f], generator=gen, dtype=torch.float32)} for f in films}
+        shapes = {f: {k: tuple(v.shape) for k, v in full[f].items()} for f in films}
+        dtypes = {f: {k: v.dtype for k, v in full[f].items()} for f in films}
+        placement = FilmPlacement()
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+        payload = {f: ({k: v.clone() for k, v in full[f].items()} if f in placement.mine(films) else {})
+                   for f in films}
+        placement.share(films, payload, shapes, dtypes, torch.device("cpu"))
+        dist.all_reduce = real
+        ok = len(calls) == 1                         # ONE collective per pass
+        for f in films:
+            for k, v in full[f].items():
+                got = payload[f][k]
+                ok = ok and got.dtype == v.dtype and got.shape == v.shape and torch.equal(got, v)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_film_placement_share_is_one_collective_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in out), out

@@ -264,6 +264,25 @@ def test_mutual_inductance_matrix_vs_reference(golden):
     assert m[0, 0] > 0 and m[1, 1] > 0 and abs(m[0, 1] - m[1, 0]) < 0.05 * abs(m[0, 1])
 
 
+def test_mutual_inductance_default_iterations_same_on_both_paths():
+    """Without an ``iterations`` argument the reference forwards ``solve``'s default, 0 coupling
+    iterations (device/device.py:593-627, solver/solve.py:303): the all-columns-at-once path and the
+    one-solve-per-hole path must return the same (uncoupled) matrix."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(12, ("washer", "washer"), z_spacing=0.4)
+    M_sweep = np.asarray(device.mutual_inductance_matrix().magnitude)
+    # an extra keyword that the fast path does not take forces the per-hole loop of solve() calls
+    M_loop = np.asarray(device.mutual_inductance_matrix(check_inversion=False).magnitude)
+    assert np.max(np.abs(M_sweep - M_loop)) < 1e-10 * np.max(np.abs(M_loop))
+    M_coupled = np.asarray(device.mutual_inductance_matrix(iterations=1).magnitude)
+    assert np.max(np.abs(M_coupled - M_loop)) > 1e-6 * np.max(np.abs(M_loop))  # coupling does change M
+    # a device without holes: empty matrix, as the reference's loop over holes produces
+    plain = synthetic.make_stack_device(8, ("disk",))
+    assert np.asarray(plain.mutual_inductance_matrix().magnitude).shape == (0, 0)
+
+
 def test_find_fluxoid_solution():
     """find_fluxoid_solution (fluxoid.py:55-119): the returned solution has the requested fluxoids."""
     import superscreen_amd as sc
@@ -439,8 +458,9 @@ def test_terminal_currents_vs_reference(golden, name, method):
 
 
 def test_vector_potential_and_polygon_flux():
-    """Solution.vector_potential_at_position (solution.py:833-934) against its cdist/einsum formula,
-    and polygon_flux (:430-482) against the flux part of polygon_fluxoid."""
+    """Solution.vector_potential_at_position (solution.py:833-934) on a solved device against its
+    cdist/einsum formula, and polygon_flux (:430-482) against the flux part of polygon_fluxoid (the
+    reference's own outputs: test_vector_potential_and_polygon_flux_vs_reference)."""
     import superscreen_amd as sc
     from superscreen_amd import synthetic
     from superscreen_amd.units import MU_0
@@ -473,6 +493,37 @@ def test_vector_potential_and_polygon_flux():
         sol.polygon_flux("nope")
 
 
+def test_vector_potential_and_polygon_flux_vs_reference(golden):
+    """``Solution.vector_potential_at_position`` (solution.py:833-934) and ``Solution.polygon_flux``
+    (:430-482) against the outputs of the reference's own methods (tests/golden/potential_flux.npz,
+    recorded by oracle/make_golden.py::potential_and_flux_fixture)."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+    from superscreen_amd.solution import FilmSolution, Solution
+
+    d = golden("potential_flux.npz")
+    names = [str(x) for x in d["names"]]
+    device = synthetic.make_stack_device(int(d["K"]), ("washer", "disk"), z_spacing=float(d["z0s"][1]))
+    assert list(device.films) == names
+    n = len(device.meshes[names[0]].sites)
+    fs = {nm: FilmSolution(stream=np.zeros(n), current_density=d[f"J_{nm}"], applied_field=d[f"total_field_{nm}"],
+                           self_field=np.zeros(n)) for nm in names}
+    sol = Solution(device=device, film_solutions=fs, applied_field_func=sc.ConstantField(0.0), field_units="mT",
+                   current_units="uA")
+    got = sol.vector_potential_at_position(d["eval_xyz"], units="mT * um", with_units=False, return_sum=False)
+    for nm in names:
+        assert got[nm].shape == d[f"A_{nm}"].shape
+        assert relerr(got[nm], d[f"A_{nm}"]) < 1e-12
+    total = sol.vector_potential_at_position(d["eval_xyz"][:, :2], zs=float(d["zs_plane"]), units="mT * um",
+                                             with_units=False)
+    assert relerr(total, d["A_sum_plane"]) < 1e-12
+    for poly in ("washer0", "disk1", "hole0"):
+        a = sol.polygon_flux(poly, with_units=False)
+        b = sol.polygon_flux(poly, units="T * m**2", with_units=False)
+        assert abs(a - float(d[f"flux_{poly}_mT_um2"])) < 1e-12 * abs(float(d[f"flux_{poly}_mT_um2"]))
+        assert abs(b - float(d[f"flux_{poly}_T_m2"])) < 1e-12 * abs(float(d[f"flux_{poly}_T_m2"]))
+
+
 def test_film_placement_two_ranks():
     """parallel.FilmPlacement (owner-computes films, broadcast of the O(n) result vectors): two
     ranks share this GPU, gloo carries the broadcasts, results equal the single-process solve."""
@@ -492,6 +543,27 @@ def test_film_placement_two_ranks():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("owner-computes == single process") == 2
+
+
+def test_nccl_backend_single_rank():
+    """The ``nccl`` (= RCCL) backend itself: one rank on this GPU (RCCL does not admit two ranks on one
+    device, so the 2-rank test above stays on gloo).  The worker runs the coupling plan, the C-ABI
+    communicator, the placement exchange and the sharded sweep on RCCL."""
+    import socket
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "workers", "nccl_worker.py")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "coupling plan, C-ABI communicator, placement and sharded sweep ok" in out.stdout
 
 
 @pytest.mark.parametrize("method,dtype,tol", [("auto", "float64", 1e-11), ("lu", "float64", 1e-11),
