@@ -81,23 +81,14 @@ __device__ __forceinline__ void tile_full_f64(int64_t K, double alpha, const dou
     opa.issue(0, sm.a[0], wave);
     opb.issue(0, sm.b[0], wave);
 
+    // The accumulators start at zero and C enters in the epilogue (C = beta C + alpha acc): the first MFMA
+    // then waits for the first LDS stage only, not for 128 KB of C tile (the prologue load cost the K = 256
+    // update 17 % and the K = 512 update 9 %, tools/probes/syrk_k_probe.py, beta = 1 vs beta = 0).
     acc_t acc[4][4];
-    double *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
-    if (beta != 0.0) {
-        const double scale = beta / alpha;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-    }
+        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -123,13 +114,42 @@ __device__ __forceinline__ void tile_full_f64(int64_t K, double alpha, const dou
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
+    // Epilogue in 16-byte pieces.  The accumulator of a 16 x 16 tile holds, per lane, ONE column (lane & 15)
+    // of the rows lk + 4 r: lanes 2 c and 2 c + 1 swap half of their values so that each lane ends up with
+    // TWO adjacent columns of two rows (even lanes: r = 0, 2; odd lanes: r = 1, 3).  That halves the number
+    // of memory instructions of the tile's read-modify-write (32 x 16 B per lane instead of 64 x 8 B; the
+    // store tail is issue bound) and makes every access a full 16-byte one.
+    const int odd = lane & 1;
+    double *Cp = C + (m0 + wm * 64 + lk + 4 * odd) * ldc + n0 + wn * 64 + (li & ~1);
+    const bool has_c = (beta != 0.0);
+    double2 cin[2][8];
+    auto load_block = [&](int i, double2 (&dst)[8]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+            for (int q = 0; q < 2; ++q)
+                dst[2 * j + q] = *reinterpret_cast<const double2 *>(Cp + static_cast<int64_t>(i * 16 + 8 * q) * ldc + j * 16);
+    };
+    if (has_c) load_block(0, cin[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (has_c && i + 1 < 4) load_block(i + 1, cin[(i + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double r0 = acc[i][j][2 * q], r1 = acc[i][j][2 * q + 1];
+                const double t = __shfl_xor(odd ? r0 : r1, 1, 64);
+                double2 v;
+                v.x = alpha * (odd ? t : r0);
+                v.y = alpha * (odd ? r1 : t);
+                if (has_c) {
+                    v.x = __builtin_fma(beta, cin[i & 1][2 * j + q].x, v.x);
+                    v.y = __builtin_fma(beta, cin[i & 1][2 * j + q].y, v.y);
+                }
+                *reinterpret_cast<double2 *>(Cp + static_cast<int64_t>(i * 16 + 8 * q) * ldc + j * 16) = v;
+            }
+    }
 }
 
 // ---- FULL path, f32, NT (both operands K-MAJOR) -----------------------------------------------
@@ -378,7 +398,8 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
     const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
     const size_t smem = sizeof(OpSmemF64) > sizeof(EdgeSmem<T>) ? sizeof(OpSmemF64) : sizeof(EdgeSmem<T>);
     const int aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
-                        ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
+                        ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0) &&
+                        (reinterpret_cast<uintptr_t>(C) % 16 == 0) && ((ldc * sizeof(T)) % 16 == 0);
     const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
     static DeviceFlags lds_flags;
     if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB, LOWER>), smem}}) !=

@@ -1,0 +1,156 @@
+// HBM write-stream probe (development aid): which store form / work distribution fills a multi-GB buffer
+// fastest on this box?  Backs the choice of store instructions in q_assemble_kernel / system_assemble_kernel.
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/store_probe.hip -o tools/probes/store_probe && tools/probes/store_probe [GB]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum Form { PLAIN16, NT16, PLAIN4, NT4, SC1_16, SC01_16, PLAIN8, NT8 };
+
+template <int FORM>
+__device__ __forceinline__ void store16(u32x4 *p, u32x4 v) {
+    if (FORM == PLAIN16) *p = v;
+    else if (FORM == NT16) __builtin_nontemporal_store(v, p);
+    else if (FORM == SC1_16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if (FORM == SC01_16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// grid-stride: consecutive workgroups write adjacent 4 KiB pieces; the whole chip sweeps one window
+template <int FORM>
+__global__ void fill_gridstride16(u32x4 *__restrict__ dst, size_t count16) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count16; i += stride)
+        store16<FORM>(dst + i, v);
+}
+
+// 4 bytes per lane: 256 B per wave-instruction
+template <bool NT>
+__global__ void fill_gridstride4(unsigned *__restrict__ dst, size_t count4) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count4; i += stride) {
+        if (NT) __builtin_nontemporal_store(0x3f800000u, dst + i);
+        else dst[i] = 0x3f800000u;
+    }
+}
+
+template <bool NT>
+__global__ void fill_gridstride8(unsigned long long *__restrict__ dst, size_t count8) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count8; i += stride) {
+        if (NT) __builtin_nontemporal_store(0x3f8000003f800000ull, dst + i);
+        else dst[i] = 0x3f8000003f800000ull;
+    }
+}
+
+// chunked: every workgroup owns one contiguous chunk and walks it front to back
+template <int FORM>
+__global__ void fill_chunked16(u32x4 *__restrict__ dst, size_t count16) {
+    const size_t per = (count16 + gridDim.x - 1) / gridDim.x;
+    const size_t b = per * blockIdx.x, e = (b + per < count16) ? b + per : count16;
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t i = b + threadIdx.x; i < e; i += blockDim.x) store16<FORM>(dst + i, v);
+}
+
+// the shape of q_assemble_kernel: a workgroup owns a strip of 16 matrix rows and sweeps the columns;
+// a wave-instruction stores 1 KiB of one row, then the same column range of the next row
+template <int FORM, int TR>
+__global__ void fill_strips16(u32x4 *__restrict__ dst, size_t n_rows, size_t row16) {
+    const size_t r0 = static_cast<size_t>(blockIdx.x) * TR;
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t c = threadIdx.x; c < row16; c += blockDim.x)
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+            if (r0 + r < n_rows) store16<FORM>(dst + (r0 + r) * row16 + c, v);
+}
+
+// row-major order inside the strip: finish 4 KiB x k of one row before the next row (wave <-> row quarter)
+template <int FORM, int TR, int CH>
+__global__ void fill_strips_rowchunks16(u32x4 *__restrict__ dst, size_t n_rows, size_t row16) {
+    const size_t r0 = static_cast<size_t>(blockIdx.x) * TR;
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t c0 = 0; c0 < row16; c0 += static_cast<size_t>(blockDim.x) * CH)
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const size_t c = c0 + static_cast<size_t>(k) * blockDim.x + threadIdx.x;
+                if (r0 + r < n_rows && c < row16) store16<FORM>(dst + (r0 + r) * row16 + c, v);
+            }
+}
+
+template <typename F>
+double time_ms(F launch, int reps = 7) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    launch();
+    hipDeviceSynchronize();
+    std::vector<float> t;
+    for (int i = 0; i < reps; ++i) {
+        hipEventRecord(a, 0);
+        launch();
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+int main(int argc, char **argv) {
+    const double gb = argc > 1 ? atof(argv[1]) : 5.05;
+    const size_t n_rows = 25117, row16 = (static_cast<size_t>(gb * 1e9) / n_rows / 16 + 63) / 64 * 64;
+    const size_t bytes = n_rows * row16 * 16, count16 = bytes / 16;
+    void *buf;
+    if (hipMalloc(&buf, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    printf("buffer %.3f GB (%zu rows x %zu B)\n", bytes / 1e9, n_rows, row16 * 16);
+    auto report = [&](const char *name, double ms) { printf("%-58s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
+    u32x4 *d = static_cast<u32x4 *>(buf);
+    for (int wgs : {1024, 2048, 4096, 8192, 16384}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "grid-stride 16B plain, %d WG x 256", wgs);
+        report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(wgs), dim3(256), 0, 0, d, count16); }));
+        snprintf(nm, sizeof nm, "grid-stride 16B nt, %d WG x 256", wgs);
+        report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<NT16>, dim3(wgs), dim3(256), 0, 0, d, count16); }));
+    }
+    report("grid-stride 16B plain, 2048 WG x 1024", time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(2048), dim3(1024), 0, 0, d, count16); }));
+    report("grid-stride 16B nt, 512 WG x 1024", time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<NT16>, dim3(512), dim3(1024), 0, 0, d, count16); }));
+    report("grid-stride 16B sc1, 2048 WG x 256", time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<SC1_16>, dim3(2048), dim3(256), 0, 0, d, count16); }));
+    report("grid-stride 16B sc0 sc1, 2048 WG x 256", time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<SC01_16>, dim3(2048), dim3(256), 0, 0, d, count16); }));
+    report("grid-stride 4B plain, 4096 WG x 256", time_ms([&] { hipLaunchKernelGGL(fill_gridstride4<false>, dim3(4096), dim3(256), 0, 0, (unsigned *)buf, bytes / 4); }));
+    report("grid-stride 4B nt, 4096 WG x 256", time_ms([&] { hipLaunchKernelGGL(fill_gridstride4<true>, dim3(4096), dim3(256), 0, 0, (unsigned *)buf, bytes / 4); }));
+    report("grid-stride 8B plain, 4096 WG x 256", time_ms([&] { hipLaunchKernelGGL(fill_gridstride8<false>, dim3(4096), dim3(256), 0, 0, (unsigned long long *)buf, bytes / 8); }));
+    report("grid-stride 8B nt, 4096 WG x 256", time_ms([&] { hipLaunchKernelGGL(fill_gridstride8<true>, dim3(4096), dim3(256), 0, 0, (unsigned long long *)buf, bytes / 8); }));
+    for (int wgs : {256, 512, 2048, 8192}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "chunked 16B plain, %d WG x 256", wgs);
+        report(nm, time_ms([&] { hipLaunchKernelGGL(fill_chunked16<PLAIN16>, dim3(wgs), dim3(256), 0, 0, d, count16); }));
+        snprintf(nm, sizeof nm, "chunked 16B nt, %d WG x 256", wgs);
+        report(nm, time_ms([&] { hipLaunchKernelGGL(fill_chunked16<NT16>, dim3(wgs), dim3(256), 0, 0, d, count16); }));
+    }
+    const unsigned strips16 = (n_rows + 15) / 16, strips8 = (n_rows + 7) / 8, strips4 = (n_rows + 3) / 4, strips32 = (n_rows + 31) / 32;
+    report("strips of 16 rows (q_assemble shape) 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 16>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 16 rows (q_assemble shape) 16B nt", time_ms([&] { hipLaunchKernelGGL((fill_strips16<NT16, 16>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 16 rows 16B sc0 sc1", time_ms([&] { hipLaunchKernelGGL((fill_strips16<SC01_16, 16>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 8 rows 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 8>), dim3(strips8), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 8 rows 16B nt", time_ms([&] { hipLaunchKernelGGL((fill_strips16<NT16, 8>), dim3(strips8), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 4 rows 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 4>), dim3(strips4), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 4 rows 16B nt", time_ms([&] { hipLaunchKernelGGL((fill_strips16<NT16, 4>), dim3(strips4), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 32 rows 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 32>), dim3(strips32), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 16 rows, 512 threads, 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 16>), dim3(strips16), dim3(512), 0, 0, d, n_rows, row16); }));
+    report("strips of 16 rows, 1024 threads, 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 16>), dim3(strips16), dim3(1024), 0, 0, d, n_rows, row16); }));
+    report("strips of 16 rows, 16 KiB of a row at a time, plain", time_ms([&] { hipLaunchKernelGGL((fill_strips_rowchunks16<PLAIN16, 16, 4>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
+    report("strips of 16 rows, 16 KiB of a row at a time, nt", time_ms([&] { hipLaunchKernelGGL((fill_strips_rowchunks16<NT16, 16, 4>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
+    // hipMemset as the runtime's own fill
+    report("hipMemsetAsync", time_ms([&] { hipMemsetAsync(buf, 0, bytes, 0); }));
+    hipFree(buf);
+    return 0;
+}
