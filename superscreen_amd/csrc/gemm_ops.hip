@@ -10,6 +10,8 @@
 //   K-MINOR  (m|n contiguous: A for op T, B for op N) [16][128 + 16]
 // so NT (SYRK: both operands are row panels of the same matrix) uses two K-MAJOR images and TN
 // (backward substitution with L^T on many right-hand sides) two K-MINOR images.
+#include <stdlib.h>
+
 #include "gemm_profile.hpp"
 #include "mfma_traits.hpp"
 
@@ -81,14 +83,23 @@ __device__ __forceinline__ void tile_full_f64(int64_t K, double alpha, const dou
     opa.issue(0, sm.a[0], wave);
     opb.issue(0, sm.b[0], wave);
 
-    // The accumulators start at zero and C enters in the epilogue (C = beta C + alpha acc): the first MFMA
-    // then waits for the first LDS stage only, not for 128 KB of C tile (the prologue load cost the K = 256
-    // update 17 % and the K = 512 update 9 %, tools/probes/syrk_k_probe.py, beta = 1 vs beta = 0).
     acc_t acc[4][4];
+    double *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
+    if (beta != 0.0) {
+        const double scale = beta / alpha;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -114,42 +125,13 @@ __device__ __forceinline__ void tile_full_f64(int64_t K, double alpha, const dou
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // Epilogue in 16-byte pieces.  The accumulator of a 16 x 16 tile holds, per lane, ONE column (lane & 15)
-    // of the rows lk + 4 r: lanes 2 c and 2 c + 1 swap half of their values so that each lane ends up with
-    // TWO adjacent columns of two rows (even lanes: r = 0, 2; odd lanes: r = 1, 3).  That halves the number
-    // of memory instructions of the tile's read-modify-write (32 x 16 B per lane instead of 64 x 8 B; the
-    // store tail is issue bound) and makes every access a full 16-byte one.
-    const int odd = lane & 1;
-    double *Cp = C + (m0 + wm * 64 + lk + 4 * odd) * ldc + n0 + wn * 64 + (li & ~1);
-    const bool has_c = (beta != 0.0);
-    double2 cin[2][8];
-    auto load_block = [&](int i, double2 (&dst)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                dst[2 * j + q] = *reinterpret_cast<const double2 *>(Cp + static_cast<int64_t>(i * 16 + 8 * q) * ldc + j * 16);
-    };
-    if (has_c) load_block(0, cin[0]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (has_c && i + 1 < 4) load_block(i + 1, cin[(i + 1) & 1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const double r0 = acc[i][j][2 * q], r1 = acc[i][j][2 * q + 1];
-                const double t = __shfl_xor(odd ? r0 : r1, 1, 64);
-                double2 v;
-                v.x = alpha * (odd ? t : r0);
-                v.y = alpha * (odd ? r1 : t);
-                if (has_c) {
-                    v.x = __builtin_fma(beta, cin[i & 1][2 * j + q].x, v.x);
-                    v.y = __builtin_fma(beta, cin[i & 1][2 * j + q].y, v.y);
-                }
-                *reinterpret_cast<double2 *>(Cp + static_cast<int64_t>(i * 16 + 8 * q) * ldc + j * 16) = v;
-            }
-    }
+            for (int r = 0; r < 4; ++r)
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
 }
 
 // ---- FULL path, f32, NT (both operands K-MAJOR) -----------------------------------------------
@@ -334,8 +316,23 @@ template <typename T, int TA, int TB, bool LOWER>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
     const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
-    int64_t ntn, int aligned) {
+    int64_t ntn, int aligned, int stagger_first, int stagger_ticks) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // Phase stagger (see launch_op_l): of the two workgroups that share a CU in the first generation of
+    // the grid, the one whose LDS allocation does not start at 0 begins one tile-compute-time late.  Every
+    // later workgroup inherits the phase of the one whose slot it takes, so for the rest of the launch one
+    // partner moves its C tile (read at the start, written at the end of a tile) while the other has the
+    // SIMDs' matrix pipes to itself.  Unstaggered, all workgroups of the chip load, compute and store in
+    // lockstep: ~30 us of every tile round are a chip-wide burst of C traffic with idle matrix pipes
+    // (65 % of the MFMA rate at K = 256, 79 % at K = 512, independent of where in the tile C is read).
+    if (stagger_ticks > 0 && static_cast<int>(blockIdx.x) < stagger_first) {
+        unsigned lds_alloc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));
+        if ((lds_alloc & 0xfffu) != 0u) {  // LDS_BASE: the second workgroup placed on this CU
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < static_cast<unsigned long long>(stagger_ticks)) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     int64_t tm, tn;
     if constexpr (LOWER) {
         // Lower-triangular tile enumeration in bands of 8 tile rows, column by column inside a
@@ -398,8 +395,7 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
     const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
     const size_t smem = sizeof(OpSmemF64) > sizeof(EdgeSmem<T>) ? sizeof(OpSmemF64) : sizeof(EdgeSmem<T>);
     const int aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
-                        ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0) &&
-                        (reinterpret_cast<uintptr_t>(C) % 16 == 0) && ((ldc * sizeof(T)) % 16 == 0);
+                        ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
     const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
     static DeviceFlags lds_flags;
     if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB, LOWER>), smem}}) !=
@@ -410,9 +406,29 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
                                                                 : static_cast<double>(M) * N);
     ProfileScope scope(aligned && sizeof(T) == 8 && TA == OP_N && TB == OP_T, lower ? kProfileSyrkLower : kProfileOpNT,
                        flops, st);
+    // stagger: grids of more than one generation (two workgroups per CU are resident); the late partner
+    // waits one exclusive tile-compute time: K / 16 stages x 64 MFMAs x 64 cycles (f64) at ~2.2 GHz = 0.116 us
+    // per unit of K (float32: half), in ticks of the 100 MHz wall clock.  SSA_GEMM_STAGGER scales it (0 = off).
+    static const double stagger_scale = [] {
+        const char *e = getenv("SSA_GEMM_STAGGER");
+        return e ? atof(e) : 1.0;
+    }();
+    int num_cus = 256, dev = 0;
+    static int cus_of_device[kMaxDevices] = {};
+    if (current_device(&dev) == SSA_OK) {
+        if (cus_of_device[dev] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus_of_device[dev] = v;
+        }
+        if (cus_of_device[dev] > 0) num_cus = cus_of_device[dev];
+    }
+    const int stagger_first = 2 * num_cus;
+    int stagger_ticks = 0;
+    if (aligned && nwg > stagger_first && K >= 128)
+        stagger_ticks = static_cast<int>(stagger_scale * 11.6 * static_cast<double>(K) * (sizeof(T) == 8 ? 1.0 : 0.5));
     hipLaunchKernelGGL((gemm_op_kernel<T, TA, TB, LOWER>), dim3(static_cast<unsigned>(nwg)),
                        dim3(kGemmThreads), smem, st, M, N, K, static_cast<T>(alpha), A, lda, B, ldb,
-                       static_cast<T>(beta), C, ldc, ntm, ntn, aligned);
+                       static_cast<T>(beta), C, ldc, ntm, ntn, aligned, stagger_first, stagger_ticks);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }

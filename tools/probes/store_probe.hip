@@ -84,6 +84,18 @@ __global__ void fill_strips_rowchunks16(u32x4 *__restrict__ dst, size_t n_rows, 
             }
 }
 
+// one shot: no loop; a workgroup writes U consecutive 4 KiB pieces (U stores per lane, all issued at once)
+template <int FORM, int U>
+__global__ void fill_oneshot16(u32x4 *__restrict__ dst, size_t count16) {
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    const size_t base = (static_cast<size_t>(blockIdx.x) * U) * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + static_cast<size_t>(u) * blockDim.x;
+        if (i < count16) store16<FORM>(dst + i, v);
+    }
+}
+
 template <typename F>
 double time_ms(F launch, int reps = 7) {
     hipEvent_t a, b;
@@ -149,6 +161,29 @@ int main(int argc, char **argv) {
     report("strips of 16 rows, 1024 threads, 16B plain", time_ms([&] { hipLaunchKernelGGL((fill_strips16<PLAIN16, 16>), dim3(strips16), dim3(1024), 0, 0, d, n_rows, row16); }));
     report("strips of 16 rows, 16 KiB of a row at a time, plain", time_ms([&] { hipLaunchKernelGGL((fill_strips_rowchunks16<PLAIN16, 16, 4>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
     report("strips of 16 rows, 16 KiB of a row at a time, nt", time_ms([&] { hipLaunchKernelGGL((fill_strips_rowchunks16<NT16, 16, 4>), dim3(strips16), dim3(256), 0, 0, d, n_rows, row16); }));
+    {
+        auto one = [&](auto kern, int U, int threads, const char *nm) {
+            const unsigned grid = static_cast<unsigned>((count16 + static_cast<size_t>(U) * threads - 1) / (static_cast<size_t>(U) * threads));
+            char name[128];
+            snprintf(name, sizeof name, "one shot 16B %s, %d stores/lane, %d threads (%u WG)", nm, U, threads, grid);
+            report(name, time_ms([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, d, count16); }));
+        };
+        one(fill_oneshot16<PLAIN16, 1>, 1, 256, "plain");
+        one(fill_oneshot16<PLAIN16, 2>, 2, 256, "plain");
+        one(fill_oneshot16<PLAIN16, 4>, 4, 256, "plain");
+        one(fill_oneshot16<PLAIN16, 8>, 8, 256, "plain");
+        one(fill_oneshot16<PLAIN16, 16>, 16, 256, "plain");
+        one(fill_oneshot16<PLAIN16, 4>, 4, 512, "plain");
+        one(fill_oneshot16<PLAIN16, 4>, 4, 1024, "plain");
+        one(fill_oneshot16<PLAIN16, 1>, 1, 1024, "plain");
+        one(fill_oneshot16<NT16, 4>, 4, 256, "nt");
+        one(fill_oneshot16<SC1_16, 4>, 4, 256, "sc1");
+    }
+    for (int wgs : {32768, 65536, 131072}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "grid-stride 16B plain, %d WG x 256", wgs);
+        report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(wgs), dim3(256), 0, 0, d, count16); }));
+    }
     // hipMemset as the runtime's own fill
     report("hipMemsetAsync", time_ms([&] { hipMemsetAsync(buf, 0, bytes, 0); }));
     hipFree(buf);
