@@ -21,6 +21,8 @@
 // inverses (and their transposes) of the SNB x SNB diagonal blocks of L, so that both triangular
 // solves are chains of 2 row-major GEMVs per block that stream at HBM speed
 // (x_k = inv_k b_k;  b_rest -= L[rest, k] x_k), with no transposed access and no per-row dependency.
+#include <stdlib.h>
+
 #include <mutex>
 #include <utility>
 
@@ -191,8 +193,9 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
 // with its two events, and a low-priority stream on which a matrix that is done before the others
 // (a smaller film) builds its solve-phase blocks while the tail of the others still runs.
 struct CholLane {
-    hipStream_t side = nullptr, finish = nullptr;
-    hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr;
+    hipStream_t side = nullptr, finish = nullptr, upd = nullptr;
+    hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr,
+               ev_upd = nullptr;
 };
 constexpr int kMaxLanes = 16;
 
@@ -217,6 +220,8 @@ inline int get_lanes(int count, LaneSet **out) {
         if (lanes[i].side != nullptr) continue;
         if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].finish, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_upd, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_strip, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -236,11 +241,15 @@ inline int destroy_lanes() {
         std::lock_guard<std::mutex> enq(g_lane_sets[d].enqueue);
         for (CholLane &ln : g_lane_sets[d].lanes) {
             if (ln.side == nullptr) continue;
-            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.finish) != hipSuccess) rc = SSA_ERR_HIP;
-            hipEvent_t evs[5] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk};
+            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.finish) != hipSuccess ||
+                hipStreamSynchronize(ln.upd) != hipSuccess)
+                rc = SSA_ERR_HIP;
+            hipEvent_t evs[6] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk, ln.ev_upd};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.finish) != hipSuccess) rc = SSA_ERR_HIP;
+            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.finish) != hipSuccess ||
+                hipStreamDestroy(ln.upd) != hipSuccess)
+                rc = SSA_ERR_HIP;
             ln = CholLane{};
         }
     }
@@ -411,6 +420,14 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (rc != SSA_OK) return rc;
     std::lock_guard<std::mutex> enqueue_lock(lane_set->enqueue);
     CholLane *lanes = lane_set->lanes;
+    // SSA_CHOL_UPD_STREAMS=1 (experiment): the trailing updates of matrix i go to a stream of their own instead of
+    // alternating on the caller's stream, so that the partially filled last round of tiles of one matrix'
+    // update overlaps the next update of another matrix
+    static const bool own_update_streams = [] {
+        const char *e = getenv("SSA_CHOL_UPD_STREAMS");
+        return e && atoi(e) != 0;
+    }();
+    const bool split_updates = own_update_streams && count > 1;
     // outer steps (per matrix) that are chain bound: the last ~6k columns at this panel speed
     constexpr int64_t kTailCols = 6144;
     FinishPlan<T> plans[kMaxLanes];
@@ -427,6 +444,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         // fork: the side stream starts after everything enqueued so far on the caller's stream
         if (hipEventRecord(ln.ev_strip, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
             return SSA_ERR_HIP;
+        if (split_updates && hipStreamWaitEvent(ln.upd, ln.ev_strip, 0) != hipSuccess) return SSA_ERR_HIP;
         rc = chol_factor_panel(J, 0, ln.side);
         if (rc != SSA_OK) return rc;
         if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
@@ -449,7 +467,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 // panel and behind what the caller's stream holds for it so far
                 if (!detached[i]) {
                     detached[i] = true;
-                    if (hipEventRecord(ln.ev_fork, st) != hipSuccess ||
+                    if (hipEventRecord(ln.ev_fork, split_updates ? ln.upd : st) != hipSuccess ||
                         hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess ||
                         hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess)
                         return SSA_ERR_HIP;
@@ -462,13 +480,14 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 }
                 continue;
             }
+            hipStream_t us = split_updates ? ln.upd : st;     // where this matrix' trailing updates run
             const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
             // panels whose update of the trailing matrix is still pending: columns [pend0, k0 + CNB)
             const int64_t pend0 = pending_from[i], kp = k0 + CNB - pend0;
             const T *P = J.A + (k0 + CNB) * J.lda + pend0;    // those panels below the diagonal block of panel k
             T *C = J.A + (k0 + CNB) * J.lda + (k0 + CNB);
-            if (hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
+            if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
             // the strip runs on the chain's own stream, behind panel k (same stream) and behind the last
             // trailing update of THIS matrix (which wrote the strip's columns): it does not queue behind
             // the other matrices' updates on the caller's stream
@@ -487,9 +506,9 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             if (right > nw && !delay) {  // rest of the trailing update: lower tiles of the (right - nw) block
                 const T *P2 = P + nw * J.lda;
                 rc = gemm_op_t(0, 1, 1, right - nw, right - nw, kp, -1.0, P2, J.lda, P2, J.lda, 1.0,
-                               C + nw * J.lda + nw, J.lda, st);
+                               C + nw * J.lda + nw, J.lda, us);
                 if (rc != SSA_OK) return rc;
-                if (hipEventRecord(ln.ev_syrk, st) != hipSuccess) return SSA_ERR_HIP;
+                if (hipEventRecord(ln.ev_syrk, us) != hipSuccess) return SSA_ERR_HIP;
                 syrk_recorded[i] = true;
             }
             if (!delay) pending_from[i] = k0 + CNB;
@@ -497,13 +516,16 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             // stream has waited for) are final: fills the slots where the stream waits for the chain
             FinishPlan<T> &fp = plans[i];
             if (fp.next < fp.n_early && k0 + CNB >= fp.early_cols()) {
-                rc = fp.run_step(fp.next++, st);
+                rc = fp.run_step(fp.next++, us);
                 if (rc != SSA_OK) return rc;
             }
         }
     }
     for (int i = 0; i < count; ++i) {  // join, then the inverses of the diagonal blocks
         if (hipStreamWaitEvent(st, detached[i] ? lanes[i].ev_finish : lanes[i].ev_panel, 0) != hipSuccess)
+            return SSA_ERR_HIP;
+        if (split_updates && (hipEventRecord(lanes[i].ev_upd, lanes[i].upd) != hipSuccess ||
+                              hipStreamWaitEvent(st, lanes[i].ev_upd, 0) != hipSuccess))
             return SSA_ERR_HIP;
     }
     for (int i = 0; i < count; ++i) {

@@ -181,28 +181,64 @@ class LUFactors:
 
 def lu_factor(A: torch.Tensor, n: int) -> LUFactors:
     """``scipy.linalg.lu_factor`` (solver/solve_film.py:279): in-place on ``A [n, lda]``."""
+    return lu_factor_batch([(A, n)])[0]
+
+
+_lu_streams: dict = {}
+
+
+def lu_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[LUFactors]:
+    """LU factorizations of several matrices (the films of a device), in place, each on a stream of its
+    own: a factorization is a strictly sequential chain of latency-bound panel kernels and MFMA trailing
+    updates, so the panels of one matrix run beside the updates of the others (the Cholesky route does the
+    same inside one schedule, ``ssa_chol_factor_batch``).  Every matrix has its own workspace; the factors
+    do not depend on what they are batched with."""
     lib = load_library()
-    dt = dtype_code(A.dtype)
-    lda = A.shape[1]
-    dev = A.device
-    ipiv = torch.empty(n, dtype=torch.int32, device=dev)
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
-    aux = torch.empty(lib.ssa_lu_aux_bytes(n, dt) // A.element_size(), dtype=A.dtype, device=dev)
-    nbytes = lib.ssa_lu_factor_workspace_bytes(n, dt)
-    ws = _ws(nbytes, dev)
-    check(lib.ssa_lu_factor(ptr(A), n, lda, ptr(ipiv), ptr(info), ptr(aux), dt, ptr(ws), nbytes,
-                            current_stream()), "ssa_lu_factor")
-    ipiv_h = np.ascontiguousarray(ipiv.cpu().numpy())  # synchronises the stream
-    info_h = int(info.item())
-    if info_h < 0:
-        raise _hip.HipLibraryError(
-            "ssa_lu_factor: the cooperative panel kernel timed out waiting for a peer workgroup."
-        )
-    perm_h = np.empty(n, dtype=np.int64)
-    check(lib.ssa_lu_pivots_to_permutation(ipiv_h.ctypes.data, n, perm_h.ctypes.data),
-          "ssa_lu_pivots_to_permutation")
-    perm = torch.from_numpy(perm_h).to(dev)
-    return LUFactors(lu=A, n=n, ipiv=ipiv, perm=perm, aux=aux, info=info_h, dtype=A.dtype)
+    if not systems:
+        return []
+    dev = systems[0][0].device
+    main = torch.cuda.current_stream(dev)
+    side = _lu_streams.setdefault(dev.index, [])
+    while len(side) < len(systems) - 1:
+        side.append(torch.cuda.Stream(device=dev))
+    streams = [main] + side[:len(systems) - 1]
+    start = torch.cuda.Event()
+    start.record(main)
+    pending = []
+    for (A, n), st in zip(systems, streams):
+        dt = dtype_code(A.dtype)
+        ipiv = torch.empty(n, dtype=torch.int32, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        aux = torch.empty(lib.ssa_lu_aux_bytes(n, dt) // A.element_size(), dtype=A.dtype, device=dev)
+        nbytes = lib.ssa_lu_factor_workspace_bytes(n, dt)
+        ws = _ws(nbytes, dev)
+        pending.append((A, n, ipiv, info, aux, ws, nbytes, dt, st))
+    for A, n, ipiv, info, aux, ws, nbytes, dt, st in pending:
+        if st is not main:
+            st.wait_event(start)          # after the assembly (and the zero-fill of info) on the caller's stream
+            for t in (A, ipiv, info, aux, ws):
+                t.record_stream(st)
+        check(lib.ssa_lu_factor(ptr(A), n, A.shape[1], ptr(ipiv), ptr(info), ptr(aux), dt, ptr(ws), nbytes,
+                                st.cuda_stream), "ssa_lu_factor")
+    for *_, st in pending:
+        if st is not main:
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+    out = []
+    for A, n, ipiv, info, aux, ws, nbytes, dt, st in pending:
+        ipiv_h = np.ascontiguousarray(ipiv.cpu().numpy())  # synchronises the stream
+        info_h = int(info.item())
+        if info_h < 0:
+            raise _hip.HipLibraryError(
+                "ssa_lu_factor: the cooperative panel kernel timed out waiting for a peer workgroup."
+            )
+        perm_h = np.empty(n, dtype=np.int64)
+        check(lib.ssa_lu_pivots_to_permutation(ipiv_h.ctypes.data, n, perm_h.ctypes.data),
+              "ssa_lu_pivots_to_permutation")
+        perm = torch.from_numpy(perm_h).to(dev)
+        out.append(LUFactors(lu=A, n=n, ipiv=ipiv, perm=perm, aux=aux, info=info_h, dtype=A.dtype))
+    return out
 
 
 def lu_solve_permuted(f: LUFactors, B: torch.Tensor) -> torch.Tensor:

@@ -392,9 +392,12 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             ix_d = torch.from_numpy(interior.astype(np.int64)).to(dev)
             ni = len(interior)
 
-            def lu_route(ix_d=ix_d, ni=ni, assemble=assemble, name=name):
-                minusA = assemble(ix_d, ix_d, -1.0)      # -A, written once, factored in place
-                factors = kernels.lu_factor(minusA, ni)  # solve_film.py:279
+            def lu_route(ix_d=ix_d, ni=ni, assemble=assemble, name=name, assemble_only=False, factors=None):
+                if factors is None:
+                    minusA = assemble(ix_d, ix_d, -1.0)      # -A, written once, factored in place
+                    if assemble_only:
+                        return minusA, ni
+                    factors = kernels.lu_factor(minusA, ni)  # solve_film.py:279
                 if factors.info > 0:
                     logger.warning(f"LU of film {name!r}: exactly singular U[{factors.info - 1}, "
                                    f"{factors.info - 1}] (LAPACK info = {factors.info}).")
@@ -424,6 +427,14 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     # the other films' updates.
     with_S = [p for p in pending if p[4] is not None]
     chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S])))
+    # the films that take the LU route (method="lu", Lambda(x, y), a failed Cholesky) are factored together,
+    # one stream per film: the panel chain of one film runs beside the trailing updates of the others
+    lu_keys = [p[0] for p in pending if p[3] > 0 and (chols.get(p[0]) is None or chols[p[0]].info != 0)]
+    if method == "cholesky" and any(chols.get(k) is not None for k in lu_keys):
+        bad = [k[0] for k in lu_keys if chols.get(k) is not None]
+        raise RuntimeError(f"diag(w) A of film {bad[0]!r} is not positive definite.")
+    lu_inputs = {p[0]: p[5](assemble_only=True) for p in pending if p[0] in lu_keys}
+    lu_batch = dict(zip(lu_inputs, kernels.lu_factor_batch(list(lu_inputs.values())))) if lu_inputs else {}
     for key, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term in pending:
         name, role = key
         system = None
@@ -444,7 +455,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             system = LinearSystem(indices=interior, indices_device=ix_d, grad_Lambda_term=grad_Lambda_term,
                                   _assemble=host_A)
         if system is None:
-            factors = lu_route()
+            factors = lu_route(factors=lu_batch[key])
             system = LinearSystem(indices=interior, factors=factors, indices_device=ix_d,
                                   grad_Lambda_term=grad_Lambda_term,
                                   rhs_indices_device=ix_d[factors.perm].contiguous(), _assemble=host_A)
