@@ -12,7 +12,8 @@ from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsuperscreen_hip.so")
+# SSA_LIB_PATH: an experiment build of the same C ABI (python -m superscreen_amd.build -D... --libname=...)
+LIB_PATH = os.environ.get("SSA_LIB_PATH") or os.path.join(_PKG, "lib", "libsuperscreen_hip.so")
 
 SSA_F32 = 0
 SSA_F64 = 1

@@ -44,8 +44,13 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), libname: str = LIBNAME) -> str:
+    """``extra_flags`` / ``libname``: experiment builds (e.g. ``-DSSA_SNB=2048`` into a second library that
+    ``SSA_LIB_PATH`` selects at run time); they get their own object directory."""
+    global OBJDIR
     os.makedirs(LIBDIR, exist_ok=True)
+    if libname != LIBNAME:
+        OBJDIR = os.path.join(PKG, "build", libname.replace(".so", ""))
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
@@ -56,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if not force and _newer(o, [s] + headers):
             return o
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -64,7 +69,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    out = lib_path()
+    out = os.path.join(LIBDIR, libname)
     if force or not _newer(out, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs + ["-ldl"]
         if verbose:
@@ -74,4 +79,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    names = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--libname=")]
+    print(build(force="--force" in sys.argv, extra_flags=flags, libname=names[0] if names else LIBNAME))

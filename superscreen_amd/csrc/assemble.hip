@@ -38,6 +38,17 @@ __device__ __forceinline__ void store_pair(OutT *p, OutT a, OutT b) {
 }
 
 // Q_ij = -q_ij (i != j), Q_ii = (C_i + sum_{l != i} q_il w_l) / w_i.
+//
+// Rows per workgroup: the grid is a whole number of "rounds" of the chip's resident workgroup slots and the
+// n rows are dealt out evenly (heights differ by at most one row, <= TR): with fixed 16-row strips a matrix
+// of 25 117 rows is 1 570 workgroups on 1 024 slots, i.e. two rounds of 16 rows for 1.53 rounds of work
+// (every workgroup streams at the same rate, so the second round runs half empty).
+__host__ __device__ inline void strip_rows(int64_t n, int64_t groups, int64_t b, int64_t *i0, int *h) {
+    const int64_t base = n / groups, extra = n % groups;
+    *i0 = b * base + (b < extra ? b : extra);
+    *h = static_cast<int>(base + (b < extra ? 1 : 0));
+}
+
 template <typename OutT, int TR>
 __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
     const double *__restrict__ xy, const double *__restrict__ w, const double *__restrict__ C,
@@ -46,13 +57,15 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * TR;
+    int64_t i0;
+    int h;  // rows of this workgroup, 1 .. TR (workgroup-uniform)
+    strip_rows(n, gridDim.x, blockIdx.x, &i0, &h);
 
     // Row coordinates are workgroup-uniform: scalar loads into SGPRs, no LDS traffic.
     double xi[TR], yi[TR];
 #pragma unroll
     for (int r = 0; r < TR; ++r) {
-        const int64_t i = (i0 + r < n) ? i0 + r : n - 1;
+        const int64_t i = (r < h) ? i0 + r : i0;
         xi[r] = xy[2 * i];
         yi[r] = xy[2 * i + 1];
     }
@@ -69,17 +82,19 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         const double w1 = has1 ? w[j + 1] : 0.0;
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
-            const int64_t i = i0 + r;
-            const double dx0 = xi[r] - xj0, dy0 = yi[r] - yj0;
-            const double dx1 = xi[r] - xj1, dy1 = yi[r] - yj1;
-            double q0 = inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
-            double q1 = inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
-            q0 = (i == j) ? 0.0 : q0;                  // distance.py:104-105
-            q1 = (i == j + 1 || !has1) ? 0.0 : q1;
-            acc[r] = __builtin_fma(q0, w0, acc[r]);
-            acc[r] = __builtin_fma(q1, w1, acc[r]);
-            if (Q != nullptr && i < n) {
-                store_pair<OutT>(Q + i * ldq + j, static_cast<OutT>(-q0), static_cast<OutT>(-q1));
+            if (r < h) {  // uniform branch: rows beyond this workgroup's share cost nothing
+                const int64_t i = i0 + r;
+                const double dx0 = xi[r] - xj0, dy0 = yi[r] - yj0;
+                const double dx1 = xi[r] - xj1, dy1 = yi[r] - yj1;
+                double q0 = inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
+                double q1 = inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
+                q0 = (i == j) ? 0.0 : q0;                  // distance.py:104-105
+                q1 = (i == j + 1 || !has1) ? 0.0 : q1;
+                acc[r] = __builtin_fma(q0, w0, acc[r]);
+                acc[r] = __builtin_fma(q1, w1, acc[r]);
+                if (Q != nullptr) {
+                    store_pair<OutT>(Q + i * ldq + j, static_cast<OutT>(-q0), static_cast<OutT>(-q1));
+                }
             }
         }
     }
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         if (lane == 0) s_part[wave][r] = s;
     }
     __syncthreads();  // also drains this workgroup's stores (vmcnt(0)) before the diagonal
-    if (tid < TR && i0 + tid < n) {
+    if (tid < h) {
         const int64_t i = i0 + tid;
         double s = 0.0;
 #pragma unroll
@@ -99,6 +114,28 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         if (qdiag != nullptr) qdiag[i] = d;
         if (Q != nullptr) Q[i * ldq + i] = static_cast<OutT>(d);
     }
+}
+
+// Number of workgroups for n rows: a whole number of rounds of the kernel's resident slots on this device
+// (every CU then holds the same number of equally long workgroups), plain ceil(n / TR) strips for small n.
+template <typename Kernel>
+inline int64_t balanced_groups(Kernel kernel, int64_t n, int tr) {
+    static int slots_of_device[kMaxDevices] = {};
+    int dev = 0;
+    int64_t plain = ceil_div(n, tr);
+    if (current_device(&dev) != SSA_OK) return plain;
+    if (slots_of_device[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kAsmThreads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0)
+            return plain;
+        slots_of_device[dev] = per_cu * cus;
+    }
+    // one workgroup per slot and round; below ~8 rows per workgroup the per-row share of the column loads
+    // grows and the launch is latency bound anyway: plain strips
+    const int64_t slots = slots_of_device[dev];
+    if (n < 8 * slots) return plain;
+    return slots * ceil_div(n, static_cast<int64_t>(tr) * slots);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -139,7 +176,10 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * TR;
+    // lower_only: a strip's work grows with its row index; the long strips go first so that the short
+    // ones fill the end of the launch
+    const int64_t strip = lower_only ? static_cast<int64_t>(gridDim.x) - 1 - blockIdx.x : blockIdx.x;
+    const int64_t r0 = strip * TR;
     if (tid < TR) {
         const int64_t r = (r0 + tid < nr) ? r0 + tid : nr - 1;
         s_x[tid] = row_x[r];
@@ -212,11 +252,12 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
     if (n <= 0 || !xy || !w || !C) return SSA_ERR_INVALID_ARGUMENT;
     if (Q && (ldq < n || (ldq & 1))) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
-    const dim3 grid(static_cast<unsigned>(ceil_div(n, kStripRows)));
     if (dtype == SSA_F64) {
+        const dim3 grid(static_cast<unsigned>(balanced_groups(q_assemble_kernel<double, kStripRows>, n, kStripRows)));
         hipLaunchKernelGGL((q_assemble_kernel<double, kStripRows>), grid, dim3(kAsmThreads), 0,
                            as_stream(stream), xy, w, C, n, static_cast<double *>(Q), ldq, qdiag);
     } else {
+        const dim3 grid(static_cast<unsigned>(balanced_groups(q_assemble_kernel<float, kStripRows>, n, kStripRows)));
         hipLaunchKernelGGL((q_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads), 0,
                            as_stream(stream), xy, w, C, n, static_cast<float *>(Q), ldq, qdiag);
     }

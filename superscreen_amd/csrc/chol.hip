@@ -127,7 +127,10 @@ inline int gemm_batched_t(int64_t M, int64_t N, int64_t K, double alpha, const f
     return gemm_batched_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, st);
 }
 
-constexpr int64_t SNB = 4096;  // block size of the triangular solves (pre-inverted diagonal blocks)
+#ifndef SSA_SNB
+#define SSA_SNB 4096
+#endif
+constexpr int64_t SNB = SSA_SNB;  // block size of the triangular solves (pre-inverted diagonal blocks)
 
 // aux layout (elements):  inv [nblk][SNB][SNB] | invT [nblk][SNB][SNB] | tmp | scratch
 struct AuxLayout {
