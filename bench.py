@@ -266,7 +266,8 @@ def config4_scan(sc, torch, dist, rank, world, iterations):
     from superscreen_amd import synthetic
     from superscreen_amd.parallel import solve_sweep_sharded
 
-    device = synthetic.make_stack_device(81, ("washer", "disk"), solve_dtype="float64")
+    K4 = int(os.environ.get("BENCH_CONFIG4_K", "81"))             # testing aid: smaller meshes
+    device = synthetic.make_stack_device(K4, ("washer", "disk"), solve_dtype="float64")
     scan = [float(v) for v in np.linspace(0.1, 6.4, 64)]          # mT
 
     def barrier():
@@ -314,7 +315,8 @@ def config5_stack(sc, torch, dist, rank, world, iterations, steps=2):
     from superscreen_amd import synthetic
     from superscreen_amd.parallel import CouplingPlan, FilmPlacement
 
-    device = synthetic.make_stack_device(100, ("disk",) * 4, z_spacing=0.5, solve_dtype="float64")
+    K5 = int(os.environ.get("BENCH_CONFIG5_K", "100"))            # testing aid: smaller meshes
+    device = synthetic.make_stack_device(K5, ("disk",) * 4, z_spacing=0.5, solve_dtype="float64")
     films = list(device.films)
     placement = coupling = None
     if world > 1 and world <= len(films):

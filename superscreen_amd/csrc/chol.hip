@@ -423,14 +423,16 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (rc != SSA_OK) return rc;
     std::lock_guard<std::mutex> enqueue_lock(lane_set->enqueue);
     CholLane *lanes = lane_set->lanes;
-    // SSA_CHOL_UPD_STREAMS=1 (experiment): the trailing updates of matrix i go to a stream of their own instead of
-    // alternating on the caller's stream, so that the partially filled last round of tiles of one matrix'
-    // update overlaps the next update of another matrix
-    static const bool own_update_streams = [] {
+    // With three or more matrices the trailing updates of matrix i go to a stream of their own instead of
+    // alternating on the caller's stream: the partially filled last round of tiles of one update then overlaps
+    // the next update of another matrix, and a matrix' chain no longer waits behind the updates of all the
+    // others (4 x 30 301-vertex stack: 350 -> 317 ms; two matrices: no gain, 156.6 vs 158.7 ms, so they keep the
+    // single stream).  SSA_CHOL_UPD_STREAMS=0 / 1 forces either form.
+    static const int update_stream_mode = [] {
         const char *e = getenv("SSA_CHOL_UPD_STREAMS");
-        return e && atoi(e) != 0;
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    const bool split_updates = own_update_streams && count > 1;
+    const bool split_updates = (update_stream_mode < 0) ? count >= 3 : (update_stream_mode == 1 && count > 1);
     // outer steps (per matrix) that are chain bound: the last ~6k columns at this panel speed
     constexpr int64_t kTailCols = 6144;
     FinishPlan<T> plans[kMaxLanes];

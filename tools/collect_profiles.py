@@ -1,0 +1,155 @@
+"""Collects the rocprofv3 evidence behind bench.py's numbers on the GPU box and writes the summaries that
+get committed under profiles/ (run from the repo root on the box; development aid).
+
+    python tools/collect_profiles.py <tag> [out_dir]
+
+Passes (each `rocprofv3 ... -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`, counters in their own
+passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass):
+  stats   --kernel-trace --stats                      -> <tag>_bench_kernel_stats.csv, <tag>_bench.json
+  fetch   --pmc FETCH_SIZE --kernel-trace
+  write   --pmc WRITE_SIZE --kernel-trace             -> <tag>_syrk_pmc.json, <tag>_hbm_pmc.json
+  mfma    --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace
+                                                      -> <tag>_syrk_mfma_pmc.json
+and one plain `python3 bench.py` (no profiler)        -> <tag>_bench_full.json
+Corrections: counters in KiB; FETCH_SIZE x2 on gfx950 (half-count of wide reads); WRITE_SIZE exact.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SYRK = "gemm_op_kernel<double, 0, 1, true>"
+SIMDS, XCDS = 256 * 4, 8
+
+
+def run_pass(name, flags, out_dir, bench_args):
+    d = os.path.join(out_dir, name)
+    shutil.rmtree(d, ignore_errors=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", name, "--", "python3",
+           os.path.join(ROOT, "bench.py")] + bench_args
+    p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not line:
+        sys.stderr.write(p.stdout[-2000:] + p.stderr[-4000:])
+        raise SystemExit(f"pass {name} failed")
+    return d, json.loads(line[-1])
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", f"*{suffix}"), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[0]
+
+
+def rows(path):
+    with open(path) as f:
+        return list(csv.DictReader(f))
+
+
+def counter_per_kernel(path, counter, needle):
+    vals = [float(r["Counter_Value"]) for r in rows(path) if r["Counter_Name"] == counter and needle in r["Kernel_Name"]]
+    return vals
+
+
+def main():
+    tag = sys.argv[1]
+    out_dir = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "profiles_" + tag))
+    os.makedirs(out_dir, exist_ok=True)
+    prof = os.path.join(out_dir, "summaries")
+    os.makedirs(prof, exist_ok=True)
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+    d, line = run_pass("stats", ["--kernel-trace", "--stats"], out_dir, args)
+    shutil.copy(find(d, "kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
+    json.dump(line, open(os.path.join(prof, f"{tag}_bench.json"), "w"), indent=1)
+    stat = [r for r in rows(find(d, "kernel_stats.csv")) if SYRK in r["Name"]][0]
+    avg_us_stats = float(stat["AverageNs"]) * 1e-3
+    roof = line["roofline"]
+
+    df, _ = run_pass("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"], out_dir, args)
+    dw, _ = run_pass("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"], out_dir, args)
+    fcsv, wcsv = find(df, "counter_collection.csv"), find(dw, "counter_collection.csv")
+    f = counter_per_kernel(fcsv, "FETCH_SIZE", SYRK)
+    w = counter_per_kernel(wcsv, "WRITE_SIZE", SYRK)
+    fetch_b, write_b = 2.0 * sum(f) / len(f) * 1024.0, sum(w) / len(w) * 1024.0
+    json.dump({
+        "kernel_contains": SYRK,
+        "launches": {"fetch_pass": len(f), "write_pass": len(w)},
+        "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+        "traffic_bytes_per_launch": fetch_b + write_b,
+        "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+        "avg_launch_us": roof["avg_launch_us"], "avg_launch_gflop": roof["avg_launch_gflop"],
+        "avg_launch_us_rocprofv3_stats": avg_us_stats,
+        "note": "memory-side L2 traffic (Infinity-Cache hits are counted, MI355X_MICROARCH.md); fetch x2 (gfx950 "
+                "half-count of wide reads), counters in KiB; avg_launch_us / avg_launch_gflop: what bench.py measured "
+                "live with HIP events in the --kernel-trace --stats pass of the same command (rocprofv3's own average "
+                "for the kernel in that pass next to it); bench.py flags `traffic_stale` when its live averages move "
+                "more than 5 % away from these",
+    }, open(os.path.join(prof, f"{tag}_syrk_pmc.json"), "w"), indent=1)
+
+    # HBM-bound kernels from the same two passes
+    hbm = {}
+    wq = counter_per_kernel(wcsv, "WRITE_SIZE", "q_assemble_kernel<double")
+    tr = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+          for r in rows(find(dw, "kernel_trace.csv")) if "q_assemble_kernel<double" in r["Kernel_Name"]}
+    big = sorted(wq)[-5:] if wq else []
+    if big:
+        n = line["config"]["vertices_per_film"]
+        ids = [r["Dispatch_Id"] for r in rows(wcsv) if r["Counter_Name"] == "WRITE_SIZE" and "q_assemble_kernel<double" in
+               r["Kernel_Name"] and float(r["Counter_Value"]) >= big[0]]
+        secs = [tr[i] for i in ids if i in tr]
+        hbm["q_assemble_kernel (dense Q, bench extras)"] = {
+            "launches": len(big), "WRITE_SIZE_bytes_per_launch": sum(big) / len(big) * 1024.0,
+            "algorithmic_bytes": n * n * 8, "avg_ms": sum(secs) / max(1, len(secs)) * 1e3,
+            "HBM_write_TBps": (sum(big) / len(big) * 1024.0) / (sum(secs) / max(1, len(secs))) / 1e12 if secs else None}
+    fg = [(r["Dispatch_Id"], float(r["Counter_Value"])) for r in rows(fcsv)
+          if r["Counter_Name"] == "FETCH_SIZE" and "gemv_kernel<double, 4, true, 0>" in r["Kernel_Name"]]
+    tg = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+          for r in rows(find(df, "kernel_trace.csv")) if "gemv_kernel<double, 4, true, 0>" in r["Kernel_Name"]}
+    if fg:
+        tot_b = 2.0 * sum(v for _, v in fg) * 1024.0
+        tot_s = sum(tg[i] for i, _ in fg if i in tg)
+        hbm["gemv_kernel<double, 4, true, 0> (triangular-solve chain, all launches of the run)"] = {
+            "launches": len(fg), "FETCH_SIZE_bytes_total_x2": tot_b, "total_ms": tot_s * 1e3,
+            "HBM_read_TBps": tot_b / tot_s / 1e12 if tot_s else None}
+    hbm["note"] = ("rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                   "(dispatches serialized by the profiler); counters in KiB, FETCH x2 on gfx950")
+    json.dump(hbm, open(os.path.join(prof, f"{tag}_hbm_pmc.json"), "w"), indent=1)
+
+    dm, _ = run_pass("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64",
+                              "--kernel-trace"], out_dir, args)
+    per = {}
+    for r in rows(find(dm, "counter_collection.csv")):
+        if SYRK in r["Kernel_Name"]:
+            per.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+           for r in rows(find(dm, "kernel_trace.csv")) if SYRK in r["Kernel_Name"]}
+    sel = [(c, dur[i]) for i, c in per.items() if i in dur and len(c) >= 3]
+    busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"] for c, _ in sel)
+    gui = sum(c["GRBM_GUI_ACTIVE"] for c, _ in sel) / XCDS
+    mops = sum(c["SQ_INSTS_VALU_MFMA_MOPS_F64"] for c, _ in sel)
+    secs = sum(t for _, t in sel)
+    json.dump({
+        "kernel_contains": SYRK, "launches": len(sel), "avg_launch_us": secs / len(sel) * 1e6,
+        "effective_clock_GHz": gui / secs / 1e9, "mfma_busy_fraction_of_active_cycles": busy / (gui * SIMDS),
+        "fp64_mfma_flops_per_launch": mops * 512 / len(sel), "achieved_TFLOPs": mops * 512 / secs / 1e12,
+        "peak_at_effective_clock_TFLOPs": SIMDS * 32 * (gui / secs) / 1e12,
+        "note": "one v_mfma_f64_16x16x4_f64 = 2048 flop per 64 cycles per SIMD -> 32 flop/clk/SIMD; nominal peak 78.6 "
+                "TFLOP/s assumes 2.4 GHz; under FP64 MFMA load the chip holds a lower clock (DVFS)",
+    }, open(os.path.join(prof, f"{tag}_syrk_mfma_pmc.json"), "w"), indent=1)
+
+    p = subprocess.run(["python3", os.path.join(ROOT, "bench.py")], cwd=ROOT, capture_output=True, text=True)
+    full = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if full:
+        json.dump(json.loads(full[-1]), open(os.path.join(prof, f"{tag}_bench_full.json"), "w"), indent=1)
+    print("summaries in", prof, os.listdir(prof))
+
+
+if __name__ == "__main__":
+    main()
