@@ -163,7 +163,8 @@ def cpu_baseline(K: int, iterations: int, budget_s: float):
     n_probe = 6000
     probe = rng.standard_normal((n_probe, n_probe)) + n_probe * np.eye(n_probe)
     sweep = {}
-    for t in sorted({max(1, phys // 4), max(1, phys // 2), phys, logical}):
+    for t in sorted({max(1, phys // 16), max(1, phys // 8), max(1, phys // 4), max(1, 3 * phys // 8), max(1, phys // 2),
+                     phys, logical}):
         with threadpool_limits(limits=t):
             la.lu_factor(probe[:1000, :1000])
             t0 = time.perf_counter()

@@ -374,6 +374,29 @@ int ssa_fill_probe(void *dst, size_t bytes, void *stream);
  */
 int ssa_mfma_probe(int iters, void *sink, double *flops_out, void *stream);
 
+/*
+ * LU without row interchanges, with look-ahead, for a batch of matrices (the films of a device) -- the fast
+ * form of  lu_factor(-A)  solver/solve_film.py:279 for the matrices this solver actually meets: the London
+ * systems are strictly diagonally dominant by rows, LAPACK's partial pivoting never swaps (ipiv == arange).
+ * Same schedule as ssa_chol_factor_batch: 256-column panels factored on a side stream while the previous
+ * trailing update (one NN MFMA GEMM, K = 256 or 512) still runs, all matrices of the batch interleaved.
+ * The result is what ?getrf returns IF AND ONLY IF no multiplier exceeds 1 in magnitude (then the diagonal is
+ * the pivot LAPACK picks at every column, ties included); that condition is verified on the finished factor:
+ *   info[i] =  0   factors and ipiv (= arange) are LAPACK's, to rounding
+ *           = -2   a row interchange would have been needed (or a pivot block was singular): the buffer
+ *                  holds garbage; assemble the matrix again and call ssa_lu_factor (partial pivoting)
+ *   A[i]    [np, lda] dtype, np = ssa_lu_padded_n(n): the caller allocates np rows and lda >= np; rows and
+ *           columns n .. np-1 are overwritten with the identity before factoring (full MFMA tiles everywhere);
+ *           the leading n x n part of the result is the factorization of the n x n matrix
+ *   ipiv[i] [np] int32,  aux[i]: ssa_lu_aux_bytes(n)  (for ssa_lu_solve with the TRUE n),
+ *   workspace[i]: ssa_lu_factor_nopivot_workspace_bytes(n) each (distinct buffers).
+ */
+int64_t ssa_lu_padded_n(int64_t n);
+size_t ssa_lu_factor_nopivot_workspace_bytes(int64_t n, int dtype);
+int ssa_lu_factor_nopivot_batch(int count, void *const *A, const int64_t *n, const int64_t *lda,
+                                int32_t *const *ipiv, int32_t *const *info, void *const *aux, int dtype,
+                                void *const *workspace, const size_t *workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------- */
 /* (7) Inter-film coupling across GPUs: RCCL all-reduce of the coupling vector         */
 /* ---------------------------------------------------------------------------------- */

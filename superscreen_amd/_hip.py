@@ -48,6 +48,9 @@ SIGNATURES = {
     "ssa_lu_aux_bytes": (c_size_t, [I64, c_int]),
     "ssa_lu_factor": (c_int, [P, I64, I64, P, P, P, c_int, P, c_size_t, P]),
     "ssa_lu_pivots_to_permutation": (c_int, [P, I64, P]),
+    "ssa_lu_padded_n": (c_int64, [I64]),
+    "ssa_lu_factor_nopivot_workspace_bytes": (c_size_t, [I64, c_int]),
+    "ssa_lu_factor_nopivot_batch": (c_int, [c_int, P, P, P, P, P, P, c_int, P, P, P]),
     "ssa_lu_solve_workspace_bytes": (c_size_t, [I64, I64, c_int]),
     "ssa_lu_solve": (c_int, [P, I64, I64, P, P, I64, I64, c_int, P, c_size_t, P]),
     "ssa_gemv": (c_int, [P, I64, I64, I64, P, P, P, P, c_double, c_double, c_int, P]),

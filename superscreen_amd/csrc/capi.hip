@@ -5,6 +5,7 @@
 
 namespace ssa {
 int chol_shutdown();
+int lu_shutdown();
 }
 
 extern "C" int ssa_abi_version(void) { return SSA_ABI_VERSION; }
@@ -38,6 +39,7 @@ extern "C" int ssa_device_info(int *num_cus, size_t *hbm_bytes, char *arch_name,
 
 extern "C" int ssa_shutdown(void) {
     const int a = ssa::chol_shutdown();
+    const int c = ssa::lu_shutdown();
     const int b = ssa::profile_shutdown();
-    return a != SSA_OK ? a : b;
+    return a != SSA_OK ? a : (c != SSA_OK ? c : b);
 }

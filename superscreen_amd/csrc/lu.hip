@@ -24,6 +24,7 @@
 // i?amax does -- is what ?getf2 would produce.  Inter-workgroup hand-offs follow the CDNA4
 // recipe: sc1 payload stores, per-wave vmcnt(0) drain, relaxed agent-scope counter,
 // relaxed poll, sc1 loads; every spin is bounded.
+#include <mutex>
 #include <utility>
 
 #include "common.hpp"
@@ -803,6 +804,305 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
     }
     return rc;
 }
+// =========================================================================================
+// No-interchange route: LU with look-ahead for matrices whose partial pivoting never swaps rows
+// =========================================================================================
+// The London systems are strictly diagonally dominant by rows: LAPACK's ?getrf
+// returns ipiv == arange for them.  Without interchanges the factorization has the structure of the
+// Cholesky route (chol.hip) and takes the same schedule:
+//
+//   per matrix and 256-column panel k           chain (high-priority side stream)        update stream
+//   ------------------------------------------------------------------------------------------------------
+//   column strip  C[:, 0:256]  -= L21p U12p[:, 0:256]     (pending panels p, K = 256 / 512)
+//   row strip     C[0:256, 256:] -= L21p[0:256] U12p[:, 256:]
+//   diagonal block: 4 speculative 64-column sub-panels restricted to the block's 256 rows
+//                   (lu_panel_spec3_kernel + block trsm + in-block GEMM: the kernels of getrf above)
+//   WL = inv(L11), WU = inv(U11)                (LDS substitution kernels)
+//   L21 = A21 WU, U12 = WL A12                  (two in-place MFMA GEMMs each)
+//                                                                             rest  C[256:, 256:] -= L21p U12p
+//                                                                             (every other panel with K = 512
+//                                                                              for large trailing matrices)
+//
+// i.e. panel k + 1 is factored while the rest of update k runs (look-ahead), the matrices of a batch hide
+// each other's chains, and the trailing update is one NN GEMM.  What makes the result LAPACK's: partial
+// pivoting keeps the diagonal at column J iff no multiplier below it exceeds 1 in magnitude (|a_rJ| <=
+// |u_JJ|, ties go to the lowest index = the diagonal).  Inside a diagonal block the speculative kernel
+// checks exactly that; for the rows below a block the multipliers are the entries of L21, checked by one
+// pass over the finished factor (np_check_kernel).  Any violation (or a singular pivot block) is reported
+// as info = -2 and the caller factors the matrix again with ssa_lu_factor (full partial pivoting).
+constexpr int kMaxLuLanes = 16;
+struct LuLane {
+    hipStream_t side = nullptr, upd = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr;
+};
+struct LuLaneSet {
+    LuLane lanes[kMaxLuLanes];
+    std::mutex enqueue;
+};
+LuLaneSet g_lu_lane_sets[kMaxDevices];
+std::mutex g_lu_lane_mutex;
+
+inline int get_lu_lanes(int count, LuLaneSet **out) {
+    std::lock_guard<std::mutex> lock(g_lu_lane_mutex);
+    int dev = 0;
+    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
+    LuLane *lanes = g_lu_lane_sets[dev].lanes;
+    for (int i = 0; i < count; ++i) {
+        if (lanes[i].side != nullptr) continue;
+        if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_rest, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_upd, hipEventDisableTiming) != hipSuccess)
+            return SSA_ERR_HIP;
+    }
+    *out = &g_lu_lane_sets[dev];
+    return SSA_OK;
+}
+
+int lu_shutdown() {
+    std::lock_guard<std::mutex> lock(g_lu_lane_mutex);
+    int rc = SSA_OK;
+    for (int d = 0; d < kMaxDevices; ++d) {
+        std::lock_guard<std::mutex> enq(g_lu_lane_sets[d].enqueue);
+        for (LuLane &ln : g_lu_lane_sets[d].lanes) {
+            if (ln.side == nullptr) continue;
+            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
+            hipEvent_t evs[4] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd};
+            for (hipEvent_t e : evs)
+                if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
+            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
+            ln = LuLane{};
+        }
+    }
+    return rc;
+}
+
+template <typename T>
+struct NpScratch {
+    unsigned int *cnt, *timeout;
+    unsigned long long *hdr;
+    T *rows;
+    int *flags;       // [nsub] speculation flags | [nsub] zero columns
+    int64_t nsub;
+    T *backup, *dinv, *top, *WL, *WU;
+};
+inline size_t np_workspace_bytes(int64_t np, size_t es) {
+    const size_t nsub = static_cast<size_t>(np / PW);
+    return PanelScratchBytes::cnt + PanelScratchBytes::hdr + 2 * static_cast<size_t>(kMaxPanelGroups) * PW * es +
+           2 * nsub * sizeof(int) + static_cast<size_t>(NB) * PW * es + (NB / PW + 1) * 64 * 64 * es +
+           2 * static_cast<size_t>(NB) * NB * es + 16 * 256;
+}
+template <typename T>
+NpScratch<T> np_carve(void *workspace, int64_t np) {
+    Carver cv(workspace);
+    NpScratch<T> s;
+    s.cnt = cv.take<unsigned int>(kShards * 32 + 32);
+    s.timeout = s.cnt + kShards * 32;
+    s.hdr = cv.take<unsigned long long>(2 * kMaxPanelGroups * 2);
+    s.rows = cv.take<T>(2 * static_cast<size_t>(kMaxPanelGroups) * PW);
+    s.nsub = np / PW;
+    s.flags = cv.take<int>(2 * s.nsub);
+    s.backup = cv.take<T>(static_cast<size_t>(NB) * PW);
+    s.dinv = cv.take<T>(static_cast<size_t>(NB / PW) * 64 * 64);
+    s.top = cv.take<T>(64 * 64);
+    s.WL = cv.take<T>(static_cast<size_t>(NB) * NB);
+    s.WU = cv.take<T>(static_cast<size_t>(NB) * NB);
+    return s;
+}
+
+template <typename T>
+struct NpJob {
+    T *A;
+    int64_t n, np, lda;   // true order, padded order (multiple of NB), leading dimension (>= np)
+    int32_t *ipiv, *info;
+    T *aux;
+    void *workspace;
+};
+
+// rows n .. np-1 and columns n .. np-1 of the padded matrix: zero with a unit diagonal
+template <typename T>
+__global__ void np_pad_identity_kernel(T *A, int64_t lda, int64_t n, int64_t np) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (c >= np) return;
+    if (r >= n) A[r * lda + c] = (c == r) ? T(1) : T(0);
+    else if (c >= n) A[r * lda + c] = T(0);
+}
+
+// any |L_ij| > 1 below the diagonal (a row that LAPACK's partial pivoting would have moved up), or a raised
+// speculation flag -> info = -2 (unless a singular pivot was already reported)
+template <typename T>
+__global__ __launch_bounds__(256) void np_check_kernel(const T *__restrict__ A, int64_t lda, int64_t n,
+                                                       const int *__restrict__ flags, int64_t nflags,
+                                                       int32_t *__restrict__ info) {
+    bool bad = false;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 16;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int64_t i = r0 + rr;
+        if (i >= n) break;
+        for (int64_t j = threadIdx.x; j < i; j += 256) bad = bad || (fabs(static_cast<double>(A[i * lda + j])) > 1.0);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t k = threadIdx.x; k < nflags; k += 256) bad = bad || (flags[k] != 0);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMin(info, -2);
+}
+
+// One outer panel of one matrix on stream s: the 256 x 256 diagonal block at k0 (four speculative sub-panels
+// restricted to the block's rows), the inverses of its two factors, then L21 = A21 WU and U12 = WL A12 as
+// in-place MFMA GEMMs.  WU is upper and WL lower triangular: the second 128 columns of L21 need all 256
+// columns of A21 (done first), the first 128 only the first 128 -- every workgroup reads and writes its own
+// 128 rows, which makes the in-place product safe; U12 likewise by rows.
+template <typename T>
+int np_panel(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, hipStream_t s) {
+    T *A = J.A;
+    const int64_t lda = J.lda;
+    const int64_t kend = k0 + NB;
+    int rc;
+    for (int64_t j0 = k0; j0 < kend; j0 += PW) {
+        const int64_t sub = j0 / PW, sidx = (j0 - k0) / PW;
+        const int m = static_cast<int>(kend - j0);
+        Spec3Args<T> sa;
+        sa.A = A; sa.lda = lda; sa.j0 = j0; sa.m = m; sa.jb = PW;
+        sa.ipiv = J.ipiv; sa.backup = S.backup; sa.spec_flag = S.flags + sub; sa.zero_col = S.flags + S.nsub + sub;
+        sa.cnt = S.cnt; sa.dinv = S.dinv + sidx * 64 * 64; sa.top = S.top;
+        hipLaunchKernelGGL((lu_panel_spec3_kernel<T>), dim3(ceil_div(m, kSpec3Rows) + 1), dim3(256),
+                           spec3_smem_bytes<T>(), s, sa);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        // copies the parked diagonal block into A; if the speculation failed it pivots inside the block only --
+        // the flag stays raised and the whole factorization is reported as info = -2
+        PanelArgs<T> pa;
+        pa.A = A; pa.lda = lda; pa.j0 = j0; pa.m = m; pa.jb = PW; pa.rpw = m; pa.ipiv = J.ipiv; pa.info = J.info;
+        pa.cnt = S.cnt; pa.hdr = S.hdr; pa.rows = S.rows; pa.timeout = S.timeout;
+        pa.backup = S.backup; pa.spec_flag = S.flags + sub; pa.zero_col = S.flags + S.nsub + sub; pa.top = S.top;
+        hipLaunchKernelGGL((lu_panel_kernel<T>), dim3(1), dim3(kPanelThreads), panel_smem_bytes<T>(), s, pa);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        const int64_t wb = kend - (j0 + PW);
+        if (wb > 0) {
+            T *L11 = A + j0 * lda + j0;
+            T *U12 = A + j0 * lda + j0 + PW;
+            hipLaunchKernelGGL((trsm_lower_inv_kernel<T>), dim3(ceil_div(wb, 32)), dim3(256), trsm_inv_smem_bytes<T>(),
+                               s, L11, lda, S.dinv + sidx * 64 * 64, U12, lda, static_cast<int>(PW), wb);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+            rc = gemm_t<T>(wb, wb, PW, -1.0, A + (j0 + PW) * lda + j0, lda, U12, lda, 1.0,
+                           A + (j0 + PW) * lda + j0 + PW, lda, s);
+            if (rc != SSA_OK) return rc;
+        }
+    }
+    const int64_t M = J.np - kend;
+    if (M <= 0) return SSA_OK;
+    T *D = A + k0 * (lda + 1);
+    rc = launch_trsm<T, false, true>(D, lda, 0, S.WL, NB, 0, NB, NB, 1, s);
+    if (rc != SSA_OK) return rc;
+    rc = launch_trsm<T, true, true>(D, lda, 0, S.WU, NB, 0, NB, NB, 1, s);
+    if (rc != SSA_OK) return rc;
+    T *A21 = A + kend * lda + k0;
+    rc = gemm_t<T>(M, 128, 256, 1.0, A21, lda, S.WU + 128, NB, 0.0, A21 + 128, lda, s);
+    if (rc != SSA_OK) return rc;
+    rc = gemm_t<T>(M, 128, 128, 1.0, A21, lda, S.WU, NB, 0.0, A21, lda, s);
+    if (rc != SSA_OK) return rc;
+    T *A12 = A + k0 * lda + kend;
+    rc = gemm_t<T>(128, M, 256, 1.0, S.WL + 128 * NB, NB, A12, lda, 0.0, A12 + 128 * lda, lda, s);
+    if (rc != SSA_OK) return rc;
+    return gemm_t<T>(128, M, 128, 1.0, S.WL, NB, A12, lda, 0.0, A12, lda, s);
+}
+
+template <typename T>
+int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
+    if (count <= 0 || count > kMaxLuLanes) return SSA_ERR_INVALID_ARGUMENT;
+    static DeviceFlags lds_flags;
+    if (raise_dynamic_lds(lds_flags,
+                          {{reinterpret_cast<const void *>(&lu_panel_kernel<T>), panel_smem_bytes<T>()},
+                           {reinterpret_cast<const void *>(&lu_panel_spec3_kernel<T>), spec3_smem_bytes<T>()},
+                           {reinterpret_cast<const void *>(&trsm_lower_inv_kernel<T>), trsm_inv_smem_bytes<T>()}}) !=
+        SSA_OK)
+        return SSA_ERR_HIP;
+    LuLaneSet *lane_set = nullptr;
+    int rc = get_lu_lanes(count, &lane_set);
+    if (rc != SSA_OK) return rc;
+    std::lock_guard<std::mutex> enqueue_lock(lane_set->enqueue);
+    LuLane *lanes = lane_set->lanes;
+    NpScratch<T> scratch[kMaxLuLanes];
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const NpJob<T> &J = jobs[i];
+        LuLane &ln = lanes[i];
+        if (J.np % NB != 0 || J.lda < J.np || J.lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;
+        if (J.np > nmax) nmax = J.np;
+        scratch[i] = np_carve<T>(J.workspace, J.np);
+        if (J.np > J.n) {
+            hipLaunchKernelGGL((np_pad_identity_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.np, 256)),
+                                                                 static_cast<unsigned>(J.np)),
+                               dim3(256), 0, st, J.A, J.lda, J.n, J.np);
+            SSA_RETURN_IF_LAUNCH_FAILED();
+        }
+        if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess ||
+            hipMemsetAsync(scratch[i].flags, 0, 2 * scratch[i].nsub * sizeof(int), st) != hipSuccess)
+            return SSA_ERR_HIP;
+        if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_fork, 0) != hipSuccess ||
+            hipStreamWaitEvent(ln.upd, ln.ev_fork, 0) != hipSuccess)
+            return SSA_ERR_HIP;
+        rc = np_panel(J, scratch[i], 0, ln.side);
+        if (rc != SSA_OK) return rc;
+        if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+    }
+    constexpr int kDelayDepth = 2;            // as in the Cholesky schedule: two panels per trailing update
+    constexpr int64_t kDelayMinCols = 8192;   // while the trailing matrix is large
+    int64_t pending_from[kMaxLuLanes] = {};
+    bool rest_recorded[kMaxLuLanes] = {};
+    for (int64_t k0 = 0; k0 + NB < nmax; k0 += NB) {
+        for (int i = 0; i < count; ++i) {
+            const NpJob<T> &J = jobs[i];
+            LuLane &ln = lanes[i];
+            if (k0 + NB >= J.np) continue;
+            const int64_t right = J.np - k0 - NB;   // order of the trailing matrix (a multiple of NB)
+            const int64_t nw = NB;
+            const int64_t pend0 = pending_from[i], kp = k0 + NB - pend0;
+            const T *PL = J.A + (k0 + NB) * J.lda + pend0;   // pending L panels, rows of the trailing matrix
+            const T *PU = J.A + pend0 * J.lda + (k0 + NB);   // pending U panels, columns of the trailing matrix
+            T *C = J.A + (k0 + NB) * (J.lda + 1);
+            if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;   // panel k done
+            // the strips of the next panel need this matrix' last rest update (it wrote their entries)
+            if (rest_recorded[i] && hipStreamWaitEvent(ln.side, ln.ev_rest, 0) != hipSuccess) return SSA_ERR_HIP;
+            rc = gemm_t<T>(right, nw, kp, -1.0, PL, J.lda, PU, J.lda, 1.0, C, J.lda, ln.side);
+            if (rc != SSA_OK) return rc;
+            if (right > nw) {
+                rc = gemm_t<T>(nw, right - nw, kp, -1.0, PL, J.lda, PU + nw, J.lda, 1.0, C + nw, J.lda, ln.side);
+                if (rc != SSA_OK) return rc;
+            }
+            rc = np_panel(J, scratch[i], k0 + NB, ln.side);
+            if (rc != SSA_OK) return rc;
+            if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+            const bool delay = kp < kDelayDepth * NB && right > kDelayMinCols &&
+                               ((k0 + J.np) / NB) % kDelayDepth != kDelayDepth - 1;
+            if (right > nw && !delay) {
+                rc = gemm_t<T>(right - nw, right - nw, kp, -1.0, PL + nw * J.lda, J.lda, PU + nw, J.lda, 1.0,
+                               C + nw * (J.lda + 1), J.lda, ln.upd);
+                if (rc != SSA_OK) return rc;
+                if (hipEventRecord(ln.ev_rest, ln.upd) != hipSuccess) return SSA_ERR_HIP;
+                rest_recorded[i] = true;
+            }
+            if (!delay) pending_from[i] = k0 + NB;
+        }
+    }
+    for (int i = 0; i < count; ++i) {
+        const NpJob<T> &J = jobs[i];
+        LuLane &ln = lanes[i];
+        if (hipEventRecord(ln.ev_upd, ln.upd) != hipSuccess || hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess ||
+            hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess)
+            return SSA_ERR_HIP;
+        hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, st,
+                           J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
 // Inverses of `batch` non-unit lower triangular blocks (kb <= NB): block b is read at
 // Ablk + b * a_stride and its inverse written at out + b * o_stride with leading dimension ldo.
 int trtri_lower_batched_f64(const double *Ablk, int64_t lda, int64_t a_stride, int kb, double *out,
@@ -849,6 +1149,47 @@ extern "C" int ssa_lu_factor(void *A, int64_t n, int64_t lda, int32_t *ipiv, int
                              workspace, as_stream(stream));
     return getrf<float>(static_cast<float *>(A), n, lda, ipiv, info, static_cast<float *>(aux),
                         workspace, as_stream(stream));
+}
+
+extern "C" int64_t ssa_lu_padded_n(int64_t n) { return ceil_div(n, NB) * NB; }
+
+extern "C" size_t ssa_lu_factor_nopivot_workspace_bytes(int64_t n, int dtype) {
+    return np_workspace_bytes(ssa_lu_padded_n(n), dtype == SSA_F64 ? 8 : 4);
+}
+
+extern "C" int ssa_lu_factor_nopivot_batch(int count, void *const *A, const int64_t *n, const int64_t *lda,
+                                           int32_t *const *ipiv, int32_t *const *info, void *const *aux, int dtype,
+                                           void *const *workspace, const size_t *workspace_bytes, void *stream) {
+    if (count <= 0 || !A || !n || !lda || !ipiv || !info || !aux || !workspace || !workspace_bytes)
+        return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < count; ++i) {
+        if (!A[i] || !ipiv[i] || !info[i] || !aux[i] || n[i] <= 0 || lda[i] < ssa_lu_padded_n(n[i]))
+            return SSA_ERR_INVALID_ARGUMENT;
+        if (!workspace[i] || workspace_bytes[i] < ssa_lu_factor_nopivot_workspace_bytes(n[i], dtype))
+            return SSA_ERR_WORKSPACE_TOO_SMALL;
+    }
+    for (int first = 0; first < count; first += kMaxLuLanes) {
+        const int c = (count - first < kMaxLuLanes) ? count - first : kMaxLuLanes;
+        int rc;
+        if (dtype == SSA_F64) {
+            NpJob<double> jobs[kMaxLuLanes];
+            for (int i = 0; i < c; ++i)
+                jobs[i] = NpJob<double>{static_cast<double *>(A[first + i]), n[first + i], ssa_lu_padded_n(n[first + i]),
+                                        lda[first + i], ipiv[first + i], info[first + i],
+                                        static_cast<double *>(aux[first + i]), workspace[first + i]};
+            rc = getrf_np_batch<double>(jobs, c, as_stream(stream));
+        } else {
+            NpJob<float> jobs[kMaxLuLanes];
+            for (int i = 0; i < c; ++i)
+                jobs[i] = NpJob<float>{static_cast<float *>(A[first + i]), n[first + i], ssa_lu_padded_n(n[first + i]),
+                                       lda[first + i], ipiv[first + i], info[first + i],
+                                       static_cast<float *>(aux[first + i]), workspace[first + i]};
+            rc = getrf_np_batch<float>(jobs, c, as_stream(stream));
+        }
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
 }
 
 extern "C" int ssa_lu_pivots_to_permutation(const int32_t *ipiv_host, int64_t n,

@@ -241,6 +241,55 @@ def lu_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[LUFacto
     return out
 
 
+def lu_padded_n(n: int) -> int:
+    """Rows / minimum leading dimension of the buffer :func:`lu_factor_nopivot_batch` factors in place."""
+    return int(load_library().ssa_lu_padded_n(n))
+
+
+def lu_factor_nopivot_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[Optional[LUFactors]]:
+    """``scipy.linalg.lu_factor`` of several matrices whose partial pivoting never swaps rows (the London
+    systems: strictly diagonally dominant), in one look-ahead schedule (``ssa_lu_factor_nopivot_batch``).
+    ``systems``: ``(A [lu_padded_n(n), lda >= lu_padded_n(n)], n)``, factored in place.  An entry of the result
+    is ``None`` where LAPACK would have interchanged rows (the buffer is then garbage: assemble the matrix
+    again and use :func:`lu_factor`); otherwise the factors and ``ipiv == arange`` are LAPACK's to rounding."""
+    import ctypes
+
+    lib = load_library()
+    count = len(systems)
+    if count == 0:
+        return []
+    dev = systems[0][0].device
+    dt = dtype_code(systems[0][0].dtype)
+    items = []
+    for A, n in systems:
+        npad = lu_padded_n(n)
+        if A.shape[0] < npad or A.shape[1] < npad:
+            raise ValueError("lu_factor_nopivot_batch needs buffers padded to lu_padded_n(n) rows and columns.")
+        if dtype_code(A.dtype) != dt:
+            raise ValueError("lu_factor_nopivot_batch: all matrices must have the same dtype.")
+        ipiv = torch.empty(npad, dtype=torch.int32, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        aux = torch.empty(lib.ssa_lu_aux_bytes(n, dt) // A.element_size(), dtype=A.dtype, device=dev)
+        nbytes = lib.ssa_lu_factor_nopivot_workspace_bytes(n, dt)
+        items.append((A, n, ipiv, info, aux, _ws(nbytes, dev), nbytes))
+    PtrArr, I64Arr, SzArr = ctypes.c_void_p * count, ctypes.c_int64 * count, ctypes.c_size_t * count
+    check(lib.ssa_lu_factor_nopivot_batch(
+        count, PtrArr(*[it[0].data_ptr() for it in items]), I64Arr(*[it[1] for it in items]),
+        I64Arr(*[it[0].shape[1] for it in items]), PtrArr(*[it[2].data_ptr() for it in items]),
+        PtrArr(*[it[3].data_ptr() for it in items]), PtrArr(*[it[4].data_ptr() for it in items]), dt,
+        PtrArr(*[it[5].data_ptr() for it in items]), SzArr(*[it[6] for it in items]), current_stream()),
+        "ssa_lu_factor_nopivot_batch")
+    out: List[Optional[LUFactors]] = []
+    for A, n, ipiv, info, aux, ws, nbytes in items:
+        info_h = int(info.item())  # synchronises the stream
+        if info_h < 0:
+            out.append(None)
+            continue
+        out.append(LUFactors(lu=A, n=n, ipiv=ipiv[:n], perm=torch.arange(n, dtype=torch.int64, device=dev), aux=aux,
+                             info=info_h, dtype=A.dtype))
+    return out
+
+
 def lu_solve_permuted(f: LUFactors, B: torch.Tensor) -> torch.Tensor:
     """``scipy.linalg.lu_solve`` (solver/solve_film.py:530) on an already row-permuted rhs
     ``B [n] or [n, nrhs]`` (``B = h[perm]``); solved in place and returned."""

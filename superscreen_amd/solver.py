@@ -286,7 +286,7 @@ class LinearSystem:
                 return None
             self.factors = self._lu_factorize()
         f = self.factors
-        return f.lu[:, :f.n].cpu().numpy(), f.ipiv.cpu().numpy()
+        return f.lu[:f.n, :f.n].cpu().numpy(), f.ipiv[:f.n].cpu().numpy()
 
 
 @dataclass
@@ -392,8 +392,14 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             ix_d = torch.from_numpy(interior.astype(np.int64)).to(dev)
             ni = len(interior)
 
-            def lu_route(ix_d=ix_d, ni=ni, assemble=assemble, name=name, assemble_only=False, factors=None):
+            def lu_route(ix_d=ix_d, ni=ni, fd=fd, assemble=assemble, name=name, assemble_only=False, factors=None,
+                         padded=False):
                 if factors is None:
+                    if padded:   # buffer for the no-interchange route (kernels.lu_factor_nopivot_batch)
+                        npad = kernels.lu_padded_n(ni)
+                        return kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d,
+                                                       sign=-1.0, dtype=dtype, ld=kernels.padded_ld(npad, dtype),
+                                                       alloc_rows=npad), ni
                     minusA = assemble(ix_d, ix_d, -1.0)      # -A, written once, factored in place
                     if assemble_only:
                         return minusA, ni
@@ -433,8 +439,19 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     if method == "cholesky" and any(chols.get(k) is not None for k in lu_keys):
         bad = [k[0] for k in lu_keys if chols.get(k) is not None]
         raise RuntimeError(f"diag(w) A of film {bad[0]!r} is not positive definite.")
-    lu_inputs = {p[0]: p[5](assemble_only=True) for p in pending if p[0] in lu_keys}
-    lu_batch = dict(zip(lu_inputs, kernels.lu_factor_batch(list(lu_inputs.values())))) if lu_inputs else {}
+    # First the no-interchange route (look-ahead, one schedule for all films): it applies whenever LAPACK's
+    # partial pivoting would not swap rows, which is verified on the result; a film that fails the check is
+    # assembled again and goes through the pivoting route (one stream per film).
+    lu_batch = {}
+    if lu_keys:
+        routes = {p[0]: p[5] for p in pending}
+        fast = kernels.lu_factor_nopivot_batch([routes[k](padded=True) for k in lu_keys])
+        lu_batch = {k: f for k, f in zip(lu_keys, fast) if f is not None}
+        redo = [k for k in lu_keys if k not in lu_batch]
+        del fast
+        if redo:
+            logger.info(f"LU of {[k[0] for k in redo]}: row interchanges needed, factoring with partial pivoting.")
+            lu_batch.update(zip(redo, kernels.lu_factor_batch([routes[k](assemble_only=True) for k in redo])))
     for key, interior, ix_d, ni, S, lu_route, host_A, fd, grad_Lambda_term in pending:
         name, role = key
         system = None

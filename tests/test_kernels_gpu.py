@@ -594,3 +594,54 @@ def test_coupling_allreduce_c_abi_and_shutdown(K):
     for a, b in zip(base, again):
         for nm in device.films:
             assert np.array_equal(a.film_solutions[nm].stream, b.film_solutions[nm].stream)
+
+
+def _nopivot_buffer(K, A, dtype):
+    n = len(A)
+    npad = K.lu_padded_n(n)
+    ld = K.padded_ld(npad, dtype)
+    Ad = torch.full((npad, ld), float("nan"), dtype=getattr(torch, dtype), device="cuda")  # padding is set by the library
+    Ad[:n, :n] = dev(A.astype(dtype))
+    return Ad
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-3)])
+@pytest.mark.parametrize("n", [3, 64, 257, 1500, 4500, 9011])
+def test_lu_nopivot_matches_lapack_on_dominant_matrices(K, dtype, tol, n):
+    """The look-ahead route without interchanges (ssa_lu_factor_nopivot_batch) on row-diagonally-dominant,
+    NON-symmetric matrices: LAPACK's getrf returns ipiv == arange for them and the factors must agree."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + 1.0          # strictly dominant by rows ...
+    A = A * rng.uniform(0.5, 2.0, n)[None, :]                            # ... is not enough for |l| <= 1 by columns:
+    A[np.arange(n), np.arange(n)] = np.maximum(np.abs(A).sum(axis=0), np.abs(A).sum(axis=1)) + 1.0
+    A = A.astype(dtype)
+    lu_ref, piv_ref = la.lu_factor(A)
+    assert np.array_equal(piv_ref, np.arange(n))
+    f = K.lu_factor_nopivot_batch([(_nopivot_buffer(K, A, dtype), n)])[0]
+    assert f is not None and f.info == 0
+    assert np.array_equal(f.ipiv.cpu().numpy(), piv_ref)
+    assert relerr(f.lu.cpu().numpy()[:n, :n], lu_ref) < (1e-12 if dtype == "float64" else 1e-4)
+    for nrhs in (1, 5):
+        b = rng.standard_normal((n, nrhs)).astype(dtype)
+        x = K.lu_solve(f, dev(b[:, 0]) if nrhs == 1 else dev(b)).cpu().numpy().reshape(n, nrhs)
+        assert relerr(x, np.linalg.solve(A.astype(np.float64), b.astype(np.float64))) < tol
+
+
+def test_lu_nopivot_rejects_matrices_that_need_interchanges_and_batches_are_reproducible(K):
+    rng = np.random.default_rng(5)
+    n1, n2 = 700, 1300
+    general = rng.standard_normal((n1, n1))                              # LAPACK pivots here
+    dom = rng.standard_normal((n2, n2)) + 2.0 * n2 * np.eye(n2)
+    almost = dom.copy()
+    almost[900, 100] = 1.5 * almost[100, 100]                            # ONE multiplier above 1, far below the diagonal block
+    out = K.lu_factor_nopivot_batch([(_nopivot_buffer(K, general, "float64"), n1),
+                                     (_nopivot_buffer(K, dom, "float64"), n2),
+                                     (_nopivot_buffer(K, almost, "float64"), n2)])
+    assert out[0] is None and out[2] is None and out[1] is not None
+    assert not np.array_equal(la.lu_factor(almost)[1], np.arange(n2))    # LAPACK does swap rows for it
+    alone = K.lu_factor_nopivot_batch([(_nopivot_buffer(K, dom, "float64"), n2)])[0]
+    assert torch.equal(alone.lu[:n2, :n2], out[1].lu[:n2, :n2])         # a matrix' factor does not depend on its batch
+    singular = dom.copy()
+    singular[:, 300] = 0.0
+    assert K.lu_factor_nopivot_batch([(_nopivot_buffer(K, singular, "float64"), n2)])[0] is None

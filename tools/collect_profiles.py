@@ -1,7 +1,7 @@
 """Collects the rocprofv3 evidence behind bench.py's numbers on the GPU box and writes the summaries that
 get committed under profiles/ (run from the repo root on the box; development aid).
 
-    python tools/collect_profiles.py <tag> [out_dir]
+    python tools/collect_profiles.py <tag> [summary_dir]
 
 Passes (each `rocprofv3 ... -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`, counters in their own
 passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass):
@@ -59,10 +59,10 @@ def counter_per_kernel(path, counter, needle):
 
 def main():
     tag = sys.argv[1]
-    out_dir = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "profiles_" + tag))
-    os.makedirs(out_dir, exist_ok=True)
-    prof = os.path.join(out_dir, "summaries")
+    prof = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "profiles_" + tag))
     os.makedirs(prof, exist_ok=True)
+    out_dir = os.path.join("/tmp", "ssa_profiles_" + tag)   # raw rocprofv3 output (hundreds of MB) stays on the box
+    os.makedirs(out_dir, exist_ok=True)
     args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
 
     d, line = run_pass("stats", ["--kernel-trace", "--stats"], out_dir, args)
