@@ -28,6 +28,7 @@
 #include <utility>
 
 #include "common.hpp"
+#include "lu_diag.hpp"
 
 namespace ssa {
 
@@ -815,9 +816,8 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 //   ------------------------------------------------------------------------------------------------------
 //   column strip  C[:, 0:256]  -= L21p U12p[:, 0:256]     (pending panels p, K = 256 / 512)
 //   row strip     C[0:256, 256:] -= L21p[0:256] U12p[:, 256:]
-//   diagonal block: 4 speculative 64-column sub-panels restricted to the block's 256 rows
-//                   (lu_panel_spec3_kernel + block trsm + in-block GEMM: the kernels of getrf above)
-//   WL = inv(L11), WU = inv(U11)                (LDS substitution kernels)
+//   diagonal block: L11 \ U11 in place, WL = inv(L11), WU = inv(U11)    (lu_diag256_kernel, lu_diag.hpp:
+//                   one workgroup, 64-column Gaussian eliminations in registers + MFMA block products)
 //   L21 = A21 WU, U12 = WL A12                  (two in-place MFMA GEMMs each)
 //                                                                             rest  C[256:, 256:] -= L21p U12p
 //                                                                             (every other panel with K = 512
@@ -826,9 +826,8 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 // i.e. panel k + 1 is factored while the rest of update k runs (look-ahead), the matrices of a batch hide
 // each other's chains, and the trailing update is one NN GEMM.  What makes the result LAPACK's: partial
 // pivoting keeps the diagonal at column J iff no multiplier below it exceeds 1 in magnitude (|a_rJ| <=
-// |u_JJ|, ties go to the lowest index = the diagonal).  Inside a diagonal block the speculative kernel
-// checks exactly that; for the rows below a block the multipliers are the entries of L21, checked by one
-// pass over the finished factor (np_check_kernel).  Any violation (or a singular pivot block) is reported
+// |u_JJ|, ties go to the lowest index = the diagonal).  The multipliers are the entries of L: one pass over
+// the finished factor checks them (np_check_kernel).  Any violation (or a singular pivot block) is reported
 // as info = -2 and the caller factors the matrix again with ssa_lu_factor (full partial pivoting).
 constexpr int kMaxLuLanes = 16;
 struct LuLane {
@@ -888,13 +887,13 @@ struct NpScratch {
     T *rows;
     int *flags;       // [nsub] speculation flags | [nsub] zero columns
     int64_t nsub;
-    T *backup, *dinv, *top, *WL, *WU;
+    T *backup, *dinv, *top, *WL, *WU, *dscratch;
 };
 inline size_t np_workspace_bytes(int64_t np, size_t es) {
     const size_t nsub = static_cast<size_t>(np / PW);
     return PanelScratchBytes::cnt + PanelScratchBytes::hdr + 2 * static_cast<size_t>(kMaxPanelGroups) * PW * es +
            2 * nsub * sizeof(int) + static_cast<size_t>(NB) * PW * es + (NB / PW + 1) * 64 * 64 * es +
-           2 * static_cast<size_t>(NB) * NB * es + 16 * 256;
+           2 * static_cast<size_t>(NB) * NB * es + 6 * 64 * 64 * es + 16 * 256;
 }
 template <typename T>
 NpScratch<T> np_carve(void *workspace, int64_t np) {
@@ -911,6 +910,7 @@ NpScratch<T> np_carve(void *workspace, int64_t np) {
     s.top = cv.take<T>(64 * 64);
     s.WL = cv.take<T>(static_cast<size_t>(NB) * NB);
     s.WU = cv.take<T>(static_cast<size_t>(NB) * NB);
+    s.dscratch = cv.take<T>(6 * 64 * 64);
     return s;
 }
 
@@ -938,9 +938,10 @@ __global__ void np_pad_identity_kernel(T *A, int64_t lda, int64_t n, int64_t np)
 template <typename T>
 __global__ __launch_bounds__(256) void np_check_kernel(const T *__restrict__ A, int64_t lda, int64_t n,
                                                        const int *__restrict__ flags, int64_t nflags,
-                                                       int32_t *__restrict__ info) {
+                                                       int32_t *__restrict__ info, int32_t *__restrict__ ipiv) {
     bool bad = false;
     const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 16;
+    if (threadIdx.x < 16 && r0 + threadIdx.x < n) ipiv[r0 + threadIdx.x] = static_cast<int32_t>(r0 + threadIdx.x);
     for (int rr = 0; rr < 16; ++rr) {
         const int64_t i = r0 + rr;
         if (i >= n) break;
@@ -951,9 +952,8 @@ __global__ __launch_bounds__(256) void np_check_kernel(const T *__restrict__ A, 
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicMin(info, -2);
 }
 
-// One outer panel of one matrix on stream s: the 256 x 256 diagonal block at k0 (four speculative sub-panels
-// restricted to the block's rows), the inverses of its two factors, then L21 = A21 WU and U12 = WL A12 as
-// in-place MFMA GEMMs.  WU is upper and WL lower triangular: the second 128 columns of L21 need all 256
+// One outer panel of one matrix on stream s: the diagonal-block kernel (lu_diag.hpp: L11 \ U11 in place and the
+// inverses WL, WU of the two factors), then L21 = A21 WU and U12 = WL A12 as in-place MFMA GEMMs.  WU is upper and WL lower triangular: the second 128 columns of L21 need all 256
 // columns of A21 (done first), the first 128 only the first 128 -- every workgroup reads and writes its own
 // 128 rows, which makes the in-place product safe; U12 likewise by rows.
 template <typename T>
@@ -962,43 +962,12 @@ int np_panel(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, hipStream_t s
     const int64_t lda = J.lda;
     const int64_t kend = k0 + NB;
     int rc;
-    for (int64_t j0 = k0; j0 < kend; j0 += PW) {
-        const int64_t sub = j0 / PW, sidx = (j0 - k0) / PW;
-        const int m = static_cast<int>(kend - j0);
-        Spec3Args<T> sa;
-        sa.A = A; sa.lda = lda; sa.j0 = j0; sa.m = m; sa.jb = PW;
-        sa.ipiv = J.ipiv; sa.backup = S.backup; sa.spec_flag = S.flags + sub; sa.zero_col = S.flags + S.nsub + sub;
-        sa.cnt = S.cnt; sa.dinv = S.dinv + sidx * 64 * 64; sa.top = S.top;
-        hipLaunchKernelGGL((lu_panel_spec3_kernel<T>), dim3(ceil_div(m, kSpec3Rows) + 1), dim3(256),
-                           spec3_smem_bytes<T>(), s, sa);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-        // copies the parked diagonal block into A; if the speculation failed it pivots inside the block only --
-        // the flag stays raised and the whole factorization is reported as info = -2
-        PanelArgs<T> pa;
-        pa.A = A; pa.lda = lda; pa.j0 = j0; pa.m = m; pa.jb = PW; pa.rpw = m; pa.ipiv = J.ipiv; pa.info = J.info;
-        pa.cnt = S.cnt; pa.hdr = S.hdr; pa.rows = S.rows; pa.timeout = S.timeout;
-        pa.backup = S.backup; pa.spec_flag = S.flags + sub; pa.zero_col = S.flags + S.nsub + sub; pa.top = S.top;
-        hipLaunchKernelGGL((lu_panel_kernel<T>), dim3(1), dim3(kPanelThreads), panel_smem_bytes<T>(), s, pa);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-        const int64_t wb = kend - (j0 + PW);
-        if (wb > 0) {
-            T *L11 = A + j0 * lda + j0;
-            T *U12 = A + j0 * lda + j0 + PW;
-            hipLaunchKernelGGL((trsm_lower_inv_kernel<T>), dim3(ceil_div(wb, 32)), dim3(256), trsm_inv_smem_bytes<T>(),
-                               s, L11, lda, S.dinv + sidx * 64 * 64, U12, lda, static_cast<int>(PW), wb);
-            SSA_RETURN_IF_LAUNCH_FAILED();
-            rc = gemm_t<T>(wb, wb, PW, -1.0, A + (j0 + PW) * lda + j0, lda, U12, lda, 1.0,
-                           A + (j0 + PW) * lda + j0 + PW, lda, s);
-            if (rc != SSA_OK) return rc;
-        }
-    }
+    T *D = A + k0 * (lda + 1);
+    hipLaunchKernelGGL((luk::lu_diag256_kernel<T>), dim3(1), dim3(256), sizeof(luk::LuSmem<T>), s, D,
+                       static_cast<int>(lda), S.WL, S.WU, static_cast<int>(NB), S.dscratch, J.info);
+    SSA_RETURN_IF_LAUNCH_FAILED();
     const int64_t M = J.np - kend;
     if (M <= 0) return SSA_OK;
-    T *D = A + k0 * (lda + 1);
-    rc = launch_trsm<T, false, true>(D, lda, 0, S.WL, NB, 0, NB, NB, 1, s);
-    if (rc != SSA_OK) return rc;
-    rc = launch_trsm<T, true, true>(D, lda, 0, S.WU, NB, 0, NB, NB, 1, s);
-    if (rc != SSA_OK) return rc;
     T *A21 = A + kend * lda + k0;
     rc = gemm_t<T>(M, 128, 256, 1.0, A21, lda, S.WU + 128, NB, 0.0, A21 + 128, lda, s);
     if (rc != SSA_OK) return rc;
@@ -1014,11 +983,8 @@ template <typename T>
 int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLuLanes) return SSA_ERR_INVALID_ARGUMENT;
     static DeviceFlags lds_flags;
-    if (raise_dynamic_lds(lds_flags,
-                          {{reinterpret_cast<const void *>(&lu_panel_kernel<T>), panel_smem_bytes<T>()},
-                           {reinterpret_cast<const void *>(&lu_panel_spec3_kernel<T>), spec3_smem_bytes<T>()},
-                           {reinterpret_cast<const void *>(&trsm_lower_inv_kernel<T>), trsm_inv_smem_bytes<T>()}}) !=
-        SSA_OK)
+    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&luk::lu_diag256_kernel<T>),
+                                       sizeof(luk::LuSmem<T>)}}) != SSA_OK)
         return SSA_ERR_HIP;
     LuLaneSet *lane_set = nullptr;
     int rc = get_lu_lanes(count, &lane_set);
@@ -1030,7 +996,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     for (int i = 0; i < count; ++i) {
         const NpJob<T> &J = jobs[i];
         LuLane &ln = lanes[i];
-        if (J.np % NB != 0 || J.lda < J.np || J.lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;
+        if (J.np % NB != 0 || J.lda < J.np || J.lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets in the block kernel
         if (J.np > nmax) nmax = J.np;
         scratch[i] = np_carve<T>(J.workspace, J.np);
         if (J.np > J.n) {
@@ -1095,7 +1061,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess)
             return SSA_ERR_HIP;
         hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, st,
-                           J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info);
+                           J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info, J.ipiv);
         SSA_RETURN_IF_LAUNCH_FAILED();
         rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, st);
         if (rc != SSA_OK) return rc;

@@ -1,0 +1,292 @@
+// Diagonal-block kernel of the LU route without interchanges (lu.hip, getrf_np_batch): one workgroup factors
+// the 256 x 256 diagonal block D of an outer panel, D = L U (L unit lower, no pivoting), AND inverts both
+// factors, WL = L^-1, WU = U^-1, so that the rest of the panel is four in-place MFMA GEMMs
+// (L21 = A21 WU, U12 = WL A12).  The non-symmetric sibling of chol_diag256_kernel (chol_diag.hpp), built from
+// the same pieces -- loops with small bodies (the speculative sub-panel kernel of the pivoting route is
+// straight-line code that runs at instruction-fetch speed: 70 us alone, 460 us beside a trailing update),
+// rotating register arrays, MFMA block products with operands straight from L2:
+//
+//   for s = 0..3:  [L_ss \ U_ss, WL_ss] = ge64_lu(D_ss)      Gaussian elimination on [D_ss | I], registers,
+//                                                            one LDS hop + one barrier per column
+//                  WU_ss = I U_ss^-1,  L_is = D_is U_ss^-1   row-wise substitution against the static U_ss in
+//                                          (i > s)           LDS: NO barrier (every row is independent)
+//                  U_sj = WL_ss D_sj                (j > s)  MFMA
+//                  D_ij -= L_is U_sj             (i, j > s)  MFMA
+//   for d = 1..3:  WL_ij = -WL_ii sum_t L_it WL_tj  (i - j = d),   WU_ij = -WU_ii sum_t U_it WU_tj  (j - i = d)
+//
+// LAPACK's partial pivoting would keep every diagonal entry iff no multiplier exceeds 1 in magnitude; the
+// multipliers are the entries of L, which np_check_kernel inspects on the finished factor, so nothing is
+// checked here except an exactly zero pivot (reported through `bad`).
+#pragma once
+
+#include "chol_diag.hpp"
+
+namespace ssa {
+namespace luk {
+
+using cholk::opaque;
+using cholk::SB;
+using cholk::slab_gemm;
+using cholk::slab_load;
+using cholk::slab_store;
+using cholk::slab_zero;
+
+template <typename T>
+struct LuSmem {
+    T ra[2][4][16 + 2];   // row J of the D half   (slot k of residue q: column 4 (I0 + k) + q)
+    T mb[2][4][16 + 2];   // row J of the eliminated identity (absolute slot i: column 4 i + q)
+    T lout[64][64 + 1];   // the block on its way in; L \ U of the block on its way out; U for the substitutions
+    T wout[64][64 + 1];   // staging of results on their way out
+    T rdiag[64];          // 1 / u_JJ
+};
+
+// broadcast of lane (4 * (lane / 4) + S) inside every quad (DPP quad_perm), 64- and 32-bit payloads
+template <int S>
+__device__ __forceinline__ int quad_bcast_i32(int x) {
+    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
+    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
+}
+template <int S>
+__device__ __forceinline__ double quad_bcast(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = quad_bcast_i32<S>(static_cast<int>(b & 0xffffffffll));
+    const int hi = quad_bcast_i32<S>(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+template <int S>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(quad_bcast_i32<S>(__float_as_int(x)));
+}
+
+// the same with the lane as a (loop-unrolled, hence constant-folded) argument
+template <typename T>
+__device__ __forceinline__ T quad_bcast_s(T x, int S) {
+    switch (S) {
+        case 0: return quad_bcast<0>(x);
+        case 1: return quad_bcast<1>(x);
+        case 2: return quad_bcast<2>(x);
+        default: return quad_bcast<3>(x);
+    }
+}
+
+__device__ __forceinline__ double rcp_acc(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+__device__ __forceinline__ float rcp_acc(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+}
+
+// L \ U of the 64 x 64 block at D (overwritten, also left in sm.lout), WL = L^-1 (unit lower, full block with
+// zeros above the diagonal) to Wout, reciprocals of the pivots in sm.rdiag.  All 256 threads: thread (r, q)
+// holds columns q + 4 i of row r of [D | I].
+template <typename T>
+__device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T> &sm, bool &bad) {
+    const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
+    const int lane = t & 63, wave = t >> 6;
+    for (int rr = wave; rr < 64; rr += 4) sm.lout[rr][lane] = D[rr * ld + lane];
+    __syncthreads();
+    T a[16], m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        a[i] = sm.lout[r][q + 4 * i];
+        m[i] = (q + 4 * i == r) ? T(1) : T(0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int I0 = 0; I0 < 16; ++I0) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+            const int J = 4 * I0 + S;
+            const int par = S & 1;
+            if (r == J) {  // the four threads of row J publish it (D half: rotated slots, identity half: absolute)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sm.ra[par][q][k] = a[k];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm.mb[par][q][i] = m[i];
+            }
+            __syncthreads();
+            const T pv = sm.ra[par][S][0];
+            bad = bad || (pv == T(0));
+            const T acol = quad_bcast_s<T>(a[0], S);                 // this row's entry in column J
+            const T l = (r > J) ? acol * rcp_acc(pv) : T(0);    // multiplier
+            {   // slot 0 = column group I0: column 4 I0 + q is J iff q == S, right of J iff q > S
+                const T upd = a[0] - l * sm.ra[par][q][0];
+                a[0] = (q > S) ? upd : ((q == S && r > J) ? l : a[0]);
+            }
+#pragma unroll
+            for (int k = 1; k < 16; ++k) a[k] -= l * sm.ra[par][q][k];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] -= l * sm.mb[par][q][i];
+        }
+        sm.lout[r][4 * I0 + q] = a[0];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
+        a[15] = T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i];
+    __syncthreads();
+    if (t < 64) {
+        const T d = sm.lout[t][t];
+        sm.rdiag[t] = (d != T(0)) ? rcp_acc(d) : T(1);
+    }
+    for (int rr = wave; rr < 64; rr += 4) {
+        D[rr * ld + lane] = sm.lout[rr][lane];
+        Wout[rr * ldw + lane] = sm.wout[rr][lane];
+    }
+    __syncthreads();
+}
+
+// X = B U^-1 for the 64 x 64 upper triangular U in sm.lout (diagonal included; reciprocals in sm.rdiag) and a
+// 64-row block B: thread (r, q) owns columns q + 4 i of row r.  Column by column, x_J = b_J / u_JJ is passed
+// round the quad by DPP and the rest of the row updated with row J of U from LDS -- U does not change, so no
+// barrier is needed inside the loop.  B = identity if Bsrc == nullptr (X = U^-1).  X goes to Xdst (may alias Bsrc).
+template <typename T>
+__device__ __forceinline__ void trsm_right_upper64(const T *Bsrc, int ldb, T *Xdst, int ldx, LuSmem<T> &sm) {
+    const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
+    const int lane = t & 63, wave = t >> 6;
+    if (Bsrc != nullptr) {
+        for (int rr = wave; rr < 64; rr += 4) sm.wout[rr][lane] = Bsrc[rr * ldb + lane];
+        __syncthreads();
+    }
+    T b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = (Bsrc != nullptr) ? sm.wout[r][q + 4 * i] : ((q + 4 * i == r) ? T(1) : T(0));
+    __syncthreads();
+#pragma unroll 1
+    for (int I0 = 0; I0 < 16; ++I0) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+            const int J = 4 * I0 + S;
+            const T x = quad_bcast_s<T>(b[0], S) * sm.rdiag[J];
+            {
+                const T upd = b[0] - x * sm.lout[J][4 * I0 + q];
+                b[0] = (q > S) ? upd : ((q == S) ? x : b[0]);
+            }
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                const int c = 4 * (I0 + k) + q;                       // columns beyond the block: nothing to update
+                const T u = (c < 64) ? sm.lout[J][c < 64 ? c : 63] : T(0);
+                b[k] -= x * u;
+            }
+        }
+        sm.wout[r][4 * I0 + q] = b[0];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) b[k] = b[k + 1];
+        b[15] = T(0);
+    }
+    __syncthreads();
+    for (int rr = wave; rr < 64; rr += 4) Xdst[rr * ldx + lane] = sm.wout[rr][lane];
+    __syncthreads();
+}
+
+// D: the 256 x 256 diagonal block (leading dimension lda), overwritten with L \ U; WL, WU: the inverses of the
+// two factors (leading dimension ldw, full 256 x 256 with explicit zeros in the other triangle); scratch:
+// 6 * 64 * 64 elements; a zero pivot sets *info = -2 (the caller falls back to the pivoting route).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL, T *WU, int ldw, T *scratch,
+                                                            int32_t *info) {
+    extern __shared__ __attribute__((aligned(16))) char luk_smem_raw[];
+    LuSmem<T> &sm = *reinterpret_cast<LuSmem<T> *>(luk_smem_raw);
+    const int wave = threadIdx.x >> 6;
+    using acc_t = typename Mfma<T>::acc_t;
+    __builtin_amdgcn_s_setprio(3);
+    bool bad = false;
+    auto blk = [&](T *base, int ld, int bi, int bj) { return base + (bi * ld + bj) * SB; };
+
+    // the inverses are written block by block: start from zero (upper blocks of WL, lower blocks of WU)
+    for (int e = threadIdx.x; e < 256 * 256; e += 256) {
+        const int i = e >> 8, j = e & 255;
+        if ((i >> 6) < (j >> 6)) WL[i * ldw + j] = T(0);
+        if ((i >> 6) > (j >> 6)) WU[i * ldw + j] = T(0);
+    }
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        ge64_lu<T>(blk(D, lda, s, s), lda, blk(WL, ldw, s, s), ldw, sm, bad);
+        trsm_right_upper64<T>(nullptr, 0, blk(WU, ldw, s, s), ldw, sm);             // WU_ss = U_ss^-1
+#pragma unroll 1
+        for (int i = s + 1; i < 4; ++i)                                             // L_is = D_is U_ss^-1
+            trsm_right_upper64<T>(blk(D, lda, i, s), lda, blk(D, lda, i, s), lda, sm);
+        const int lane = opaque(threadIdx.x) & 63;
+        // U_sj = WL_ss D_sj: a slab of the result needs ALL rows of D_sj, so the four slabs of a block are
+        // computed (one per wave), then stored behind a barrier
+#pragma unroll 1
+        for (int j = s + 1; j < 4; ++j) {
+            acc_t acc[4];
+            slab_zero<T>(acc);
+            slab_gemm<T, false>(acc, blk(WL, ldw, s, s) + 16 * wave * ldw, ldw, blk(D, lda, s, j), lda, T(1), lane);
+            __syncthreads();
+            slab_store<T>(acc, blk(D, lda, s, j) + 16 * wave * lda, lda, lane);
+            __syncthreads();
+        }
+        // D_ij -= L_is U_sj
+        const int nb = 3 - s;
+#pragma unroll 1
+        for (int task = wave; task < nb * nb * 4; task += 4) {
+            const int p = task / 4, slab = task % 4;
+            const int i = s + 1 + p / nb, j = s + 1 + p % nb;
+            acc_t acc[4];
+            T *crow = blk(D, lda, i, j) + 16 * slab * lda;
+            slab_load<T>(acc, crow, lda, lane);
+            slab_gemm<T, false>(acc, blk(D, lda, i, s) + 16 * slab * lda, lda, blk(D, lda, s, j), lda, T(-1), lane);
+            slab_store<T>(acc, crow, lda, lane);
+        }
+        __syncthreads();
+    }
+    if (bad && threadIdx.x == 0) atomicMin(info, -2);
+
+    // off-diagonal blocks of WL = L^-1 (below) and WU = U^-1 (above the diagonal), by distance from it
+    T *scrL = scratch, *scrU = scratch + 3 * SB * SB;
+#pragma unroll 1
+    for (int d = 1; d < 4; ++d) {
+        const int npairs = 4 - d;
+        const int lane = opaque(threadIdx.x) & 63;
+#pragma unroll 1
+        for (int task = wave; task < 2 * npairs * 4; task += 4) {
+            const bool upper = task >= npairs * 4;
+            const int tt0 = upper ? task - npairs * 4 : task;
+            const int p = tt0 / 4, slab = tt0 % 4;
+            acc_t acc[4];
+            slab_zero<T>(acc);
+            if (!upper) {   // S_ij = sum_{t = j}^{i - 1} L_it WL_tj,   i = j + d
+                const int j = p, i = j + d;
+#pragma unroll 1
+                for (int tt = j; tt < i; ++tt)
+                    slab_gemm<T, false>(acc, blk(D, lda, i, tt) + 16 * slab * lda, lda, blk(WL, ldw, tt, j), ldw, T(1), lane);
+                slab_store<T>(acc, scrL + p * SB * SB + 16 * slab * SB, SB, lane);
+            } else {        // S_ij = sum_{t = i + 1}^{j} U_it WU_tj,   j = i + d
+                const int i = p, j = i + d;
+#pragma unroll 1
+                for (int tt = i + 1; tt <= j; ++tt)
+                    slab_gemm<T, false>(acc, blk(D, lda, i, tt) + 16 * slab * lda, lda, blk(WU, ldw, tt, j), ldw, T(1), lane);
+                slab_store<T>(acc, scrU + p * SB * SB + 16 * slab * SB, SB, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int task = wave; task < 2 * npairs * 4; task += 4) {
+            const bool upper = task >= npairs * 4;
+            const int tt0 = upper ? task - npairs * 4 : task;
+            const int p = tt0 / 4, slab = tt0 % 4;
+            acc_t acc[4];
+            slab_zero<T>(acc);
+            if (!upper) {   // WL_ij = -WL_ii S_ij
+                const int j = p, i = j + d;
+                slab_gemm<T, false>(acc, blk(WL, ldw, i, i) + 16 * slab * ldw, ldw, scrL + p * SB * SB, SB, T(-1), lane);
+                slab_store<T>(acc, blk(WL, ldw, i, j) + 16 * slab * ldw, ldw, lane);
+            } else {        // WU_ij = -WU_ii S_ij
+                const int i = p, j = i + d;
+                slab_gemm<T, false>(acc, blk(WU, ldw, i, i) + 16 * slab * ldw, ldw, scrU + p * SB * SB, SB, T(-1), lane);
+                slab_store<T>(acc, blk(WU, ldw, i, j) + 16 * slab * ldw, ldw, lane);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace luk
+}  // namespace ssa
