@@ -10,8 +10,6 @@
 //   K-MINOR  (m|n contiguous: A for op T, B for op N) [16][128 + 16]
 // so NT (SYRK: both operands are row panels of the same matrix) uses two K-MAJOR images and TN
 // (backward substitution with L^T on many right-hand sides) two K-MINOR images.
-#include <stdlib.h>
-
 #include "gemm_profile.hpp"
 #include "mfma_traits.hpp"
 
@@ -316,23 +314,8 @@ template <typename T, int TA, int TB, bool LOWER>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     int64_t M, int64_t N, int64_t K, T alpha, const T *__restrict__ A, int64_t lda,
     const T *__restrict__ B, int64_t ldb, T beta, T *__restrict__ C, int64_t ldc, int64_t ntm,
-    int64_t ntn, int aligned, int stagger_first, int stagger_ticks) {
+    int64_t ntn, int aligned) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // Phase stagger (see launch_op_l): of the two workgroups that share a CU in the first generation of
-    // the grid, the one whose LDS allocation does not start at 0 begins one tile-compute-time late.  Every
-    // later workgroup inherits the phase of the one whose slot it takes, so for the rest of the launch one
-    // partner moves its C tile (read at the start, written at the end of a tile) while the other has the
-    // SIMDs' matrix pipes to itself.  Unstaggered, all workgroups of the chip load, compute and store in
-    // lockstep: ~30 us of every tile round are a chip-wide burst of C traffic with idle matrix pipes
-    // (65 % of the MFMA rate at K = 256, 79 % at K = 512, independent of where in the tile C is read).
-    if (stagger_ticks > 0 && static_cast<int>(blockIdx.x) < stagger_first) {
-        unsigned lds_alloc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));
-        if ((lds_alloc & 0xfffu) != 0u) {  // LDS_BASE: the second workgroup placed on this CU
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < static_cast<unsigned long long>(stagger_ticks)) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     int64_t tm, tn;
     if constexpr (LOWER) {
         // Lower-triangular tile enumeration in bands of 8 tile rows, column by column inside a
@@ -406,29 +389,9 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
                                                                 : static_cast<double>(M) * N);
     ProfileScope scope(aligned && sizeof(T) == 8 && TA == OP_N && TB == OP_T, lower ? kProfileSyrkLower : kProfileOpNT,
                        flops, st);
-    // stagger: grids of more than one generation (two workgroups per CU are resident); the late partner
-    // waits one exclusive tile-compute time: K / 16 stages x 64 MFMAs x 64 cycles (f64) at ~2.2 GHz = 0.116 us
-    // per unit of K (float32: half), in ticks of the 100 MHz wall clock.  SSA_GEMM_STAGGER scales it (0 = off).
-    static const double stagger_scale = [] {
-        const char *e = getenv("SSA_GEMM_STAGGER");
-        return e ? atof(e) : 1.0;
-    }();
-    int num_cus = 256, dev = 0;
-    static int cus_of_device[kMaxDevices] = {};
-    if (current_device(&dev) == SSA_OK) {
-        if (cus_of_device[dev] == 0) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus_of_device[dev] = v;
-        }
-        if (cus_of_device[dev] > 0) num_cus = cus_of_device[dev];
-    }
-    const int stagger_first = 2 * num_cus;
-    int stagger_ticks = 0;
-    if (aligned && nwg > stagger_first && K >= 128)
-        stagger_ticks = static_cast<int>(stagger_scale * 11.6 * static_cast<double>(K) * (sizeof(T) == 8 ? 1.0 : 0.5));
     hipLaunchKernelGGL((gemm_op_kernel<T, TA, TB, LOWER>), dim3(static_cast<unsigned>(nwg)),
                        dim3(kGemmThreads), smem, st, M, N, K, static_cast<T>(alpha), A, lda, B, ldb,
-                       static_cast<T>(beta), C, ldc, ntm, ntn, aligned, stagger_first, stagger_ticks);
+                       static_cast<T>(beta), C, ldc, ntm, ntn, aligned);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }
