@@ -46,18 +46,19 @@ __device__ __forceinline__ float rsqrt_acc(float x) {
 }
 
 // LDS of ge64: column J of D (2 parities x 4 residues x 32 slots, slots 16..31 stay zero for the
-// rotated overrun).  A wave reads 4 distinct addresses per instruction (one per residue q), so the q stride
-// must not be a multiple of the 256-byte bank period: +2 elements of padding (unpadded, the 4-way conflict
-// cost 2x kernel time).
+// rotated overrun) and row J of the eliminated identity (2 x 4 x 16).  A wave reads 4 distinct
+// addresses per instruction (one per residue q), so the q stride must not be a multiple of the
+// 256-byte bank period: +2 elements of padding (unpadded, the 4-way conflict cost 2x kernel time).
 template <typename T>
 struct Ge64Smem {
     T cb[2][4][32 + 2];
-    T lout[64][64 + 1];  // the block on its way in, the finished columns of L on their way out; the
-                         // triangular factor the substitution pass reads
+    T mb[2][4][16 + 2];
+    T lout[64][64 + 1];  // the block on its way in, the finished columns of L on their way out
     T wout[64][64 + 1];  // W_ss on its way out
-    T rdiag[64];         // reciprocals of the diagonal of the factor
 };
 
+// [L, W] of the 64 x 64 block at D (leading dimension ld); L overwrites the lower triangle of D,
+// W (full block, zero above the diagonal) goes to Wout.  All 256 threads.
 __device__ __forceinline__ int opaque(int x) {
     // Hides the value from loop-invariant code motion: without it the compiler hoists every
     // per-lane constant of every phase (identity columns, row offsets) to the top of the kernel and
@@ -66,98 +67,6 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
-// broadcast of lane (4 * (lane / 4) + S) inside every quad (DPP quad_perm), 64- and 32-bit payloads
-template <int S>
-__device__ __forceinline__ int quad_bcast_i32(int x) {
-    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
-    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
-}
-template <int S>
-__device__ __forceinline__ double quad_bcast(double x) {
-    const long long b = __double_as_longlong(x);
-    const int lo = quad_bcast_i32<S>(static_cast<int>(b & 0xffffffffll));
-    const int hi = quad_bcast_i32<S>(static_cast<int>(b >> 32));
-    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
-}
-template <int S>
-__device__ __forceinline__ float quad_bcast(float x) {
-    return __int_as_float(quad_bcast_i32<S>(__float_as_int(x)));
-}
-// the same with the lane as a (loop-unrolled, hence constant-folded) argument
-template <typename T>
-__device__ __forceinline__ T quad_bcast_s(T x, int S) {
-    switch (S) {
-        case 0: return quad_bcast<0>(x);
-        case 1: return quad_bcast<1>(x);
-        case 2: return quad_bcast<2>(x);
-        default: return quad_bcast<3>(x);
-    }
-}
-
-// X = B U^-1 for a 64 x 64 upper triangular U held in LDS and a 64-row block B: thread (r, q) owns columns
-// q + 4 i of row r.  Column by column, x_J = b_J / u_JJ is passed round the quad by DPP and the rest of the
-// row is updated with row J of U from LDS.  U does not change, so there is NO barrier inside the loop (the
-// rows are independent): 64 steps of one DPP broadcast + 16 FMAs, against one LDS hop + one barrier per step
-// for an elimination that has to publish a pivot row.
-//   TRANS_U:   U(J, c) = tri[c][J]  (the transpose of a lower triangular factor stored in tri), else tri[J][c]
-//   UNIT:      unit diagonal (rdiag not read)
-//   TRANS_OUT: X^T is written instead of X
-//   Bsrc == nullptr: B = identity (X = U^-1).  Xdst may alias Bsrc.  `stage` is a 64 x 65 LDS tile.
-template <typename T, bool TRANS_U, bool UNIT, bool TRANS_OUT>
-__device__ __forceinline__ void trsm_right_upper64(const T *Bsrc, int ldb, T *Xdst, int ldx, const T (*tri)[64 + 1],
-                                                   const T *rdiag, T (*stage)[64 + 1]) {
-    const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
-    const int lane = t & 63, wave = t >> 6;
-    if (Bsrc != nullptr) {
-        for (int rr = wave; rr < 64; rr += 4) stage[rr][lane] = Bsrc[rr * ldb + lane];
-        __syncthreads();
-    }
-    T b[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) b[i] = (Bsrc != nullptr) ? stage[r][q + 4 * i] : ((q + 4 * i == r) ? T(1) : T(0));
-    __syncthreads();
-#pragma unroll 1
-    for (int I0 = 0; I0 < 16; ++I0) {
-#pragma unroll
-        for (int S = 0; S < 4; ++S) {
-            const int J = 4 * I0 + S;
-            T x = quad_bcast_s<T>(b[0], S);
-            if (!UNIT) x *= rdiag[J];
-            {
-                const int c = 4 * I0 + q;
-                const T upd = b[0] - x * (TRANS_U ? tri[c][J] : tri[J][c]);
-                b[0] = (q > S) ? upd : ((q == S) ? x : b[0]);
-            }
-#pragma unroll
-            for (int k = 1; k < 16; ++k) {
-                const int c = 4 * (I0 + k) + q;          // columns beyond the block: nothing to update
-                const int cc = c < 64 ? c : 63;
-                const T u = (c < 64) ? (TRANS_U ? tri[cc][J] : tri[J][cc]) : T(0);
-                b[k] -= x * u;
-            }
-        }
-        if (TRANS_OUT) stage[4 * I0 + q][r] = b[0];
-        else stage[r][4 * I0 + q] = b[0];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) b[k] = b[k + 1];
-        b[15] = T(0);
-    }
-    __syncthreads();
-    for (int rr = wave; rr < 64; rr += 4) Xdst[rr * ldx + lane] = stage[rr][lane];
-    __syncthreads();
-}
-
-// [L, W] of the 64 x 64 block at D (leading dimension ld); L overwrites the lower triangle of D,
-// W (full block, zero above the diagonal) goes to Wout.  All 256 threads.
-//
-// L: Gaussian elimination without pivoting on D alone (thread (r, q) holds columns q + 4 i of row r).  For a
-// symmetric positive definite block the multipliers are the Cholesky factor up to the column scaling
-// 1/sqrt(d_J), and by symmetry the pivot ROW a thread needs is the pivot COLUMN, which every row owner
-// publishes with one LDS store: one LDS hop and one barrier per column, 16 FMAs per thread.
-// W = L^-1 afterwards by the barrier-free substitution pass against L^T (trsm_right_upper64): carrying the
-// identity through the elimination instead ([D | I], as this kernel first did) costs another 16 FMAs and 16
-// LDS reads per column AND puts the 16 LDS stores of the published identity row on the critical path of
-// every column (34 -> ~2 x 10 us per block).
 template <typename T>
 __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T> &sm, bool &bad) {
     const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
@@ -169,10 +78,14 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
     for (int rr = wave; rr < 64; rr += 4) sm.lout[rr][lane] = D[rr * ld + lane];
     for (int e = t; e < 2 * 4 * (32 + 2); e += 256) (&sm.cb[0][0][0])[e] = T(0);
     __syncthreads();
-    T a[16];
+    T a[16], m[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = sm.lout[r][q + 4 * i];
+    for (int i = 0; i < 16; ++i) {
+        a[i] = sm.lout[r][q + 4 * i];
+        m[i] = (q + 4 * i == r) ? T(1) : T(0);
+    }
     __syncthreads();
+    T myinv = T(0);
 #pragma unroll 1
     for (int I0 = 0; I0 < 16; ++I0) {
 #pragma unroll
@@ -180,6 +93,10 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
             const int J = 4 * I0 + S;
             const int par = S & 1;
             if (q == S) sm.cb[par][r & 3][r >> 2] = a[0];  // column J (rows < J: stale, never read)
+            if (r == J) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm.mb[par][q][i] = m[i];
+            }
             __syncthreads();
             const T d = sm.cb[par][S][I0];
             bad = bad || !(d > T(0));
@@ -187,25 +104,33 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
             const T own = sm.cb[par][r & 3][r >> 2];
             const T lr = (r >= J) ? own * inv : T(0);  // l_rJ
             const T gmul = lr * inv;                   // a_rJ / d_J
-            if (t == 4 * J) sm.rdiag[J] = inv;         // 1 / l_JJ
+            const T f = (r > J) ? gmul : T(0);
+            myinv = (r == J) ? inv : myinv;
             {   // slot 0 = column group I0: column c = q + 4 I0 is J iff q == S, right of J iff q > S
                 const T upd = a[0] - gmul * sm.cb[par][q][I0];
                 a[0] = (q == S) ? ((r >= J) ? lr : a[0]) : ((q > S) ? upd : a[0]);
             }
+#ifndef GE_NO_A
 #pragma unroll
             for (int k = 1; k < 16; ++k) a[k] -= gmul * sm.cb[par][q][I0 + k];
+#endif
+#ifndef GE_NO_M
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] -= f * sm.mb[par][q][i];
+#endif
         }
         sm.lout[r][4 * I0 + q] = a[0];
 #pragma unroll
         for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
         a[15] = T(0);
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i] * myinv;
     __syncthreads();
     for (int rr = wave; rr < 64; rr += 4) {
         if (lane <= rr) D[rr * ld + lane] = sm.lout[rr][lane];
+        Wout[rr * ldw + lane] = sm.wout[rr][lane];
     }
-    // W = L^-1 = (U^-1)^T with U = L^T: rows of the identity against the static factor in LDS
-    trsm_right_upper64<T, true, false, true>(nullptr, 0, Wout, ldw, sm.lout, sm.rdiag, sm.wout);
 }
 
 // acc[jt] += sign * A_slab * op(B) for one 16-row slab (rows given by Arow, 64 columns = K) and the

@@ -6,10 +6,10 @@
 // straight-line code that runs at instruction-fetch speed: 70 us alone, 460 us beside a trailing update),
 // rotating register arrays, MFMA block products with operands straight from L2:
 //
-//   for s = 0..3:  L_ss \ U_ss = ge64_lu(D_ss)               Gaussian elimination in registers, one LDS hop +
-//                                                            one barrier per column
-//                  WL_ss = L_ss^-1, WU_ss = U_ss^-1,         row-wise substitutions against the static factors
-//                  L_is = D_is U_ss^-1           (i > s)     in LDS: NO barrier (every row is independent)
+//   for s = 0..3:  [L_ss \ U_ss, WL_ss] = ge64_lu(D_ss)      Gaussian elimination on [D_ss | I], registers,
+//                                                            one LDS hop + one barrier per column
+//                  WU_ss = I U_ss^-1,  L_is = D_is U_ss^-1   row-wise substitution against the static U_ss in
+//                                          (i > s)           LDS: NO barrier (every row is independent)
 //                  U_sj = WL_ss D_sj                (j > s)  MFMA
 //                  D_ij -= L_is U_sj             (i, j > s)  MFMA
 //   for d = 1..3:  WL_ij = -WL_ii sum_t L_it WL_tj  (i - j = d),   WU_ij = -WU_ii sum_t U_it WU_tj  (j - i = d)
@@ -25,8 +25,6 @@ namespace ssa {
 namespace luk {
 
 using cholk::opaque;
-using cholk::quad_bcast_s;
-using cholk::trsm_right_upper64;
 using cholk::SB;
 using cholk::slab_gemm;
 using cholk::slab_load;
@@ -35,11 +33,41 @@ using cholk::slab_zero;
 
 template <typename T>
 struct LuSmem {
-    T ra[2][4][16 + 2];   // row J on its way to the other rows (slot k of residue q: column 4 (I0 + k) + q)
+    T ra[2][4][16 + 2];   // row J of the D half   (slot k of residue q: column 4 (I0 + k) + q)
+    T mb[2][4][16 + 2];   // row J of the eliminated identity (absolute slot i: column 4 i + q)
     T lout[64][64 + 1];   // the block on its way in; L \ U of the block on its way out; U for the substitutions
     T wout[64][64 + 1];   // staging of results on their way out
     T rdiag[64];          // 1 / u_JJ
 };
+
+// broadcast of lane (4 * (lane / 4) + S) inside every quad (DPP quad_perm), 64- and 32-bit payloads
+template <int S>
+__device__ __forceinline__ int quad_bcast_i32(int x) {
+    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
+    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, true);
+}
+template <int S>
+__device__ __forceinline__ double quad_bcast(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = quad_bcast_i32<S>(static_cast<int>(b & 0xffffffffll));
+    const int hi = quad_bcast_i32<S>(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+template <int S>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(quad_bcast_i32<S>(__float_as_int(x)));
+}
+
+// the same with the lane as a (loop-unrolled, hence constant-folded) argument
+template <typename T>
+__device__ __forceinline__ T quad_bcast_s(T x, int S) {
+    switch (S) {
+        case 0: return quad_bcast<0>(x);
+        case 1: return quad_bcast<1>(x);
+        case 2: return quad_bcast<2>(x);
+        default: return quad_bcast<3>(x);
+    }
+}
 
 __device__ __forceinline__ double rcp_acc(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -54,18 +82,19 @@ __device__ __forceinline__ float rcp_acc(float x) {
 
 // L \ U of the 64 x 64 block at D (overwritten, also left in sm.lout), WL = L^-1 (unit lower, full block with
 // zeros above the diagonal) to Wout, reciprocals of the pivots in sm.rdiag.  All 256 threads: thread (r, q)
-// holds columns q + 4 i of row r.  Per column: the four owners of row J publish it (rotated slots: slot k of
-// residue q = column 4 (I0 + k) + q), one barrier, every row takes its own column-J entry from its quad by
-// DPP.  The inverse of L comes afterwards from the barrier-free substitution pass (chol_diag.hpp) against L^T.
+// holds columns q + 4 i of row r of [D | I].
 template <typename T>
 __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T> &sm, bool &bad) {
     const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
     const int lane = t & 63, wave = t >> 6;
     for (int rr = wave; rr < 64; rr += 4) sm.lout[rr][lane] = D[rr * ld + lane];
     __syncthreads();
-    T a[16];
+    T a[16], m[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = sm.lout[r][q + 4 * i];
+    for (int i = 0; i < 16; ++i) {
+        a[i] = sm.lout[r][q + 4 * i];
+        m[i] = (q + 4 * i == r) ? T(1) : T(0);
+    }
     __syncthreads();
 #pragma unroll 1
     for (int I0 = 0; I0 < 16; ++I0) {
@@ -73,14 +102,16 @@ __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T
         for (int S = 0; S < 4; ++S) {
             const int J = 4 * I0 + S;
             const int par = S & 1;
-            if (r == J) {
+            if (r == J) {  // the four threads of row J publish it (D half: rotated slots, identity half: absolute)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) sm.ra[par][q][k] = a[k];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm.mb[par][q][i] = m[i];
             }
             __syncthreads();
             const T pv = sm.ra[par][S][0];
             bad = bad || (pv == T(0));
-            const T acol = quad_bcast_s<T>(a[0], S);            // this row's entry in column J
+            const T acol = quad_bcast_s<T>(a[0], S);                 // this row's entry in column J
             const T l = (r > J) ? acol * rcp_acc(pv) : T(0);    // multiplier
             {   // slot 0 = column group I0: column 4 I0 + q is J iff q == S, right of J iff q > S
                 const T upd = a[0] - l * sm.ra[par][q][0];
@@ -88,20 +119,69 @@ __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T
             }
 #pragma unroll
             for (int k = 1; k < 16; ++k) a[k] -= l * sm.ra[par][q][k];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] -= l * sm.mb[par][q][i];
         }
         sm.lout[r][4 * I0 + q] = a[0];
 #pragma unroll
         for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
         a[15] = T(0);
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i];
     __syncthreads();
     if (t < 64) {
         const T d = sm.lout[t][t];
         sm.rdiag[t] = (d != T(0)) ? rcp_acc(d) : T(1);
     }
-    for (int rr = wave; rr < 64; rr += 4) D[rr * ld + lane] = sm.lout[rr][lane];
-    // WL = L^-1 = ((L^T)^-1)^T: identity rows against the unit upper triangular L^T in LDS
-    trsm_right_upper64<T, true, true, true>(nullptr, 0, Wout, ldw, sm.lout, sm.rdiag, sm.wout);
+    for (int rr = wave; rr < 64; rr += 4) {
+        D[rr * ld + lane] = sm.lout[rr][lane];
+        Wout[rr * ldw + lane] = sm.wout[rr][lane];
+    }
+    __syncthreads();
+}
+
+// X = B U^-1 for the 64 x 64 upper triangular U in sm.lout (diagonal included; reciprocals in sm.rdiag) and a
+// 64-row block B: thread (r, q) owns columns q + 4 i of row r.  Column by column, x_J = b_J / u_JJ is passed
+// round the quad by DPP and the rest of the row updated with row J of U from LDS -- U does not change, so no
+// barrier is needed inside the loop.  B = identity if Bsrc == nullptr (X = U^-1).  X goes to Xdst (may alias Bsrc).
+template <typename T>
+__device__ __forceinline__ void trsm_right_upper64(const T *Bsrc, int ldb, T *Xdst, int ldx, LuSmem<T> &sm) {
+    const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
+    const int lane = t & 63, wave = t >> 6;
+    if (Bsrc != nullptr) {
+        for (int rr = wave; rr < 64; rr += 4) sm.wout[rr][lane] = Bsrc[rr * ldb + lane];
+        __syncthreads();
+    }
+    T b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = (Bsrc != nullptr) ? sm.wout[r][q + 4 * i] : ((q + 4 * i == r) ? T(1) : T(0));
+    __syncthreads();
+#pragma unroll 1
+    for (int I0 = 0; I0 < 16; ++I0) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) {
+            const int J = 4 * I0 + S;
+            const T x = quad_bcast_s<T>(b[0], S) * sm.rdiag[J];
+            {
+                const T upd = b[0] - x * sm.lout[J][4 * I0 + q];
+                b[0] = (q > S) ? upd : ((q == S) ? x : b[0]);
+            }
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                const int c = 4 * (I0 + k) + q;                       // columns beyond the block: nothing to update
+                const T u = (c < 64) ? sm.lout[J][c < 64 ? c : 63] : T(0);
+                b[k] -= x * u;
+            }
+        }
+        sm.wout[r][4 * I0 + q] = b[0];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) b[k] = b[k + 1];
+        b[15] = T(0);
+    }
+    __syncthreads();
+    for (int rr = wave; rr < 64; rr += 4) Xdst[rr * ldx + lane] = sm.wout[rr][lane];
+    __syncthreads();
 }
 
 // D: the 256 x 256 diagonal block (leading dimension lda), overwritten with L \ U; WL, WU: the inverses of the
@@ -127,11 +207,10 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         ge64_lu<T>(blk(D, lda, s, s), lda, blk(WL, ldw, s, s), ldw, sm, bad);
-        trsm_right_upper64<T, false, false, false>(nullptr, 0, blk(WU, ldw, s, s), ldw, sm.lout, sm.rdiag, sm.wout);             // WU_ss = U_ss^-1
+        trsm_right_upper64<T>(nullptr, 0, blk(WU, ldw, s, s), ldw, sm);             // WU_ss = U_ss^-1
 #pragma unroll 1
         for (int i = s + 1; i < 4; ++i)                                             // L_is = D_is U_ss^-1
-            trsm_right_upper64<T, false, false, false>(blk(D, lda, i, s), lda, blk(D, lda, i, s), lda, sm.lout, sm.rdiag,
-                                                        sm.wout);
+            trsm_right_upper64<T>(blk(D, lda, i, s), lda, blk(D, lda, i, s), lda, sm);
         const int lane = opaque(threadIdx.x) & 63;
         // U_sj = WL_ss D_sj: a slab of the result needs ALL rows of D_sj, so the four slabs of a block are
         // computed (one per wave), then stored behind a barrier
