@@ -75,7 +75,15 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
     // the LDS tiles: partial-line accesses (this thread layout gives 32-byte pieces) and stores
     // inside the loop both put memory acknowledgements on the critical path, which a trailing
     // update streaming through the same L2 / HBM stretches to microseconds.
-    for (int rr = wave; rr < 64; rr += 4) sm.lout[rr][lane] = D[rr * ld + lane];
+    {   // all 16 row loads of a wave in flight at once: as a rolled loop the compiler waits for every load
+        // before it issues the next (16 dependent L2 / HBM round trips per block: 8 us alone, 40 us and more
+        // beside a trailing update that keeps the memory system busy)
+        T tmp[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) tmp[it] = D[(wave + 4 * it) * ld + lane];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) sm.lout[wave + 4 * it][lane] = tmp[it];
+    }
     for (int e = t; e < 2 * 4 * (32 + 2); e += 256) (&sm.cb[0][0][0])[e] = T(0);
     __syncthreads();
     T a[16], m[16];
@@ -127,7 +135,9 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
 #pragma unroll
     for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i] * myinv;
     __syncthreads();
-    for (int rr = wave; rr < 64; rr += 4) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = wave + 4 * it;
         if (lane <= rr) D[rr * ld + lane] = sm.lout[rr][lane];
         Wout[rr * ldw + lane] = sm.wout[rr][lane];
     }

@@ -87,7 +87,13 @@ template <typename T>
 __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T> &sm, bool &bad) {
     const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
     const int lane = t & 63, wave = t >> 6;
-    for (int rr = wave; rr < 64; rr += 4) sm.lout[rr][lane] = D[rr * ld + lane];
+    {   // all 16 row loads of a wave in flight at once (a rolled loop waits for every load in turn)
+        T tmp[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) tmp[it] = D[(wave + 4 * it) * ld + lane];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) sm.lout[wave + 4 * it][lane] = tmp[it];
+    }
     __syncthreads();
     T a[16], m[16];
 #pragma unroll
@@ -134,7 +140,9 @@ __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T
         const T d = sm.lout[t][t];
         sm.rdiag[t] = (d != T(0)) ? rcp_acc(d) : T(1);
     }
-    for (int rr = wave; rr < 64; rr += 4) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = wave + 4 * it;
         D[rr * ld + lane] = sm.lout[rr][lane];
         Wout[rr * ldw + lane] = sm.wout[rr][lane];
     }
@@ -150,7 +158,11 @@ __device__ __forceinline__ void trsm_right_upper64(const T *Bsrc, int ldb, T *Xd
     const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
     const int lane = t & 63, wave = t >> 6;
     if (Bsrc != nullptr) {
-        for (int rr = wave; rr < 64; rr += 4) sm.wout[rr][lane] = Bsrc[rr * ldb + lane];
+        T tmp[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) tmp[it] = Bsrc[(wave + 4 * it) * ldb + lane];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) sm.wout[wave + 4 * it][lane] = tmp[it];
         __syncthreads();
     }
     T b[16];
@@ -180,7 +192,8 @@ __device__ __forceinline__ void trsm_right_upper64(const T *Bsrc, int ldb, T *Xd
         b[15] = T(0);
     }
     __syncthreads();
-    for (int rr = wave; rr < 64; rr += 4) Xdst[rr * ldx + lane] = sm.wout[rr][lane];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) Xdst[(wave + 4 * it) * ldx + lane] = sm.wout[wave + 4 * it][lane];
     __syncthreads();
 }
 

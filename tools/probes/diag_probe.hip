@@ -75,7 +75,7 @@ int main() {
             int inf; hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
             if (rep == 2) {
                 printf("%s: total %.1f us (info %d)\n", mode == 0 ? "alone" : mode == 1 ? "beside SYRK" : mode == 4 ? "masked beside MFMA-only burn" : mode == 5 ? "masked beside HBM-only burn" : "masked beside masked SYRK", (t[18] - t[0]) * 0.01, inf);
-                if (mode <= 1) for (int i = 0; i < 18; ++i) printf("  %-6s %7.1f us\n", names[i], (t[i + 1] - t[i]) * 0.01);
+                if (mode <= 5) for (int i = 0; i < 18; ++i) printf("  %-6s %7.1f us\n", names[i], (t[i + 1] - t[i]) * 0.01);
             }
         }
     }
