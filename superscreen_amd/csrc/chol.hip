@@ -181,12 +181,20 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
     src += blockIdx.z * s_stride;
     dst += blockIdx.z * d_stride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int rr = w; rr < 64; rr += 4) {
-        const int64_t r = bi * 64 + rr, c = bj * 64 + lane;
-        tile[rr][lane] = (r < n && c < n) ? src[r * lds_ + c] : T(0);
+    {   // the 16 row loads of a wave in flight together (a rolled loop waits for each load before the next)
+        T tmp[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int64_t r = bi * 64 + w + 4 * it, c = bj * 64 + lane;
+            tmp[it] = (r < n && c < n) ? src[r * lds_ + c] : T(0);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) tile[w + 4 * it][lane] = tmp[it];
     }
     __syncthreads();
-    for (int rr = w; rr < 64; rr += 4) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = w + 4 * it;
         const int64_t r = bj * 64 + rr, c = bi * 64 + lane;  // destination element (r, c) = source (c, r)
         if (r < n && c < n && (!STRICT || c > r)) dst[r * ldd + c] = tile[lane][rr];
     }

@@ -570,13 +570,16 @@ int lu_block_inverse(const T *A, int64_t lda, int64_t r0, int64_t sz, T *inv, in
 }
 
 template <typename T>
-int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_t st) {
+int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_t st, bool leaves_done = false) {
     const LuAux al = lu_aux_layout(n);
     T *invL = aux + al.invL, *invU = aux + al.invU, *tmp = aux + al.tmp;
-    if (hipMemsetAsync(aux, 0, static_cast<size_t>(al.tmp) * sizeof(T), st) != hipSuccess) return SSA_ERR_HIP;
     int rc;
+    // leaves_done: the 256-leaves were written by the diagonal-block kernels of the no-interchange route
+    // (into a zeroed aux), as the Cholesky route does
+    if (!leaves_done && hipMemsetAsync(aux, 0, static_cast<size_t>(al.tmp) * sizeof(T), st) != hipSuccess)
+        return SSA_ERR_HIP;
     // leaves, batched by their position s inside the LSB block
-    for (int64_t s = 0; s < LSB / NB; ++s) {
+    for (int64_t s = 0; !leaves_done && s < LSB / NB; ++s) {
         const int64_t first = s * NB;
         if (first + NB > n) break;
         const int count = static_cast<int>((n - first - NB) / LSB + 1);
@@ -587,7 +590,7 @@ int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_
                                         LSB * LSB, NB, NB, count, st);
         if (rc != SSA_OK) return rc;
     }
-    if (n % NB != 0) {  // the last, partial leaf
+    if (!leaves_done && n % NB != 0) {  // the last, partial leaf
         const int64_t r0 = n / NB * NB, Jb = r0 / LSB, off = r0 - Jb * LSB;
         const int kb = static_cast<int>(n - r0);
         rc = launch_trsm<T, false, true>(A + r0 * (lda + 1), lda, 0, invL + Jb * LSB * LSB + off * (LSB + 1), LSB, 0,
@@ -963,20 +966,25 @@ int np_panel(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, hipStream_t s
     const int64_t kend = k0 + NB;
     int rc;
     T *D = A + k0 * (lda + 1);
+    // WL, WU land in the solve-phase buffer: they are the inverted 256-leaves of the LSB block inverses
+    const LuAux al = lu_aux_layout(J.n);
+    const int64_t leaf = (k0 / LSB) * LSB * LSB + (k0 % LSB) * (LSB + 1);
+    T *WL = J.aux + al.invL + leaf, *WU = J.aux + al.invU + leaf;
+    const int64_t ldw = LSB;
     hipLaunchKernelGGL((luk::lu_diag256_kernel<T>), dim3(1), dim3(256), sizeof(luk::LuSmem<T>), s, D,
-                       static_cast<int>(lda), S.WL, S.WU, static_cast<int>(NB), S.dscratch, J.info);
+                       static_cast<int>(lda), WL, WU, static_cast<int>(ldw), S.dscratch, J.info);
     SSA_RETURN_IF_LAUNCH_FAILED();
     const int64_t M = J.np - kend;
     if (M <= 0) return SSA_OK;
     T *A21 = A + kend * lda + k0;
-    rc = gemm_t<T>(M, 128, 256, 1.0, A21, lda, S.WU + 128, NB, 0.0, A21 + 128, lda, s);
+    rc = gemm_t<T>(M, 128, 256, 1.0, A21, lda, WU + 128, ldw, 0.0, A21 + 128, lda, s);
     if (rc != SSA_OK) return rc;
-    rc = gemm_t<T>(M, 128, 128, 1.0, A21, lda, S.WU, NB, 0.0, A21, lda, s);
+    rc = gemm_t<T>(M, 128, 128, 1.0, A21, lda, WU, ldw, 0.0, A21, lda, s);
     if (rc != SSA_OK) return rc;
     T *A12 = A + k0 * lda + kend;
-    rc = gemm_t<T>(128, M, 256, 1.0, S.WL + 128 * NB, NB, A12, lda, 0.0, A12 + 128 * lda, lda, s);
+    rc = gemm_t<T>(128, M, 256, 1.0, WL + 128 * ldw, ldw, A12, lda, 0.0, A12 + 128 * lda, lda, s);
     if (rc != SSA_OK) return rc;
-    return gemm_t<T>(128, M, 128, 1.0, S.WL, NB, A12, lda, 0.0, A12, lda, s);
+    return gemm_t<T>(128, M, 128, 1.0, WL, ldw, A12, lda, 0.0, A12, lda, s);
 }
 
 template <typename T>
@@ -1006,7 +1014,8 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             SSA_RETURN_IF_LAUNCH_FAILED();
         }
         if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess ||
-            hipMemsetAsync(scratch[i].flags, 0, 2 * scratch[i].nsub * sizeof(int), st) != hipSuccess)
+            hipMemsetAsync(scratch[i].flags, 0, 2 * scratch[i].nsub * sizeof(int), st) != hipSuccess ||
+            hipMemsetAsync(J.aux, 0, static_cast<size_t>(lu_aux_layout(J.n).tmp) * sizeof(T), st) != hipSuccess)
             return SSA_ERR_HIP;
         if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_fork, 0) != hipSuccess ||
             hipStreamWaitEvent(ln.upd, ln.ev_fork, 0) != hipSuccess)
@@ -1063,7 +1072,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
         hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, st,
                            J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info, J.ipiv);
         SSA_RETURN_IF_LAUNCH_FAILED();
-        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, st);
+        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, st, true);
         if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
