@@ -1063,17 +1063,19 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             if (!delay) pending_from[i] = k0 + NB;
         }
     }
+    // Every matrix finishes on its own update stream (behind its last panel and its last trailing update): the
+    // pivot check and the solve-phase blocks of one matrix overlap the tail of the others
     for (int i = 0; i < count; ++i) {
         const NpJob<T> &J = jobs[i];
         LuLane &ln = lanes[i];
-        if (hipEventRecord(ln.ev_upd, ln.upd) != hipSuccess || hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess ||
-            hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess)
-            return SSA_ERR_HIP;
-        hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, st,
+        if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+        hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, ln.upd,
                            J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info, J.ipiv);
         SSA_RETURN_IF_LAUNCH_FAILED();
-        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, st, true);
+        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, ln.upd, true);
         if (rc != SSA_OK) return rc;
+        if (hipEventRecord(ln.ev_upd, ln.upd) != hipSuccess || hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess)
+            return SSA_ERR_HIP;
     }
     return SSA_OK;
 }
