@@ -116,6 +116,93 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense Q, band form (ssa_q_assemble_dense).  What limits a multi-GB store stream on MI355X is how many
+// separate address streams the chip has in flight: ONE 256-thread workgroup per CU, all CUs writing 4 KiB
+// pieces of one compact window that sweeps the buffer, fills at 6.3-6.4 TB/s (rocclr's fill kernel has that
+// shape); the same bytes written by 1 800 resident workgroups x 16 matrix rows each reach 5.5 TB/s with
+// nothing to compute (tools/probes/store_probe.hip).  So: a workgroup owns a BAND of columns (2 per lane for
+// float64, 4 for float32: one 16-byte store per lane and row, 4 KiB per workgroup and row) whose coordinates
+// and weights stay in registers for the whole launch, and walks down the rows; with G = floor(CUs / bands)
+// workgroups per band taking rows g, g + G, ..., the chip writes G whole consecutive rows per step.  Row
+// coordinates are scalar loads, U rows ahead.  The row sums of the diagonal are wave-reduced per (row, band,
+// wave) into a workspace and finished by q_diag_finish_kernel in a fixed order (no atomics: Q_ii must not
+// depend on the order in which workgroups finish).
+// ---------------------------------------------------------------------------------------
+template <typename OutT>
+struct BandCols {
+    static constexpr int value = 16 / sizeof(OutT);  // columns per lane: one 16-byte store
+};
+
+template <typename OutT, int U>
+__global__ __launch_bounds__(kAsmThreads) void q_band_kernel(const double *__restrict__ xy, const double *__restrict__ w,
+                                                             int64_t n, OutT *__restrict__ Q, int64_t ldq,
+                                                             double *__restrict__ partial, int bands, int groups) {
+    constexpr int CPL = BandCols<OutT>::value;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int band = blockIdx.x % bands, g = blockIdx.x / bands;
+    const int64_t j0 = (static_cast<int64_t>(band) * kAsmThreads + tid) * CPL;   // first column of this lane
+    double xj[CPL], yj[CPL], wj[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const bool ok = j0 + c < n;
+        xj[c] = ok ? xy[2 * (j0 + c)] : 0.0;
+        yj[c] = ok ? xy[2 * (j0 + c) + 1] : 0.0;
+        wj[c] = ok ? w[j0 + c] : 0.0;
+    }
+    const bool store_ok = j0 < ldq;   // ldq is a multiple of CPL (16-byte rows): a lane is in or out as a whole
+    const int pstride = bands * (kAsmThreads / kWave);
+    for (int64_t r0 = g; r0 < n; r0 += static_cast<int64_t>(groups) * U) {
+        double xi[U], yi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // workgroup-uniform: scalar loads, all U rows in flight
+            const int64_t i = r0 + static_cast<int64_t>(u) * groups;
+            const int64_t ic = i < n ? i : n - 1;
+            xi[u] = xy[2 * ic];
+            yi[u] = xy[2 * ic + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = r0 + static_cast<int64_t>(u) * groups;
+            if (i < n) {   // uniform
+                double acc = 0.0;
+                OutT v[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const double dx = xi[u] - xj[c], dy = yi[u] - yj[c];
+                    double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
+                    q = (i == j0 + c || j0 + c >= n) ? 0.0 : q;   // distance.py:104-105; padding columns
+                    acc = __builtin_fma(q, wj[c], acc);
+                    v[c] = static_cast<OutT>(-q);
+                }
+                if (store_ok) {
+                    typedef OutT vec_t __attribute__((ext_vector_type(CPL)));
+                    vec_t pack;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) pack[c] = v[c];
+                    *reinterpret_cast<vec_t *>(Q + i * ldq + j0) = pack;
+                }
+                const double s = wave_sum(acc);
+                if (lane == 0) partial[i * pstride + band * (kAsmThreads / kWave) + wave] = s;
+            }
+        }
+    }
+}
+
+// Q_ii = (C_i + sum_l q_il w_l) / w_i from the per-(band, wave) partial row sums, in a fixed order
+template <typename OutT>
+__global__ void q_diag_finish_kernel(const double *__restrict__ partial, int pstride, const double *__restrict__ C,
+                                     const double *__restrict__ w, int64_t n, OutT *__restrict__ Q, int64_t ldq,
+                                     double *__restrict__ qdiag) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < pstride; ++p) s += partial[i * pstride + p];
+    const double d = (C[i] + s) / w[i];  // device/mesh.py:455-457
+    if (qdiag != nullptr) qdiag[i] = d;
+    Q[i * ldq + i] = static_cast<OutT>(d);
+}
+
 // Number of workgroups for n rows: a whole number of rounds of the kernel's resident slots on this device
 // (every CU then holds the same number of equally long workgroups), plain ceil(n / TR) strips for small n.
 template <typename Kernel>
@@ -260,6 +347,63 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
         const dim3 grid(static_cast<unsigned>(balanced_groups(q_assemble_kernel<float, kStripRows>, n, kStripRows)));
         hipLaunchKernelGGL((q_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads), 0,
                            as_stream(stream), xy, w, C, n, static_cast<float *>(Q), ldq, qdiag);
+    }
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+
+namespace ssa {
+namespace {
+inline int q_dense_bands(int64_t n, int dtype) {
+    const int cols = kAsmThreads * (dtype == SSA_F64 ? BandCols<double>::value : BandCols<float>::value);
+    return static_cast<int>(ceil_div(n, cols));
+}
+}  // namespace
+}  // namespace ssa
+
+extern "C" size_t ssa_q_assemble_dense_workspace_bytes(int64_t n, int dtype) {
+    if (n <= 0) return 256;
+    return static_cast<size_t>(n) * q_dense_bands(n, dtype) * (kAsmThreads / kWave) * sizeof(double) + 256;
+}
+
+extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const double *C, int64_t n, void *Q,
+                                    int64_t ldq, int dtype, double *qdiag, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    if (n <= 0 || !xy || !w || !C || !Q) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    const int cpl = (dtype == SSA_F64) ? BandCols<double>::value : BandCols<float>::value;
+    if (ldq < n || ldq % cpl != 0 || reinterpret_cast<uintptr_t>(Q) % 16 != 0) return SSA_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < ssa_q_assemble_dense_workspace_bytes(n, dtype)) return SSA_ERR_WORKSPACE_TOO_SMALL;
+    int dev = 0, cus = 256;
+    static int cus_of_device[kMaxDevices] = {};
+    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
+    if (cus_of_device[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return SSA_ERR_HIP;
+        cus_of_device[dev] = v;
+    }
+    cus = cus_of_device[dev];
+    const int bands = q_dense_bands(n, dtype);
+    int groups = cus / bands;   // one workgroup per CU: `groups` whole rows are written per step
+    if (groups < 1) groups = 1;
+    if (groups > n) groups = static_cast<int>(n);
+    double *partial = static_cast<double *>(workspace);
+    const int pstride = bands * (kAsmThreads / kWave);
+    const dim3 grid(static_cast<unsigned>(bands * groups));
+    hipStream_t st = as_stream(stream);
+    constexpr int U = 4;
+    if (dtype == SSA_F64) {
+        hipLaunchKernelGGL((q_band_kernel<double, U>), grid, dim3(kAsmThreads), 0, st, xy, w, n,
+                           static_cast<double *>(Q), ldq, partial, bands, groups);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        hipLaunchKernelGGL((q_diag_finish_kernel<double>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
+                           partial, pstride, C, w, n, static_cast<double *>(Q), ldq, qdiag);
+    } else {
+        hipLaunchKernelGGL((q_band_kernel<float, U>), grid, dim3(kAsmThreads), 0, st, xy, w, n,
+                           static_cast<float *>(Q), ldq, partial, bands, groups);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        hipLaunchKernelGGL((q_diag_finish_kernel<float>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
+                           partial, pstride, C, w, n, static_cast<float *>(Q), ldq, qdiag);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;

@@ -96,6 +96,27 @@ __global__ void fill_oneshot16(u32x4 *__restrict__ dst, size_t count16) {
     }
 }
 
+// one matrix row at a time per workgroup: workgroup b owns rows b, b + G, ...; all its threads sweep the row
+template <int FORM>
+__global__ void fill_rows_seq16(u32x4 *__restrict__ dst, size_t n_rows, size_t row16) {
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t r = blockIdx.x; r < n_rows; r += gridDim.x)
+        for (size_t c = threadIdx.x; c < row16; c += blockDim.x) store16<FORM>(dst + r * row16 + c, v);
+}
+// TR rows at a time, but each WAVE writes one row (4 KiB contiguous per wave and step: 4 stores per lane)
+template <int FORM>
+__global__ void fill_wave_rows16(u32x4 *__restrict__ dst, size_t n_rows, size_t row16) {
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (size_t r = static_cast<size_t>(blockIdx.x) * nw + wave; r < n_rows; r += static_cast<size_t>(gridDim.x) * nw)
+        for (size_t c0 = 0; c0 < row16; c0 += 256)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t c = c0 + 64 * k + lane;
+                if (c < row16) store16<FORM>(dst + r * row16 + c, v);
+            }
+}
+
 template <typename F>
 double time_ms(F launch, int reps = 7) {
     hipEvent_t a, b;
@@ -183,6 +204,25 @@ int main(int argc, char **argv) {
         char nm[128];
         snprintf(nm, sizeof nm, "grid-stride 16B plain, %d WG x 256", wgs);
         report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(wgs), dim3(256), 0, 0, d, count16); }));
+    }
+    for (int wgs : {256, 512}) {
+        for (int thr : {256, 512, 1024}) {
+            char nm[128];
+            snprintf(nm, sizeof nm, "grid-stride 16B plain, %d WG x %d", wgs, thr);
+            report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(wgs), dim3(thr), 0, 0, d, count16); }));
+        }
+    }
+    for (int wgs : {256, 512, 1024, 2048, 4096}) {
+        for (int thr : {256, 1024}) {
+            char nm[128];
+            snprintf(nm, sizeof nm, "one row at a time per WG, %d WG x %d", wgs, thr);
+            report(nm, time_ms([&] { hipLaunchKernelGGL(fill_rows_seq16<PLAIN16>, dim3(wgs), dim3(thr), 0, 0, d, n_rows, row16); }));
+        }
+    }
+    for (int wgs : {256, 512, 1024, 2048}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "one row per wave, %d WG x 256", wgs);
+        report(nm, time_ms([&] { hipLaunchKernelGGL(fill_wave_rows16<PLAIN16>, dim3(wgs), dim3(256), 0, 0, d, n_rows, row16); }));
     }
     // hipMemset as the runtime's own fill
     report("hipMemsetAsync", time_ms([&] { hipMemsetAsync(buf, 0, bytes, 0); }));
