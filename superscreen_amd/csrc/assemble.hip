@@ -153,39 +153,50 @@ __global__ __launch_bounds__(kAsmThreads) void q_band_kernel(const double *__res
     const bool store_ok = j0 < ldq;   // ldq is a multiple of CPL (16-byte rows): a lane is in or out as a whole
     const int pstride = bands * (kAsmThreads / kWave);
     for (int64_t r0 = g; r0 < n; r0 += static_cast<int64_t>(groups) * U) {
+        // U rows at once, branch-free, so that their dependent chains (rsqrt + Newton step, wave reduction)
+        // interleave: with one wave per SIMD there is no other wave to hide them behind
         double xi[U], yi[U];
+        int64_t row[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {   // workgroup-uniform: scalar loads, all U rows in flight
-            const int64_t i = r0 + static_cast<int64_t>(u) * groups;
-            const int64_t ic = i < n ? i : n - 1;
+            row[u] = r0 + static_cast<int64_t>(u) * groups;
+            const int64_t ic = row[u] < n ? row[u] : n - 1;
             xi[u] = xy[2 * ic];
             yi[u] = xy[2 * ic + 1];
         }
+        double acc[U];
+        OutT v[U][CPL];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = r0 + static_cast<int64_t>(u) * groups;
-            if (i < n) {   // uniform
-                double acc = 0.0;
-                OutT v[CPL];
+        for (int u = 0; u < U; ++u) acc[u] = 0.0;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const double dx = xi[u] - xj[c], dy = yi[u] - yj[c];
-                    double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
-                    q = (i == j0 + c || j0 + c >= n) ? 0.0 : q;   // distance.py:104-105; padding columns
-                    acc = __builtin_fma(q, wj[c], acc);
-                    v[c] = static_cast<OutT>(-q);
-                }
-                if (store_ok) {
-                    typedef OutT vec_t __attribute__((ext_vector_type(CPL)));
-                    vec_t pack;
+        for (int c = 0; c < CPL; ++c) {
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) pack[c] = v[c];
-                    *reinterpret_cast<vec_t *>(Q + i * ldq + j0) = pack;
-                }
-                const double s = wave_sum(acc);
-                if (lane == 0) partial[i * pstride + band * (kAsmThreads / kWave) + wave] = s;
+            for (int u = 0; u < U; ++u) {
+                const double dx = xi[u] - xj[c], dy = yi[u] - yj[c];
+                double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
+                q = (row[u] == j0 + c || j0 + c >= n) ? 0.0 : q;   // distance.py:104-105; padding columns
+                acc[u] = __builtin_fma(q, wj[c], acc[u]);
+                v[u][c] = static_cast<OutT>(-q);
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (store_ok && row[u] < n) {
+                typedef OutT vec_t __attribute__((ext_vector_type(CPL)));
+                vec_t pack;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) pack[c] = v[u][c];
+                *reinterpret_cast<vec_t *>(Q + row[u] * ldq + j0) = pack;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lane == 0 && row[u] < n) partial[row[u] * pstride + band * (kAsmThreads / kWave) + wave] = acc[u];
     }
 }
 
@@ -391,7 +402,7 @@ extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const dou
     const int pstride = bands * (kAsmThreads / kWave);
     const dim3 grid(static_cast<unsigned>(bands * groups));
     hipStream_t st = as_stream(stream);
-    constexpr int U = 4;
+    constexpr int U = 8;
     if (dtype == SSA_F64) {
         hipLaunchKernelGGL((q_band_kernel<double, U>), grid, dim3(kAsmThreads), 0, st, xy, w, n,
                            static_cast<double *>(Q), ldq, partial, bands, groups);
