@@ -123,11 +123,12 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
 // shape); the same bytes written by 1 800 resident workgroups x 16 matrix rows each reach 5.5 TB/s with
 // nothing to compute (tools/probes/store_probe.hip).  So: a workgroup owns a BAND of columns (2 per lane for
 // float64, 4 for float32: one 16-byte store per lane and row, 4 KiB per workgroup and row) whose coordinates
-// and weights stay in registers for the whole launch, and walks down the rows; with G = floor(CUs / bands)
-// workgroups per band taking rows g, g + G, ..., the chip writes G whole consecutive rows per step.  Row
-// coordinates are scalar loads, U rows ahead.  The row sums of the diagonal are wave-reduced per (row, band,
-// wave) into a workspace and finished by q_diag_finish_kernel in a fixed order (no atomics: Q_ii must not
-// depend on the order in which workgroups finish).
+// stay in registers for the whole launch, and walks down the rows; with G = floor(CUs / bands) workgroups per
+// band taking rows g, g + G, ..., the chip writes G whole consecutive rows per step.  Row coordinates and
+// weights are scalar loads, U rows ahead.  The row sums behind the diagonal need no reduction across lanes:
+// q is symmetric, so the lane that owns column j accumulates sum_i q_ij w_i over the rows its workgroup
+// visits -- a share of ROW j's sum; the G shares per row go through a workspace and are added in a fixed
+// order by q_diag_finish_kernel (no atomics: Q_ii must not depend on the order in which workgroups finish).
 // ---------------------------------------------------------------------------------------
 template <typename OutT>
 struct BandCols {
@@ -139,43 +140,43 @@ __global__ __launch_bounds__(kAsmThreads) void q_band_kernel(const double *__res
                                                              int64_t n, OutT *__restrict__ Q, int64_t ldq,
                                                              double *__restrict__ partial, int bands, int groups) {
     constexpr int CPL = BandCols<OutT>::value;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int band = blockIdx.x % bands, g = blockIdx.x / bands;
     const int64_t j0 = (static_cast<int64_t>(band) * kAsmThreads + tid) * CPL;   // first column of this lane
-    double xj[CPL], yj[CPL], wj[CPL];
+    double xj[CPL], yj[CPL], acc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const bool ok = j0 + c < n;
         xj[c] = ok ? xy[2 * (j0 + c)] : 0.0;
         yj[c] = ok ? xy[2 * (j0 + c) + 1] : 0.0;
-        wj[c] = ok ? w[j0 + c] : 0.0;
+        acc[c] = 0.0;
     }
     const bool store_ok = j0 < ldq;   // ldq is a multiple of CPL (16-byte rows): a lane is in or out as a whole
-    const int pstride = bands * (kAsmThreads / kWave);
     for (int64_t r0 = g; r0 < n; r0 += static_cast<int64_t>(groups) * U) {
-        // U rows at once, branch-free, so that their dependent chains (rsqrt + Newton step, wave reduction)
-        // interleave: with one wave per SIMD there is no other wave to hide them behind
-        double xi[U], yi[U];
+        // U rows at once, branch-free, so that their dependent chains (rsqrt + Newton step) interleave: with one
+        // wave per SIMD there is no other wave to hide them behind
+        double xi[U], yi[U], wi[U];
         int64_t row[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {   // workgroup-uniform: scalar loads, all U rows in flight
             row[u] = r0 + static_cast<int64_t>(u) * groups;
-            const int64_t ic = row[u] < n ? row[u] : n - 1;
+            const bool ok = row[u] < n;
+            const int64_t ic = ok ? row[u] : n - 1;
             xi[u] = xy[2 * ic];
             yi[u] = xy[2 * ic + 1];
+            wi[u] = ok ? w[ic] : 0.0;
         }
-        double acc[U];
         OutT v[U][CPL];
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = 0.0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double dx = xi[u] - xj[c], dy = yi[u] - yj[c];
                 double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
-                q = (row[u] == j0 + c || j0 + c >= n) ? 0.0 : q;   // distance.py:104-105; padding columns
-                acc[u] = __builtin_fma(q, wj[c], acc[u]);
+                q = (row[u] == j0 + c) ? 0.0 : q;             // distance.py:104-105
+                // q is symmetric: the sum over the ROWS this workgroup visits of q_ij w_i, kept per column j in
+                // the lane that owns the column, is a share of row j's sum -- no cross-lane reduction at all
+                acc[c] = __builtin_fma(q, wi[u], acc[c]);
                 v[u][c] = static_cast<OutT>(-q);
             }
         }
@@ -189,26 +190,21 @@ __global__ __launch_bounds__(kAsmThreads) void q_band_kernel(const double *__res
                 *reinterpret_cast<vec_t *>(Q + row[u] * ldq + j0) = pack;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (lane == 0 && row[u] < n) partial[row[u] * pstride + band * (kAsmThreads / kWave) + wave] = acc[u];
     }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+        if (j0 + c < n) partial[static_cast<int64_t>(g) * n + j0 + c] = acc[c];
 }
 
-// Q_ii = (C_i + sum_l q_il w_l) / w_i from the per-(band, wave) partial row sums, in a fixed order
+// Q_ii = (C_i + sum_l q_il w_l) / w_i from the per-row-group shares of the row sums, in a fixed order
 template <typename OutT>
-__global__ void q_diag_finish_kernel(const double *__restrict__ partial, int pstride, const double *__restrict__ C,
+__global__ void q_diag_finish_kernel(const double *__restrict__ partial, int groups, const double *__restrict__ C,
                                      const double *__restrict__ w, int64_t n, OutT *__restrict__ Q, int64_t ldq,
                                      double *__restrict__ qdiag) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
-    for (int p = 0; p < pstride; ++p) s += partial[i * pstride + p];
+    for (int g = 0; g < groups; ++g) s += partial[static_cast<int64_t>(g) * n + i];
     const double d = (C[i] + s) / w[i];  // device/mesh.py:455-457
     if (qdiag != nullptr) qdiag[i] = d;
     Q[i * ldq + i] = static_cast<OutT>(d);
@@ -365,6 +361,7 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
 
 namespace ssa {
 namespace {
+constexpr int kQDenseMaxGroups = 64;   // row groups per band (<= CUs / bands; a device has 256 CUs)
 inline int q_dense_bands(int64_t n, int dtype) {
     const int cols = kAsmThreads * (dtype == SSA_F64 ? BandCols<double>::value : BandCols<float>::value);
     return static_cast<int>(ceil_div(n, cols));
@@ -374,7 +371,7 @@ inline int q_dense_bands(int64_t n, int dtype) {
 
 extern "C" size_t ssa_q_assemble_dense_workspace_bytes(int64_t n, int dtype) {
     if (n <= 0) return 256;
-    return static_cast<size_t>(n) * q_dense_bands(n, dtype) * (kAsmThreads / kWave) * sizeof(double) + 256;
+    return static_cast<size_t>(n) * kQDenseMaxGroups * sizeof(double) + 256;
 }
 
 extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const double *C, int64_t n, void *Q,
@@ -397,9 +394,9 @@ extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const dou
     const int bands = q_dense_bands(n, dtype);
     int groups = cus / bands;   // one workgroup per CU: `groups` whole rows are written per step
     if (groups < 1) groups = 1;
+    if (groups > kQDenseMaxGroups) groups = kQDenseMaxGroups;
     if (groups > n) groups = static_cast<int>(n);
     double *partial = static_cast<double *>(workspace);
-    const int pstride = bands * (kAsmThreads / kWave);
     const dim3 grid(static_cast<unsigned>(bands * groups));
     hipStream_t st = as_stream(stream);
     constexpr int U = 8;
@@ -408,13 +405,13 @@ extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const dou
                            static_cast<double *>(Q), ldq, partial, bands, groups);
         SSA_RETURN_IF_LAUNCH_FAILED();
         hipLaunchKernelGGL((q_diag_finish_kernel<double>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
-                           partial, pstride, C, w, n, static_cast<double *>(Q), ldq, qdiag);
+                           partial, groups, C, w, n, static_cast<double *>(Q), ldq, qdiag);
     } else {
         hipLaunchKernelGGL((q_band_kernel<float, U>), grid, dim3(kAsmThreads), 0, st, xy, w, n,
                            static_cast<float *>(Q), ldq, partial, bands, groups);
         SSA_RETURN_IF_LAUNCH_FAILED();
         hipLaunchKernelGGL((q_diag_finish_kernel<float>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
-                           partial, pstride, C, w, n, static_cast<float *>(Q), ldq, qdiag);
+                           partial, groups, C, w, n, static_cast<float *>(Q), ldq, qdiag);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
