@@ -11,6 +11,8 @@
 // diagonal stay in registers (TR per lane) and are reduced once per strip (wave shuffle + one
 // LDS hop), so the diagonal costs no extra pass over memory.  Optional row scaling and
 // lower-tiles-only output serve the Cholesky route (S = diag(w) A, chol.hip).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace ssa {
@@ -135,14 +137,14 @@ struct BandCols {
     static constexpr int value = 16 / sizeof(OutT);  // columns per lane: one 16-byte store
 };
 
-template <typename OutT, int U>
-__global__ __launch_bounds__(kAsmThreads) void q_band_kernel(const double *__restrict__ xy, const double *__restrict__ w,
+template <typename OutT, int U, int THREADS>
+__global__ __launch_bounds__(THREADS) void q_band_kernel(const double *__restrict__ xy, const double *__restrict__ w,
                                                              int64_t n, OutT *__restrict__ Q, int64_t ldq,
                                                              double *__restrict__ partial, int bands, int groups) {
     constexpr int CPL = BandCols<OutT>::value;
     const int tid = threadIdx.x;
     const int band = blockIdx.x % bands, g = blockIdx.x / bands;
-    const int64_t j0 = (static_cast<int64_t>(band) * kAsmThreads + tid) * CPL;   // first column of this lane
+    const int64_t j0 = (static_cast<int64_t>(band) * THREADS + tid) * CPL;   // first column of this lane
     double xj[CPL], yj[CPL], acc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -362,9 +364,30 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
 namespace ssa {
 namespace {
 constexpr int kQDenseMaxGroups = 64;   // row groups per band (<= CUs / bands; a device has 256 CUs)
+inline int q_dense_threads() {   // SSA_QBAND_THREADS: experiment switch
+    static const int t = [] {
+        const char *e = getenv("SSA_QBAND_THREADS");
+        const int v = e ? atoi(e) : 512;
+        return (v == 256 || v == 512 || v == 1024) ? v : 512;
+    }();
+    return t;
+}
 inline int q_dense_bands(int64_t n, int dtype) {
-    const int cols = kAsmThreads * (dtype == SSA_F64 ? BandCols<double>::value : BandCols<float>::value);
+    const int cols = q_dense_threads() * (dtype == SSA_F64 ? BandCols<double>::value : BandCols<float>::value);
     return static_cast<int>(ceil_div(n, cols));
+}
+template <typename OutT, int THREADS>
+void q_band_launch(dim3 grid, hipStream_t st, const double *xy, const double *w, int64_t n, OutT *Q, int64_t ldq,
+                   double *partial, int bands, int groups) {
+    hipLaunchKernelGGL((q_band_kernel<OutT, 8, THREADS>), grid, dim3(THREADS), 0, st, xy, w, n, Q, ldq, partial, bands,
+                       groups);
+}
+template <typename OutT>
+void q_band_dispatch(int threads, dim3 grid, hipStream_t st, const double *xy, const double *w, int64_t n, OutT *Q,
+                     int64_t ldq, double *partial, int bands, int groups) {
+    if (threads == 256) q_band_launch<OutT, 256>(grid, st, xy, w, n, Q, ldq, partial, bands, groups);
+    else if (threads == 512) q_band_launch<OutT, 512>(grid, st, xy, w, n, Q, ldq, partial, bands, groups);
+    else q_band_launch<OutT, 1024>(grid, st, xy, w, n, Q, ldq, partial, bands, groups);
 }
 }  // namespace
 }  // namespace ssa
@@ -399,16 +422,13 @@ extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const dou
     double *partial = static_cast<double *>(workspace);
     const dim3 grid(static_cast<unsigned>(bands * groups));
     hipStream_t st = as_stream(stream);
-    constexpr int U = 8;
     if (dtype == SSA_F64) {
-        hipLaunchKernelGGL((q_band_kernel<double, U>), grid, dim3(kAsmThreads), 0, st, xy, w, n,
-                           static_cast<double *>(Q), ldq, partial, bands, groups);
+        q_band_dispatch<double>(q_dense_threads(), grid, st, xy, w, n, static_cast<double *>(Q), ldq, partial, bands, groups);
         SSA_RETURN_IF_LAUNCH_FAILED();
         hipLaunchKernelGGL((q_diag_finish_kernel<double>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
                            partial, groups, C, w, n, static_cast<double *>(Q), ldq, qdiag);
     } else {
-        hipLaunchKernelGGL((q_band_kernel<float, U>), grid, dim3(kAsmThreads), 0, st, xy, w, n,
-                           static_cast<float *>(Q), ldq, partial, bands, groups);
+        q_band_dispatch<float>(q_dense_threads(), grid, st, xy, w, n, static_cast<float *>(Q), ldq, partial, bands, groups);
         SSA_RETURN_IF_LAUNCH_FAILED();
         hipLaunchKernelGGL((q_diag_finish_kernel<float>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
                            partial, groups, C, w, n, static_cast<float *>(Q), ldq, qdiag);
