@@ -74,18 +74,6 @@ int ssa_q_assemble(const double *xy, const double *w, const double *C, int64_t n
                    int64_t ldq, int dtype, double *qdiag, void *stream);
 
 /*
- * The same matrix (Q must not be NULL) written the way the memory system likes best: one workgroup per CU,
- * every workgroup a band of columns, the chip as a whole writing whole consecutive rows (6 TB/s class, against
- * 4.7-4.9 TB/s for ssa_q_assemble's row strips).  The row sums behind the diagonal pass through a workspace
- * (ssa_q_assemble_dense_workspace_bytes) and are finished in a fixed order: the result does not depend on
- * scheduling.  ldq: a multiple of 16 bytes worth of elements (2 for float64, 4 for float32), Q 16-byte aligned.
- */
-size_t ssa_q_assemble_dense_workspace_bytes(int64_t n, int dtype);
-int ssa_q_assemble_dense(const double *xy, const double *w, const double *C, int64_t n, void *Q,
-                         int64_t ldq, int dtype, double *qdiag, void *workspace,
-                         size_t workspace_bytes, void *stream);
-
-/*
  * Replaces  _build_system_2d / _build_system_1d  solver/solve_film.py:285-305 together with
  * the dense operands they slice (film_info.kernel, film_info.laplacian -- the latter is
  * `laplacian.toarray()` in the reference, solver/utils.py:292; here it stays CSR):

@@ -32,8 +32,6 @@ SIGNATURES = {
     "ssa_error_string": (c_char_p, [c_int]),
     "ssa_device_info": (c_int, [P, P, P, c_int]),
     "ssa_q_assemble": (c_int, [P, P, P, I64, P, I64, c_int, P, P]),
-    "ssa_q_assemble_dense_workspace_bytes": (c_size_t, [I64, c_int]),
-    "ssa_q_assemble_dense": (c_int, [P, P, P, I64, P, I64, c_int, P, P, c_size_t, P]),
     "ssa_system_assemble_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "ssa_system_assemble": (c_int, [P, P, P, P, I64, P, P, P, P, I64, P, I64, c_double, P, c_int,
                                     P, I64, c_int, P, c_size_t, P]),

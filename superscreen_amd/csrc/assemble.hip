@@ -11,8 +11,6 @@
 // diagonal stay in registers (TR per lane) and are reduced once per strip (wave shuffle + one
 // LDS hop), so the diagonal costs no extra pass over memory.  Optional row scaling and
 // lower-tiles-only output serve the Cholesky route (S = diag(w) A, chol.hip).
-#include <stdlib.h>
-
 #include "common.hpp"
 
 namespace ssa {
@@ -116,100 +114,6 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         if (qdiag != nullptr) qdiag[i] = d;
         if (Q != nullptr) Q[i * ldq + i] = static_cast<OutT>(d);
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// Dense Q, band form (ssa_q_assemble_dense).  What limits a multi-GB store stream on MI355X is how many
-// separate address streams the chip has in flight: ONE 256-thread workgroup per CU, all CUs writing 4 KiB
-// pieces of one compact window that sweeps the buffer, fills at 6.3-6.4 TB/s (rocclr's fill kernel has that
-// shape); the same bytes written by 1 800 resident workgroups x 16 matrix rows each reach 5.5 TB/s with
-// nothing to compute (tools/probes/store_probe.hip).  So: a workgroup owns a BAND of columns (2 per lane for
-// float64, 4 for float32: one 16-byte store per lane and row, 4 KiB per workgroup and row) whose coordinates
-// stay in registers for the whole launch, and walks down the rows; with G = floor(CUs / bands) workgroups per
-// band taking rows g, g + G, ..., the chip writes G whole consecutive rows per step.  Row coordinates and
-// weights are scalar loads, U rows ahead.  The row sums behind the diagonal need no reduction across lanes:
-// q is symmetric, so the lane that owns column j accumulates sum_i q_ij w_i over the rows its workgroup
-// visits -- a share of ROW j's sum; the G shares per row go through a workspace and are added in a fixed
-// order by q_diag_finish_kernel (no atomics: Q_ii must not depend on the order in which workgroups finish).
-// ---------------------------------------------------------------------------------------
-template <typename OutT>
-struct BandCols {
-    static constexpr int value = 16 / sizeof(OutT);  // columns per lane: one 16-byte store
-};
-
-template <typename OutT, int U, int THREADS>
-__global__ __launch_bounds__(THREADS) void q_band_kernel(const double *__restrict__ xy, const double *__restrict__ w,
-                                                             int64_t n, OutT *__restrict__ Q, int64_t ldq,
-                                                             double *__restrict__ partial, int bands, int groups) {
-    constexpr int CPL = BandCols<OutT>::value;
-    const int tid = threadIdx.x;
-    const int band = blockIdx.x % bands, g = blockIdx.x / bands;
-    const int64_t j0 = (static_cast<int64_t>(band) * THREADS + tid) * CPL;   // first column of this lane
-    double xj[CPL], yj[CPL], acc[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const bool ok = j0 + c < n;
-        xj[c] = ok ? xy[2 * (j0 + c)] : 0.0;
-        yj[c] = ok ? xy[2 * (j0 + c) + 1] : 0.0;
-        acc[c] = 0.0;
-    }
-    const bool store_ok = j0 < ldq;   // ldq is a multiple of CPL (16-byte rows): a lane is in or out as a whole
-    for (int64_t r0 = g; r0 < n; r0 += static_cast<int64_t>(groups) * U) {
-        // U rows at once, branch-free, so that their dependent chains (rsqrt + Newton step) interleave: with one
-        // wave per SIMD there is no other wave to hide them behind
-        double xi[U], yi[U], wi[U];
-        int64_t row[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {   // workgroup-uniform: scalar loads, all U rows in flight
-            row[u] = r0 + static_cast<int64_t>(u) * groups;
-            const bool ok = row[u] < n;
-            const int64_t ic = ok ? row[u] : n - 1;
-            xi[u] = xy[2 * ic];
-            yi[u] = xy[2 * ic + 1];
-            wi[u] = ok ? w[ic] : 0.0;
-        }
-        OutT v[U][CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const double dx = xi[u] - xj[c], dy = yi[u] - yj[c];
-                double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
-                q = (row[u] == j0 + c) ? 0.0 : q;             // distance.py:104-105
-                // q is symmetric: the sum over the ROWS this workgroup visits of q_ij w_i, kept per column j in
-                // the lane that owns the column, is a share of row j's sum -- no cross-lane reduction at all
-                acc[c] = __builtin_fma(q, wi[u], acc[c]);
-                v[u][c] = static_cast<OutT>(-q);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (store_ok && row[u] < n) {
-                typedef OutT vec_t __attribute__((ext_vector_type(CPL)));
-                vec_t pack;
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) pack[c] = v[u][c];
-                *reinterpret_cast<vec_t *>(Q + row[u] * ldq + j0) = pack;
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CPL; ++c)
-        if (j0 + c < n) partial[static_cast<int64_t>(g) * n + j0 + c] = acc[c];
-}
-
-// Q_ii = (C_i + sum_l q_il w_l) / w_i from the per-row-group shares of the row sums, in a fixed order
-template <typename OutT>
-__global__ void q_diag_finish_kernel(const double *__restrict__ partial, int groups, const double *__restrict__ C,
-                                     const double *__restrict__ w, int64_t n, OutT *__restrict__ Q, int64_t ldq,
-                                     double *__restrict__ qdiag) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int g = 0; g < groups; ++g) s += partial[static_cast<int64_t>(g) * n + i];
-    const double d = (C[i] + s) / w[i];  // device/mesh.py:455-457
-    if (qdiag != nullptr) qdiag[i] = d;
-    Q[i * ldq + i] = static_cast<OutT>(d);
 }
 
 // Number of workgroups for n rows: a whole number of rounds of the kernel's resident slots on this device
@@ -356,82 +260,6 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
         const dim3 grid(static_cast<unsigned>(balanced_groups(q_assemble_kernel<float, kStripRows>, n, kStripRows)));
         hipLaunchKernelGGL((q_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads), 0,
                            as_stream(stream), xy, w, C, n, static_cast<float *>(Q), ldq, qdiag);
-    }
-    SSA_RETURN_IF_LAUNCH_FAILED();
-    return SSA_OK;
-}
-
-namespace ssa {
-namespace {
-constexpr int kQDenseMaxGroups = 64;   // row groups per band (<= CUs / bands; a device has 256 CUs)
-inline int q_dense_threads() {   // SSA_QBAND_THREADS: experiment switch
-    static const int t = [] {
-        const char *e = getenv("SSA_QBAND_THREADS");
-        const int v = e ? atoi(e) : 512;
-        return (v == 256 || v == 512 || v == 1024) ? v : 512;
-    }();
-    return t;
-}
-inline int q_dense_bands(int64_t n, int dtype) {
-    const int cols = q_dense_threads() * (dtype == SSA_F64 ? BandCols<double>::value : BandCols<float>::value);
-    return static_cast<int>(ceil_div(n, cols));
-}
-template <typename OutT, int THREADS>
-void q_band_launch(dim3 grid, hipStream_t st, const double *xy, const double *w, int64_t n, OutT *Q, int64_t ldq,
-                   double *partial, int bands, int groups) {
-    hipLaunchKernelGGL((q_band_kernel<OutT, 8, THREADS>), grid, dim3(THREADS), 0, st, xy, w, n, Q, ldq, partial, bands,
-                       groups);
-}
-template <typename OutT>
-void q_band_dispatch(int threads, dim3 grid, hipStream_t st, const double *xy, const double *w, int64_t n, OutT *Q,
-                     int64_t ldq, double *partial, int bands, int groups) {
-    if (threads == 256) q_band_launch<OutT, 256>(grid, st, xy, w, n, Q, ldq, partial, bands, groups);
-    else if (threads == 512) q_band_launch<OutT, 512>(grid, st, xy, w, n, Q, ldq, partial, bands, groups);
-    else q_band_launch<OutT, 1024>(grid, st, xy, w, n, Q, ldq, partial, bands, groups);
-}
-}  // namespace
-}  // namespace ssa
-
-extern "C" size_t ssa_q_assemble_dense_workspace_bytes(int64_t n, int dtype) {
-    if (n <= 0) return 256;
-    return static_cast<size_t>(n) * kQDenseMaxGroups * sizeof(double) + 256;
-}
-
-extern "C" int ssa_q_assemble_dense(const double *xy, const double *w, const double *C, int64_t n, void *Q,
-                                    int64_t ldq, int dtype, double *qdiag, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
-    if (n <= 0 || !xy || !w || !C || !Q) return SSA_ERR_INVALID_ARGUMENT;
-    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
-    const int cpl = (dtype == SSA_F64) ? BandCols<double>::value : BandCols<float>::value;
-    if (ldq < n || ldq % cpl != 0 || reinterpret_cast<uintptr_t>(Q) % 16 != 0) return SSA_ERR_INVALID_ARGUMENT;
-    if (!workspace || workspace_bytes < ssa_q_assemble_dense_workspace_bytes(n, dtype)) return SSA_ERR_WORKSPACE_TOO_SMALL;
-    int dev = 0, cus = 256;
-    static int cus_of_device[kMaxDevices] = {};
-    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
-    if (cus_of_device[dev] == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return SSA_ERR_HIP;
-        cus_of_device[dev] = v;
-    }
-    cus = cus_of_device[dev];
-    const int bands = q_dense_bands(n, dtype);
-    int groups = cus / bands;   // one workgroup per CU: `groups` whole rows are written per step
-    if (groups < 1) groups = 1;
-    if (groups > kQDenseMaxGroups) groups = kQDenseMaxGroups;
-    if (groups > n) groups = static_cast<int>(n);
-    double *partial = static_cast<double *>(workspace);
-    const dim3 grid(static_cast<unsigned>(bands * groups));
-    hipStream_t st = as_stream(stream);
-    if (dtype == SSA_F64) {
-        q_band_dispatch<double>(q_dense_threads(), grid, st, xy, w, n, static_cast<double *>(Q), ldq, partial, bands, groups);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-        hipLaunchKernelGGL((q_diag_finish_kernel<double>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
-                           partial, groups, C, w, n, static_cast<double *>(Q), ldq, qdiag);
-    } else {
-        q_band_dispatch<float>(q_dense_threads(), grid, st, xy, w, n, static_cast<float *>(Q), ldq, partial, bands, groups);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-        hipLaunchKernelGGL((q_diag_finish_kernel<float>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
-                           partial, groups, C, w, n, static_cast<float *>(Q), ldq, qdiag);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;

@@ -54,13 +54,6 @@ def q_assemble(xy: torch.Tensor, w: torch.Tensor, C: torch.Tensor, dtype, *,
     if want_Q:
         ldq = ld or padded_ld(n, dtype)
         Q = out if out is not None else torch.empty((n, ldq), dtype=_tdtype(dtype), device=xy.device)
-    if Q is not None and ldq % (16 // Q.element_size()) == 0 and Q.data_ptr() % 16 == 0 and n >= 2048:
-        # dense Q of a mesh worth the launch: the band form (one workgroup per CU, whole rows per step)
-        nbytes = lib.ssa_q_assemble_dense_workspace_bytes(n, dtype_code(dtype))
-        ws = _ws(nbytes, xy.device)
-        check(lib.ssa_q_assemble_dense(ptr(xy), ptr(w), ptr(C), n, ptr(Q), ldq, dtype_code(dtype), ptr(qdiag),
-                                       ptr(ws), nbytes, current_stream()), "ssa_q_assemble_dense")
-        return Q, qdiag
     check(lib.ssa_q_assemble(ptr(xy), ptr(w), ptr(C), n, ptr(Q), ldq, dtype_code(dtype),
                              ptr(qdiag), current_stream()), "ssa_q_assemble")
     return Q, qdiag

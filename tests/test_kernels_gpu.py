@@ -646,41 +646,3 @@ def test_lu_nopivot_rejects_matrices_that_need_interchanges_and_batches_are_repr
     singular[:, 300] = 0.0
     f = K.lu_factor_nopivot_batch([(_nopivot_buffer(K, singular, "float64"), n2)])[0]
     assert f is None or f.info == 301      # LAPACK: U[300, 300] is exactly zero, no interchange, info = 301
-
-
-@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 1e-6)])
-@pytest.mark.parametrize("Kr", [26, 41])
-def test_q_assemble_dense_band_form(K, dtype, tol, Kr):
-    """ssa_q_assemble_dense (one workgroup per CU, column bands, whole rows per step) against ssa_q_assemble (row
-    strips) and the oracle: the off-diagonal entries are the same arithmetic (bit-identical), the diagonal differs
-    by the order of its row sum only; ragged sizes (n = 2 107 and 5 167: last band partly empty, odd n)."""
-    import ctypes
-
-    from superscreen_amd import _hip, synthetic
-
-    sites, elements, _ = synthetic.ring_disk_mesh(Kr)
-    n = len(sites)
-    mesh = orc.make_mesh(sites, elements, build_Q=(Kr == 26))
-    C = orc.C_vector(sites)
-    xy, w, Cd = dev(sites), dev(mesh.weights), dev(C)
-    Q, qd = K.q_assemble(xy, w, Cd, dtype)                       # n >= 2048: the band form
-    lib = _hip.load_library()
-    ld = Q.shape[1]
-    Q0 = torch.empty_like(Q)
-    qd0 = torch.empty_like(qd)
-    _hip.check(lib.ssa_q_assemble(_hip.ptr(xy), _hip.ptr(w), _hip.ptr(Cd), n, _hip.ptr(Q0), ld, _hip.dtype_code(dtype),
-                                  _hip.ptr(qd0), None), "ssa_q_assemble")
-    torch.cuda.synchronize()
-    a, b = Q.cpu().numpy()[:, :n], Q0.cpu().numpy()[:, :n]
-    off = ~np.eye(n, dtype=bool)
-    assert np.array_equal(a[off], b[off])
-    assert relerr(np.diag(a), np.diag(b)) < tol and relerr(qd.cpu().numpy(), qd0.cpu().numpy()) < 1e-13
-    if mesh.Q is not None:
-        assert relerr(qd.cpu().numpy(), np.diag(mesh.Q)) < 2e-14
-        assert np.max(np.abs(a[off] - mesh.Q[off]) / np.abs(mesh.Q[off])) < (2e-14 if dtype == "float64" else 1e-6)
-    # error codes: odd leading dimension, short workspace
-    ws = torch.empty(256, dtype=torch.uint8, device="cuda")
-    assert lib.ssa_q_assemble_dense(_hip.ptr(xy), _hip.ptr(w), _hip.ptr(Cd), n, _hip.ptr(Q), ld + 1, _hip.dtype_code(dtype),
-                                    None, _hip.ptr(ws), 256, None) == -1
-    assert lib.ssa_q_assemble_dense(_hip.ptr(xy), _hip.ptr(w), _hip.ptr(Cd), n, _hip.ptr(Q), ld, _hip.dtype_code(dtype),
-                                    None, _hip.ptr(ws), 256, None) == -3
