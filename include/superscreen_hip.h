@@ -363,7 +363,8 @@ int ssa_biot_savart_multi(const double *src_xy, const void *src_areas, const dou
                           int accumulate, int dtype, void *workspace, size_t workspace_bytes,
                           void *stream);
 
-/* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern (roofline peak). */
+/* HBM write-bandwidth probe: fills `bytes` bytes with a 16-byte pattern, one workgroup per CU, grid-stride, plain
+ * stores (the fastest fill shape measured on MI355X: what a pure store stream reaches on this box). */
 int ssa_fill_probe(void *dst, size_t bytes, void *stream);
 
 /*

@@ -246,7 +246,7 @@ __global__ void fill_probe_kernel(u32x4 *__restrict__ dst, size_t count16) {
     const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count16;
          i += stride)
-        __builtin_nontemporal_store(v, dst + i);
+        dst[i] = v;   // plain stores: non-temporal ones fill slower on MI355X (tools/probes/store_probe.hip)
 }
 
 }  // namespace ssa
@@ -365,7 +365,11 @@ extern "C" int ssa_current_density(const int64_t *indptr, const int64_t *indices
 
 extern "C" int ssa_fill_probe(void *dst, size_t bytes, void *stream) {
     if (!dst || bytes < 16) return SSA_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(fill_probe_kernel, dim3(2048), dim3(256), 0, as_stream(stream),
+    // one 256-thread workgroup per CU, grid-stride: the chip writes one compact 1 MiB window at a time (the
+    // fastest of the fill shapes tried, 6.4 TB/s = hipMemsetAsync; 2048 workgroups: 5.0)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(fill_probe_kernel, dim3(static_cast<unsigned>(cus > 0 ? cus : 256)), dim3(256), 0, as_stream(stream),
                        static_cast<u32x4 *>(dst), bytes / 16);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
