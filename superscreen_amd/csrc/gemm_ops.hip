@@ -18,6 +18,7 @@ namespace ssa {
 enum : int { OP_N = 0, OP_T = 1 };
 
 constexpr int KMINOR_STRIDE = BN + 16;
+constexpr int64_t kSmallTileMaxTiles = 160;   // 128 x 128 tiles of a launch below which the 32 x 128 tile is used
 constexpr int IMG_ELEMS = KC * KMINOR_STRIDE;  // the larger of the two images
 
 struct OpSmemF64 {
@@ -217,6 +218,115 @@ __device__ __forceinline__ void tile_full_f32_nt(int64_t K, float alpha, const f
                 Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
 }
 
+// ---- SMALL-TILE path, NT: 32 x 128 tile per workgroup ------------------------------------------
+// The chain of the Cholesky schedule (chol.hip) runs products whose whole grid is a fraction of the chip --
+// strips C[M x 256] -= P P0^T and panel products L21 = A21 W^T with M a few thousand rows: with 128 x 128
+// tiles such a launch takes as long as ONE tile (4096 MFMAs of 64 cycles on the 4 SIMDs of one CU: 30 us at
+// K = 256, 60 us at K = 512, plus prologue and epilogue), and in the last third of a factorization three of
+// them sit on the critical path of every panel round.  Here a workgroup computes 32 rows x 128 columns (a
+// quarter of the MFMA work, four times as many workgroups); 128 columns per workgroup keep the in-place panel
+// products safe (a workgroup reads and writes its own rows only, N = 128 is one tile).  4 waves side by
+// side, 32 x 32 each (2 x 2 MFMA tiles); operands staged by LDS-DMA like the large tile.  float32 through the
+// same 8-byte views as tile_full_f32_nt.
+constexpr int SBM = 32;
+struct SmallSmem {
+    double a[2][SBM * KC];
+    double b[2][BN * KC];
+};
+
+template <typename T>
+__device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double *__restrict__ A, int64_t lda8,
+                                              const double *__restrict__ B, int64_t ldb8, T beta, T *__restrict__ C,
+                                              int64_t ldc, int64_t m0, int64_t n0, char *smem_raw) {
+    // A, B: 8-byte views (float32: pairs of consecutive k); K8, lda8, ldb8 in 8-byte units
+    using MF = Mfma<T>;
+    using acc_t = typename MF::acc_t;
+    SmallSmem &sm = *reinterpret_cast<SmallSmem *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int swz = 2 * ((li >> 1) & 7);
+    const int sub = lane >> 3, kpos = (lane & 7) * 2;
+    // LDS-DMA sources: A image = 32 rows (one 8-row group per wave), B image = 128 rows (four groups per wave)
+    const int arow = 8 * wave + sub;
+    const double *asrc = A + (m0 + arow) * lda8 + (kpos ^ (2 * ((arow >> 1) & 7)));
+    const double *bsrc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = 8 * (wave + 4 * u) + sub;
+        bsrc[u] = B + (n0 + row) * ldb8 + (kpos ^ (2 * ((row >> 1) & 7)));
+    }
+    auto issue = [&](int64_t k0, int stage) {
+        glds16(asrc + k0, sm.a[stage] + 8 * wave * KC);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) glds16(bsrc[u] + k0, sm.b[stage] + 8 * (wave + 4 * u) * KC);
+    };
+    issue(0, 0);
+    acc_t acc[2][2];
+    T *Cw = C + m0 * ldc + n0 + wave * 32 + li;
+    if (beta != T(0)) {
+        const T scale = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int64_t nk = K8 / KC;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = static_cast<int>(kt & 1);
+        if (kt + 1 < nk) issue((kt + 1) * KC, cur ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            double fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = sm.a[cur][(i * 16 + li) * KC + ((ks * 4 + lk) ^ swz)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = sm.b[cur][(wave * 32 + j * 16 + li) * KC + ((ks * 4 + lk) ^ swz)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 8) {
+                        acc[i][j] = MF::run(fa[i], fb[j], acc[i][j]);
+                    } else {
+                        const float2 x = __builtin_bit_cast(float2, fa[i]), y = __builtin_bit_cast(float2, fb[j]);
+                        acc[i][j] = MF::run(x.x, y.x, acc[i][j]);
+                        acc[i][j] = MF::run(x.y, y.y, acc[i][j]);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGemmThreads) void gemm_nt_small_kernel(int64_t K8, T alpha, const double *__restrict__ A,
+                                                                    int64_t lda8, const double *__restrict__ B,
+                                                                    int64_t ldb8, T beta, T *__restrict__ C, int64_t ldc,
+                                                                    int64_t ntm) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t tm = wg % ntm, tn = wg / ntm;   // consecutive ids share the B panel
+    tile_small_nt<T>(K8, alpha, A, lda8, B, ldb8, beta, C, ldc, tm * SBM, tn * BN, smem_raw);
+}
+
 // ---- EDGE path: any type, any shape, guarded element-wise staging --------------------------
 template <typename T>
 struct EdgeSmem {
@@ -380,6 +490,23 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
     const int aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
                         ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0);
     const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
+    // few tiles (a launch of the panel chain): the small-tile kernel, a quarter of the latency
+    constexpr int64_t kStage = (sizeof(T) == 8) ? KC : 2 * KC;
+    if (!lower && TA == OP_N && TB == OP_T && aligned && nwg <= kSmallTileMaxTiles && M % SBM == 0 && N % BN == 0 &&
+        K % kStage == 0 && K > 0 && alpha != 0.0) {
+        static DeviceFlags small_flags;
+        if (raise_dynamic_lds(small_flags, {{reinterpret_cast<const void *>(&gemm_nt_small_kernel<T>), sizeof(SmallSmem)}}) !=
+            SSA_OK)
+            return SSA_ERR_HIP;
+        const int64_t stm = M / SBM, stn = N / BN;
+        constexpr int64_t per8 = 8 / sizeof(T);
+        ProfileScope scope(sizeof(T) == 8, kProfileOpNT, 2.0 * static_cast<double>(K) * static_cast<double>(M) * N, st);
+        hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3(static_cast<unsigned>(stm * stn)), dim3(kGemmThreads),
+                           sizeof(SmallSmem), st, K / per8, static_cast<T>(alpha), reinterpret_cast<const double *>(A),
+                           lda / per8, reinterpret_cast<const double *>(B), ldb / per8, static_cast<T>(beta), C, ldc, stm);
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        return SSA_OK;
+    }
     static DeviceFlags lds_flags;
     if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&gemm_op_kernel<T, TA, TB, LOWER>), smem}}) !=
         SSA_OK)

@@ -646,3 +646,34 @@ def test_lu_nopivot_rejects_matrices_that_need_interchanges_and_batches_are_repr
     singular[:, 300] = 0.0
     f = K.lu_factor_nopivot_batch([(_nopivot_buffer(K, singular, "float64"), n2)])[0]
     assert f is None or f.info == 301      # LAPACK: U[300, 300] is exactly zero, no interchange, info = 301
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-13), ("float32", 2e-5)])
+@pytest.mark.parametrize("shape", [(2048, 128, 256), (96, 256, 512), (4096, 256, 64), (32, 128, 32)])
+def test_gemm_nt_small_tile_path(K, dtype, tol, shape):
+    """The 32 x 128 tile of the panel chain (few-tile NT launches): against numpy with beta = 1 and beta = 0, and
+    the in-place panel product  A21[:, 128:256] = A21 W[128:256, :]^T  that relies on a workgroup reading and
+    writing only its own rows."""
+    M, N, Kd = shape
+    rng = np.random.default_rng(M + N + Kd)
+    A = rng.standard_normal((M, Kd)).astype(dtype)
+    B = rng.standard_normal((N, Kd)).astype(dtype)
+    C = rng.standard_normal((M, N)).astype(dtype)
+    for beta in (1.0, 0.0):
+        Cd = dev(C) if beta else torch.full((M, N), float("nan"), dtype=getattr(torch, dtype), device="cuda")
+        K.gemm_ex(0, 1, False, dev(A), dev(B), Cd, M, N, Kd, alpha=-0.5, beta=beta)
+        ref = beta * C.astype(np.float64) - 0.5 * A.astype(np.float64) @ B.astype(np.float64).T
+        assert relerr(Cd.cpu().numpy(), ref) < tol
+    if Kd == 256 and N == 128:
+        A21 = dev(A)                                         # [M, 256]
+        W = rng.standard_normal((256, 256)).astype(dtype)
+        Wd = dev(W)
+        from superscreen_amd import _hip
+        lib = _hip.load_library()
+        es = A21.element_size()
+        _hip.check(lib.ssa_gemm_ex(0, 1, 0, M, 128, 256, 1.0, A21.data_ptr(), 256, Wd.data_ptr() + 128 * 256 * es, 256,
+                                   0.0, A21.data_ptr() + 128 * es, 256, _hip.dtype_code(dtype), None), "ssa_gemm_ex")
+        torch.cuda.synchronize()
+        ref = A.astype(np.float64) @ W[128:, :].astype(np.float64).T
+        got = A21.cpu().numpy()
+        assert relerr(got[:, 128:], ref) < tol * 10 and np.array_equal(got[:, :128], A[:, :128])

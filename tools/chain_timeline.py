@@ -1,0 +1,66 @@
+"""Chain-stream timeline of one Cholesky factorization from a rocprofv3 kernel trace (development aid):
+for every chol_diag256 launch of the busiest chain queue, the kernels between it and the next one.
+
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -- python3 tools/chain_timeline.py run float64
+    python tools/chain_timeline.py analyse /tmp/ct"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def run(dtype):
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(91, ("washer", "disk"), solve_dtype=dtype)
+    for _ in range(2):
+        model = sc.factorize_model(device=device, current_units="uA")
+        torch.cuda.synchronize()
+        del model
+
+
+def analyse(d):
+    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
+    asm = [i for i, r in enumerate(rows) if "system_assemble" in r["Kernel_Name"]]
+    rows = rows[asm[-2]:]          # the last factorization (two films: two assemblies)
+    t0 = rows[0]["s"]
+    byq = collections.defaultdict(list)
+    for r in rows:
+        byq[r["Queue_Id"]].append(r)
+    chains = [(q, rs) for q, rs in byq.items() if any("chol_diag256" in r["Kernel_Name"] for r in rs)]
+    chains.sort(key=lambda kv: -len(kv[1]))
+    q, rs = chains[0]
+    diag = [i for i, r in enumerate(rs) if "chol_diag256" in r["Kernel_Name"]]
+    print(f"chain queue {q}: {len(diag)} panels; factorization span {(rows[-1]['e'] - t0) / 1e6:.1f} ms")
+    short = {"chol_diag256": "diag", "gemm_op_kernel": "gemm"}
+    for n, i in enumerate(diag[:-1]):
+        if not (n % 8 == 0 or n >= len(diag) - 6):
+            continue
+        j = diag[n + 1]
+        parts = []
+        for r in rs[i:j]:
+            nm = next((v for k, v in short.items() if k in r["Kernel_Name"]), r["Kernel_Name"][:12])
+            gap = (r["s"] - prev_e) / 1e3 if parts else 0.0
+            parts.append(f"{'+%.0f ' % gap if parts else ''}{nm} {(r['e'] - r['s']) / 1e3:.0f}")
+            prev_e = r["e"]
+        print(f"panel {n:3d} @ {(rs[i]['s'] - t0) / 1e6:6.1f} ms  round {(rs[j]['s'] - rs[i]['s']) / 1e3:6.0f} us :  " + " | ".join(parts))
+    syrk = [r for r in rows if "Lb1EEE" in r["Kernel_Name"] or ", true>" in r["Kernel_Name"] and "gemm_op" in r["Kernel_Name"]]
+    if syrk:
+        busy = sum(r["e"] - r["s"] for r in syrk)
+        print(f"SYRK launches {len(syrk)}, busy {busy / 1e6:.1f} ms, first {(syrk[0]['s'] - t0) / 1e6:.1f}, last end {(syrk[-1]['e'] - t0) / 1e6:.1f} ms")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2])
+    else:
+        analyse(sys.argv[2])
