@@ -229,10 +229,21 @@ __device__ __forceinline__ void tile_full_f32_nt(int64_t K, float alpha, const f
 // side, 32 x 32 each (2 x 2 MFMA tiles); operands staged by LDS-DMA like the large tile.  float32 through the
 // same 8-byte views as tile_full_f32_nt.
 constexpr int SBM = 32;
+constexpr int SNST = 4;   // LDS ring: with 16 MFMAs per wave and stage a stage computes in 0.5 us, a load takes 1-3 us:
+                          // three stages are kept in flight (one-stage prefetch made the tile latency 16 x one memory
+                          // round trip = 50 us whatever its size)
 struct SmallSmem {
-    double a[2][SBM * KC];
-    double b[2][BN * KC];
+    double a[SNST][SBM * KC];
+    double b[SNST][BN * KC];
 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+}
 
 template <typename T>
 __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double *__restrict__ A, int64_t lda8,
@@ -246,7 +257,8 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
     const int li = lane & 15, lk = lane >> 4;
     const int swz = 2 * ((li >> 1) & 7);
     const int sub = lane >> 3, kpos = (lane & 7) * 2;
-    // LDS-DMA sources: A image = 32 rows (one 8-row group per wave), B image = 128 rows (four groups per wave)
+    // LDS-DMA sources: A image = 32 rows (one 8-row group per wave), B image = 128 rows (four groups per wave):
+    // 5 loads per wave and stage
     const int arow = 8 * wave + sub;
     const double *asrc = A + (m0 + arow) * lda8 + (kpos ^ (2 * ((arow >> 1) & 7)));
     const double *bsrc[4];
@@ -255,35 +267,55 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
         const int row = 8 * (wave + 4 * u) + sub;
         bsrc[u] = B + (n0 + row) * ldb8 + (kpos ^ (2 * ((row >> 1) & 7)));
     }
-    auto issue = [&](int64_t k0, int stage) {
-        glds16(asrc + k0, sm.a[stage] + 8 * wave * KC);
+    auto issue = [&](int64_t kt) {
+        const int stage = static_cast<int>(kt % SNST);
+        glds16(asrc + kt * KC, sm.a[stage] + 8 * wave * KC);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) glds16(bsrc[u] + k0, sm.b[stage] + 8 * (wave + 4 * u) * KC);
+        for (int u = 0; u < 4; ++u) glds16(bsrc[u] + kt * KC, sm.b[stage] + 8 * (wave + 4 * u) * KC);
     };
-    issue(0, 0);
+    // the C tile first (oldest in the vmcnt order; raw values, scaled after the first wait so that nothing
+    // forces them to arrive before the stages are issued), then the first SNST - 1 stages
     acc_t acc[2][2];
     T *Cw = C + m0 * ldc + n0 + wave * 32 + li;
-    if (beta != T(0)) {
-        const T scale = beta / alpha;
+    const bool has_c = (beta != T(0));
+    if (has_c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+                    acc[i][j][r] = Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     const int64_t nk = K8 / KC;
+#pragma unroll
+    for (int p = 0; p < SNST - 1; ++p)
+        if (p < nk) issue(p);
     for (int64_t kt = 0; kt < nk; ++kt) {
-        const int cur = static_cast<int>(kt & 1);
-        if (kt + 1 < nk) issue((kt + 1) * KC, cur ^ 1);
+        const int cur = static_cast<int>(kt % SNST);
+        if (kt + SNST - 1 < nk) issue(kt + SNST - 1);   // into the slot that was read at step kt - 1 (barrier below)
+        const int64_t ahead = nk - 1 - kt;               // stages issued after stage kt: min(SNST - 1, ahead)
+        if (ahead >= 3) wait_vmcnt<15>();
+        else if (ahead == 2) wait_vmcnt<10>();
+        else if (ahead == 1) wait_vmcnt<5>();
+        else wait_vmcnt<0>();
+        // raw barrier: __syncthreads() carries a fence that drains every load in flight (vmcnt(0)), which is
+        // exactly what the ring must not do; each wave has waited for its own share of stage kt above
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0 && has_c) {
+            const T scale = beta / alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] *= scale;
+        }
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {
             double fa[2], fb[2];
@@ -304,8 +336,7 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
                     }
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();   // every wave is done reading slot `cur` before it is refilled
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
