@@ -10,8 +10,6 @@
 //   K-MINOR  (m|n contiguous: A for op T, B for op N) [16][128 + 16]
 // so NT (SYRK: both operands are row panels of the same matrix) uses two K-MAJOR images and TN
 // (backward substitution with L^T on many right-hand sides) two K-MINOR images.
-#include <stdlib.h>
-
 #include "gemm_profile.hpp"
 #include "mfma_traits.hpp"
 
@@ -353,12 +351,10 @@ template <typename T>
 __global__ __launch_bounds__(kGemmThreads) void gemm_nt_small_kernel(int64_t K8, T alpha, const double *__restrict__ A,
                                                                     int64_t lda8, const double *__restrict__ B,
                                                                     int64_t ldb8, T beta, T *__restrict__ C, int64_t ldc,
-                                                                    int64_t ntm, int lower) {
+                                                                    int64_t ntm) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
     const int64_t tm = wg % ntm, tn = wg / ntm;   // consecutive ids share the B panel
-    // lower: only the tiles that reach the diagonal or lie below it (the others exit at once)
-    if (lower && tn * BN > tm * SBM + SBM - 1) return;
     tile_small_nt<T>(K8, alpha, A, lda8, B, ldb8, beta, C, ldc, tm * SBM, tn * BN, smem_raw);
 }
 
@@ -527,30 +523,18 @@ int launch_op_l(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64
     const int64_t nwg = lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
     // few tiles (a launch of the panel chain): the small-tile kernel, a quarter of the latency
     constexpr int64_t kStage = (sizeof(T) == 8) ? KC : 2 * KC;
-    // ... and the trailing updates of the last third of a factorization (small M): there the panel chain sets the
-    // pace, the update itself sits on its critical path, and short-lived workgroups free CU slots for the
-    // chain's kernels every ~10 us instead of every 60-110 us (a chain kernel cannot start beside two resident
-    // 128 x 128 workgroups: they hold all registers and LDS of a CU)
-    static const int64_t small_lower_max = [] {
-        const char *e = getenv("SSA_SMALL_SYRK_MAX");
-        return e ? static_cast<int64_t>(atoll(e)) : int64_t(6144);
-    }();
-    const bool small_ok = lower ? (M <= small_lower_max) : (nwg <= kSmallTileMaxTiles);
-    if (TA == OP_N && TB == OP_T && aligned && small_ok && M % SBM == 0 && N % BN == 0 && K % kStage == 0 && K > 0 &&
-        alpha != 0.0) {
+    if (!lower && TA == OP_N && TB == OP_T && aligned && nwg <= kSmallTileMaxTiles && M % SBM == 0 && N % BN == 0 &&
+        K % kStage == 0 && K > 0 && alpha != 0.0) {
         static DeviceFlags small_flags;
         if (raise_dynamic_lds(small_flags, {{reinterpret_cast<const void *>(&gemm_nt_small_kernel<T>), sizeof(SmallSmem)}}) !=
             SSA_OK)
             return SSA_ERR_HIP;
         const int64_t stm = M / SBM, stn = N / BN;
         constexpr int64_t per8 = 8 / sizeof(T);
-        ProfileScope scope(sizeof(T) == 8, lower ? kProfileSyrkLower : kProfileOpNT,
-                           2.0 * static_cast<double>(K) * (lower ? 0.5 * static_cast<double>(M) * (M + 1)
-                                                                  : static_cast<double>(M) * N), st);
+        ProfileScope scope(sizeof(T) == 8, kProfileOpNT, 2.0 * static_cast<double>(K) * static_cast<double>(M) * N, st);
         hipLaunchKernelGGL((gemm_nt_small_kernel<T>), dim3(static_cast<unsigned>(stm * stn)), dim3(kGemmThreads),
                            sizeof(SmallSmem), st, K / per8, static_cast<T>(alpha), reinterpret_cast<const double *>(A),
-                           lda / per8, reinterpret_cast<const double *>(B), ldb / per8, static_cast<T>(beta), C, ldc, stm,
-                           lower);
+                           lda / per8, reinterpret_cast<const double *>(B), ldb / per8, static_cast<T>(beta), C, ldc, stm);
         SSA_RETURN_IF_LAUNCH_FAILED();
         return SSA_OK;
     }
