@@ -3,8 +3,9 @@ get committed under profiles/ (run from the repo root on the box; development ai
 
     python tools/collect_profiles.py <tag> [summary_dir]
 
-Passes (each `rocprofv3 ... -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`, counters in their own
-passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass):
+Passes (each `rocprofv3 ... -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras`, counters in their
+own passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass; the HBM-bound kernels
+from two more passes of tools/hbm_kernels.py):
   stats   --kernel-trace --stats                      -> <tag>_bench_kernel_stats.csv, <tag>_bench.json
   fetch   --pmc FETCH_SIZE --kernel-trace
   write   --pmc WRITE_SIZE --kernel-trace             -> <tag>_syrk_pmc.json, <tag>_hbm_pmc.json
@@ -26,12 +27,12 @@ SYRK = "gemm_op_kernel<double, 0, 1, true>"
 SIMDS, XCDS = 256 * 4, 8
 
 
-def run_pass(name, flags, out_dir, bench_args):
+def run_pass(name, flags, out_dir, bench_args, script="bench.py"):
     d = os.path.join(out_dir, name)
     shutil.rmtree(d, ignore_errors=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", name, "--", "python3",
-           os.path.join(ROOT, "bench.py")] + bench_args
+           os.path.join(ROOT, script)] + bench_args
     p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if p.returncode != 0 or not line:
@@ -63,7 +64,8 @@ def main():
     os.makedirs(prof, exist_ok=True)
     out_dir = os.path.join("/tmp", "ssa_profiles_" + tag)   # raw rocprofv3 output (hundreds of MB) stays on the box
     os.makedirs(out_dir, exist_ok=True)
-    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    # the headline line only (--no-extras): every launch of the profiled run belongs to the timed workload
+    args = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
 
     d, line = run_pass("stats", ["--kernel-trace", "--stats"], out_dir, args)
     shutil.copy(find(d, "kernel_stats.csv"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
@@ -93,14 +95,17 @@ def main():
                 "more than 5 % away from these",
     }, open(os.path.join(prof, f"{tag}_syrk_pmc.json"), "w"), indent=1)
 
-    # HBM-bound kernels from the same two passes
+    # HBM-bound kernels: the same two counters on tools/hbm_kernels.py (dense Q assemblies + the solves' GEMV chain)
     hbm = {}
+    df, _ = run_pass("hbm_fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"], out_dir, [], script="tools/hbm_kernels.py")
+    dw, line = run_pass("hbm_write", ["--pmc", "WRITE_SIZE", "--kernel-trace"], out_dir, [], script="tools/hbm_kernels.py")
+    fcsv, wcsv = find(df, "counter_collection.csv"), find(dw, "counter_collection.csv")
     wq = counter_per_kernel(wcsv, "WRITE_SIZE", "q_assemble_kernel<double")
     tr = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
           for r in rows(find(dw, "kernel_trace.csv")) if "q_assemble_kernel<double" in r["Kernel_Name"]}
     big = sorted(wq)[-5:] if wq else []
     if big:
-        n = line["config"]["vertices_per_film"]
+        n = line["vertices_per_film"]
         ids = [r["Dispatch_Id"] for r in rows(wcsv) if r["Counter_Name"] == "WRITE_SIZE" and "q_assemble_kernel<double" in
                r["Kernel_Name"] and float(r["Counter_Value"]) >= big[0]]
         secs = [tr[i] for i in ids if i in tr]
@@ -118,8 +123,9 @@ def main():
         hbm["gemv_kernel<double, 4, true, 0> (triangular-solve chain, all launches of the run)"] = {
             "launches": len(fg), "FETCH_SIZE_bytes_total_x2": tot_b, "total_ms": tot_s * 1e3,
             "HBM_read_TBps": tot_b / tot_s / 1e12 if tot_s else None}
-    hbm["note"] = ("rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-                   "(dispatches serialized by the profiler); counters in KiB, FETCH x2 on gfx950")
+    hbm["note"] = ("rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of tools/hbm_kernels.py (config H's films: five dense "
+                   "Q assemblies, five 11-pass solves; dispatches serialized by the profiler); counters in KiB, FETCH x2 "
+                   "on gfx950")
     json.dump(hbm, open(os.path.join(prof, f"{tag}_hbm_pmc.json"), "w"), indent=1)
 
     dm, _ = run_pass("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64",
