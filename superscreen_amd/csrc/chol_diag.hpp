@@ -146,19 +146,6 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
 // acc[jt] += sign * A_slab * op(B) for one 16-row slab (rows given by Arow, 64 columns = K) and the
 // four 16-column tiles of a 64 x 64 block B.  BT: op(B) = B^T (B[j][k] row-major), else B[k][j].
 template <typename T, bool BT>
-__device__ __forceinline__ void slab_load_b(T (&b)[16], const T *B, int ldb, int jt, int i, int g) {
-    if (BT) {
-        const T *bp = B + ((16 * jt + i) * ldb + 16 * g);
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) b[kk] = bp[kk];
-    } else {
-        const T *bp = B + (16 * g * ldb + 16 * jt + i);
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) b[kk] = bp[kk * ldb];
-    }
-}
-
-template <typename T, bool BT>
 __device__ __forceinline__ void slab_gemm(typename Mfma<T>::acc_t (&acc)[4], const T *Arow, int lda,
                                           const T *B, int ldb, T sign, int lane) {
     const int i = lane & 15, g = lane >> 4;
@@ -166,15 +153,20 @@ __device__ __forceinline__ void slab_gemm(typename Mfma<T>::acc_t (&acc)[4], con
     const T *ap = Arow + (i * lda + 16 * g);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) a[kk] = sign * ap[kk];
-    // the operands come straight from L2: the next tile's loads are in flight while this tile's 16 MFMAs run
-    // (one tile of B at a time was a load round trip of 1-1.5 us in front of every 0.5 us of MFMA work)
-    T b[2][16];
-    slab_load_b<T, BT>(b[0], B, ldb, 0, i, g);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-        if (jt + 1 < 4) slab_load_b<T, BT>(b[(jt + 1) & 1], B, ldb, jt + 1, i, g);
+        T b[16];
+        if (BT) {
+            const T *bp = B + ((16 * jt + i) * ldb + 16 * g);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) acc[jt] = Mfma<T>::run(a[kk], b[jt & 1][kk], acc[jt]);
+            for (int kk = 0; kk < 16; ++kk) b[kk] = bp[kk];
+        } else {
+            const T *bp = B + (16 * g * ldb + 16 * jt + i);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) b[kk] = bp[kk * ldb];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc[jt] = Mfma<T>::run(a[kk], b[kk], acc[jt]);
     }
 }
 
