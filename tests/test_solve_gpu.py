@@ -830,3 +830,30 @@ def test_self_field_from_the_london_equation():
     assert np.array_equal(with_vortex.film_solutions["disk1"].self_field, ref.film_solutions["disk1"].self_field)
     with pytest.raises(ValueError):
         sc.factorize_model(device=device, current_units="uA", self_field="nope")
+
+
+@pytest.mark.gpu
+def test_hole_without_mesh_vertices_is_tolerated():
+    """A hole polygon that contains no mesh vertex gives an empty hole system (the reference tolerates empty index
+    sets, solver/solve_film.py:209-218, 498-503): factorization and solve go through and equal the hole-free film."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+    from superscreen_amd.device import Device, Layer, Polygon
+
+    base = synthetic.make_stack_device(12, ("disk",), solve_dtype="float64")
+    mesh = base.meshes["disk0"]
+    sites = mesh.sites
+    # a tiny square between the centre vertex and the first ring: no vertex inside
+    c = 0.5 * (sites[0] + sites[1]) + np.array([0.0, 1e-3])
+    tiny = c + 1e-4 * np.array([[-1, -1], [1, -1], [1, 1], [-1, 1], [-1, -1]])
+    film = base.films["disk0"]
+    device = Device("tiny_hole", layers=[Layer("layer0", Lambda=0.1, z0=0.0)],
+                    films=[Polygon("disk0", layer="layer0", points=film.points)],
+                    holes=[Polygon("pinhole", layer="layer0", points=tiny)], length_units="um", solve_dtype="float64")
+    device.meshes = {"disk0": mesh}
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"pinhole": 1.0})
+    assert len(model.hole_systems["disk0"]["pinhole"].indices) == 0
+    assert model.hole_systems["disk0"]["pinhole"].A.shape == (len(sites), 0)
+    got = sc.solve(model=model, applied_field=sc.ConstantField(1.0))[0].film_solutions["disk0"]
+    ref = sc.solve(base, applied_field=sc.ConstantField(1.0))[0].film_solutions["disk0"]
+    assert np.array_equal(got.stream, ref.stream)
