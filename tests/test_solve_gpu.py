@@ -857,3 +857,33 @@ def test_hole_without_mesh_vertices_is_tolerated():
     got = sc.solve(model=model, applied_field=sc.ConstantField(1.0))[0].film_solutions["disk0"]
     ref = sc.solve(base, applied_field=sc.ConstantField(1.0))[0].film_solutions["disk0"]
     assert np.array_equal(got.stream, ref.stream)
+
+
+@pytest.mark.gpu
+def test_lu_route_falls_back_to_partial_pivoting(monkeypatch):
+    """factorize_linear_systems tries the LU without interchanges first and, for a film whose result fails the
+    LAPACK pivot check, assembles the matrix again and factors it with partial pivoting (one stream per film).
+    Here the check is made to fail for every film: the answer must not change."""
+    import superscreen_amd as sc
+    from superscreen_amd import kernels, synthetic
+
+    device = synthetic.make_stack_device(16, ("washer", "disk"), solve_dtype="float64")
+    kw = dict(applied_field=sc.ConstantField(0.6), iterations=2)
+    fast = sc.solve(model=sc.factorize_model(device=device, current_units="uA", method="lu"), **kw)
+    calls = []
+    real = kernels.lu_factor_nopivot_batch
+
+    def rejecting(systems):
+        calls.append(len(systems))
+        real(systems)                       # runs (and clobbers the buffers), but its verdict is overruled
+        return [None] * len(systems)
+
+    monkeypatch.setattr(kernels, "lu_factor_nopivot_batch", rejecting)
+    model = sc.factorize_model(device=device, current_units="uA", method="lu")
+    assert calls == [2]
+    slow = sc.solve(model=model, **kw)
+    for a, b in zip(fast, slow):
+        for nm in device.films:
+            assert relerr(b.film_solutions[nm].stream, a.film_solutions[nm].stream) < 1e-12
+    lu, piv = model.film_systems["disk1"].lu_piv
+    assert np.array_equal(piv, np.arange(len(piv))) and lu.shape == (len(piv), len(piv))
