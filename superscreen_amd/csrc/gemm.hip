@@ -177,6 +177,111 @@ __device__ __forceinline__ void gemm_tile_full_f64(int64_t K, double alpha, cons
                 Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
 }
 
+// FULL path, float32, NN.  Stage = 32 k.  A as in the NT kernel of gemm_ops.hip: 8-byte views (pairs of
+// consecutive k), the f64 image and swizzle, every LDS read feeds two v_mfma_f32_16x16x4_f32 (k even / k odd).
+// B [32 k][128 n] floats, two k-rows (1 KiB) per LDS-DMA instruction, unpadded (the DMA writes 1 KiB
+// contiguously); the two MFMAs of a pair read rows 2 p and 2 p + 1.  Lanes 0-15 and 16-31 of a read (lk = 0, 1)
+// touch rows two apart = 256 floats = the same banks: the 16-byte chunks of a row are stored XOR 4 * (p & 1)
+// (a shift by 16 banks), applied to the per-lane SOURCE address and to the read address.
+struct FullSmemF32 {
+    double a[2][BM * KC];
+    float b[2][2 * KC * BN];
+};
+
+__device__ __forceinline__ void gemm_tile_full_f32(int64_t K, float alpha, const float *__restrict__ A, int64_t lda,
+                                                   const float *__restrict__ B, int64_t ldb, float beta,
+                                                   float *__restrict__ C, int64_t ldc, int64_t m0, int64_t n0,
+                                                   char *smem_raw) {
+    using MF = Mfma<float>;
+    using acc_t = MF::acc_t;
+    FullSmemF32 &sm = *reinterpret_cast<FullSmemF32 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const double *A8 = reinterpret_cast<const double *>(A);
+    const int64_t lda8 = lda / 2;
+    const int a_sub = lane >> 3, a_kpos = (lane & 7) * 2;
+    const double *a_src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = 8 * (wave + 4 * u) + a_sub;
+        a_src[u] = A8 + (m0 + row) * lda8 + (a_kpos ^ (2 * ((row >> 1) & 7)));
+    }
+    // B: instruction t = wave + 4 u covers k-rows 2 t, 2 t + 1 (pair p = t); lane -> row 2 t + lane / 32, LDS chunk
+    // lane % 32, source chunk (lane % 32) ^ 4 (p & 1)
+    const float *b_src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = wave + 4 * u;
+        b_src[u] = B + static_cast<int64_t>(2 * t + (lane >> 5)) * ldb + n0 + 4 * ((lane & 31) ^ (4 * (t & 1)));
+    }
+    auto issue_stage = [&](int64_t kt, int buf) {   // kt counts stages of 32 k
+#pragma unroll
+        for (int u = 0; u < 4; ++u) glds16(a_src[u] + kt * KC, &sm.a[buf][8 * (wave + 4 * u) * KC]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) glds16(b_src[u] + kt * (2 * KC) * ldb, &sm.b[buf][(wave + 4 * u) * 2 * BN]);
+    };
+    issue_stage(0, 0);
+    acc_t acc[4][4];
+    float *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
+    if (beta != 0.0f) {
+        const float scale = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int swz = 2 * ((li >> 1) & 7);
+    const int64_t nk = K / (2 * KC);
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = static_cast<int>(kt & 1);
+        if (kt + 1 < nk) issue_stage(kt + 1, cur ^ 1);
+        const double *sa = &sm.a[cur][(wm * 64 + li) * KC];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            const int p = ks * 4 + lk;                       // k pair of this lane
+            float2 fa[4];
+            float fe[4], fo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(float2, sa[i * 16 * KC + (p ^ swz)]);
+            const float *sb = &sm.b[cur][2 * p * BN];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = wn * 64 + j * 16 + li;
+                const int pos = 4 * ((col >> 2) ^ (4 * (p & 1))) + (col & 3);
+                fe[j] = sb[pos];
+                fo[j] = sb[BN + pos];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = MF::run(fa[i].x, fe[j], acc[i][j]);
+                    acc[i][j] = MF::run(fa[i].y, fo[j], acc[i][j]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+}
+
 // ---------------------------------------------------------------------------------------
 // EDGE path: guarded everywhere
 // ---------------------------------------------------------------------------------------
@@ -342,11 +447,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_kernel(
         B += kb * ldb;
         K -= kb;
     }
-    const bool full = ALIGNED && sizeof(T) == 8 && (m0 + BM <= M) && (n0 + BN <= N) &&
-                      (K % KC == 0) && (K > 0) && alpha != T(0);
+    constexpr int64_t kStageK = (sizeof(T) == 8) ? KC : 2 * KC;
+    const bool full = ALIGNED && (m0 + BM <= M) && (n0 + BN <= N) && (K % kStageK == 0) && (K > 0) && alpha != T(0);
     if (full) {
         if constexpr (sizeof(T) == 8)
             gemm_tile_full_f64(K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
+        else
+            gemm_tile_full_f32(K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, smem_raw);
     } else {
         gemm_tile_edge<T, ALIGNED>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, m0, n0, sm);
     }
@@ -358,7 +465,8 @@ int launch_gemm(int64_t M, int64_t N, int64_t K, double alpha, const void *A, in
                 int batch1 = 1, int batch2 = 1, BatchStrides bs = BatchStrides{0, 0, 0, 0, 0, 0, 0}) {
     if (M <= 0 || N <= 0 || batch1 <= 0 || batch2 <= 0) return SSA_OK;
     const int64_t ntm = ceil_div(M, BM), ntn = ceil_div(N, BN);
-    const size_t smem = sizeof(GemmSmem<T>);
+    const size_t smem = (sizeof(T) == 4 && sizeof(FullSmemF32) > sizeof(GemmSmem<T>)) ? sizeof(FullSmemF32)
+                                                                                         : sizeof(GemmSmem<T>);
     const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
                          ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0) &&
