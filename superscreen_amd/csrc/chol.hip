@@ -23,6 +23,7 @@
 // (x_k = inv_k b_k;  b_rest -= L[rest, k] x_k), with no transposed access and no per-row dependency.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <utility>
 
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
 // with its two events, and a low-priority stream on which a matrix that is done before the others
 // (a smaller film) builds its solve-phase blocks while the tail of the others still runs.
 struct CholLane {
-    hipStream_t side = nullptr, finish = nullptr, upd = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr, finish = nullptr, upd = nullptr;
     hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr,
-               ev_upd = nullptr;
+               ev_upd = nullptr, ev_diag = nullptr, ev_top = nullptr, ev_below = nullptr;
 };
 constexpr int kMaxLanes = 16;
 
@@ -230,6 +231,10 @@ inline int get_lanes(int count, LaneSet **out) {
     for (int i = 0; i < count; ++i) {
         if (lanes[i].side != nullptr) continue;
         if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&lanes[i].side2, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_diag, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_top, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_below, hipEventDisableTiming) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].finish, hipStreamNonBlocking, lo) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_upd, hipEventDisableTiming) != hipSuccess ||
@@ -252,14 +257,15 @@ inline int destroy_lanes() {
         std::lock_guard<std::mutex> enq(g_lane_sets[d].enqueue);
         for (CholLane &ln : g_lane_sets[d].lanes) {
             if (ln.side == nullptr) continue;
-            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.finish) != hipSuccess ||
-                hipStreamSynchronize(ln.upd) != hipSuccess)
+            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.side2) != hipSuccess ||
+                hipStreamSynchronize(ln.finish) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess)
                 rc = SSA_ERR_HIP;
-            hipEvent_t evs[6] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk, ln.ev_upd};
+            hipEvent_t evs[9] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk,
+                                 ln.ev_upd,   ln.ev_diag,  ln.ev_top,  ln.ev_below};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.finish) != hipSuccess ||
-                hipStreamDestroy(ln.upd) != hipSuccess)
+            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.side2) != hipSuccess ||
+                hipStreamDestroy(ln.finish) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess)
                 rc = SSA_ERR_HIP;
             ln = CholLane{};
         }
@@ -275,34 +281,40 @@ struct CholJob {
     T *aux;
 };
 
-// One outer panel of one matrix: the diagonal-block kernel (L11 and W = L11^-1, chol_diag.hpp),
-// then L21 = A21 W^T as two in-place MFMA GEMMs.  W is lower triangular, so columns 128..255 of L21
-// need all 256 columns of A21 (done first) and columns 0..127 only the first 128; every workgroup
-// reads and writes its own 128 rows, which makes the in-place update safe (beta = 0: C is not read).
+// One outer panel of one matrix in pieces: the diagonal-block kernel (L11 and W = L11^-1, chol_diag.hpp) and
+// L21 = A21 W^T for a range of rows as two in-place MFMA GEMMs.  W is lower triangular, so columns 128..255 of
+// L21 need all 256 columns of A21 (done first) and columns 0..127 only the first 128; every workgroup reads and
+// writes its own rows, which makes the in-place update safe (beta = 0: C is not read).
 // W lands in the solve-phase buffer: it is the inverted 256-leaf of the SNB block inverses.
 template <typename T>
-int chol_factor_panel(const CholJob<T> &J, int64_t k0, hipStream_t s) {
+T *chol_leaf(const CholJob<T> &J, int64_t k0) {
+    return J.aux + (k0 / SNB) * SNB * SNB + (k0 % SNB) * (SNB + 1);
+}
+template <typename T>
+int chol_panel_diag(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     const int64_t n = J.n, lda = J.lda;
     T *scratch = J.aux + aux_layout(n).scratch;
-    T *W = J.aux + (k0 / SNB) * SNB * SNB + (k0 % SNB) * (SNB + 1);
     if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
-    static DeviceFlags lds_flags;  // > 64 KB of dynamic LDS needs an explicit opt-in, per device
+    static DeviceFlags lds_flags;
     if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<T>),
                                        sizeof(cholk::Ge64Smem<T>)}}) != SSA_OK)
         return SSA_ERR_HIP;
     hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), sizeof(cholk::Ge64Smem<T>), s,
-                       J.A + k0 * (lda + 1),
-                       static_cast<int>(lda), W, static_cast<int>(SNB), scratch, J.info, static_cast<int>(k0 + 1));
+                       J.A + k0 * (lda + 1), static_cast<int>(lda), chol_leaf(J, k0), static_cast<int>(SNB), scratch,
+                       J.info, static_cast<int>(k0 + 1));
     SSA_RETURN_IF_LAUNCH_FAILED();
-    const int64_t M = n - k0 - CNB;
-    if (M > 0) {
-        T *A21 = J.A + (k0 + CNB) * lda + k0;
-        int rc = gemm_op_t(0, 1, 0, M, 128, 256, 1.0, A21, lda, W + 128 * SNB, SNB, 0.0, A21 + 128, lda, s);
-        if (rc != SSA_OK) return rc;
-        rc = gemm_op_t(0, 1, 0, M, 128, 128, 1.0, A21, lda, W, SNB, 0.0, A21, lda, s);
-        if (rc != SSA_OK) return rc;
-    }
     return SSA_OK;
+}
+// rows [r0, r1) of the panel at column k0 (r0 >= k0 + CNB)
+template <typename T>
+int chol_panel_rows(const CholJob<T> &J, int64_t k0, int64_t r0, int64_t r1, hipStream_t s) {
+    const int64_t lda = J.lda, M = r1 - r0;
+    if (M <= 0) return SSA_OK;
+    const T *W = chol_leaf(J, k0);
+    T *A21 = J.A + r0 * lda + k0;
+    int rc = gemm_op_t(0, 1, 0, M, 128, 256, 1.0, A21, lda, W + 128 * SNB, SNB, 0.0, A21 + 128, lda, s);
+    if (rc != SSA_OK) return rc;
+    return gemm_op_t(0, 1, 0, M, 128, 128, 1.0, A21, lda, W, SNB, 0.0, A21, lda, s);
 }
 
 // Finishing passes (solve-phase data), each over a range so that most of them can be slipped into
@@ -458,9 +470,18 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (hipEventRecord(ln.ev_strip, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
             return SSA_ERR_HIP;
         if (split_updates && hipStreamWaitEvent(ln.upd, ln.ev_strip, 0) != hipSuccess) return SSA_ERR_HIP;
-        rc = chol_factor_panel(J, 0, ln.side);
+        if (hipStreamWaitEvent(ln.side2, ln.ev_strip, 0) != hipSuccess) return SSA_ERR_HIP;
+        rc = chol_panel_diag(J, 0, ln.side);
         if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+        if (hipEventRecord(ln.ev_diag, ln.side) != hipSuccess) return SSA_ERR_HIP;
+        rc = chol_panel_rows(J, 0, CNB, std::min<int64_t>(2 * CNB, J.n), ln.side);
+        if (rc != SSA_OK) return rc;
+        if (hipEventRecord(ln.ev_top, ln.side) != hipSuccess || hipStreamWaitEvent(ln.side2, ln.ev_diag, 0) != hipSuccess)
+            return SSA_ERR_HIP;
+        rc = chol_panel_rows(J, 0, 2 * CNB, J.n, ln.side2);
+        if (rc != SSA_OK) return rc;
+        if (hipStreamWaitEvent(ln.side2, ln.ev_top, 0) != hipSuccess || hipEventRecord(ln.ev_panel, ln.side2) != hipSuccess)
+            return SSA_ERR_HIP;
     }
     bool detached[kMaxLanes] = {};
     int64_t pending_from[kMaxLanes] = {};
@@ -501,15 +522,38 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             const T *P = J.A + (k0 + CNB) * J.lda + pend0;    // those panels below the diagonal block of panel k
             T *C = J.A + (k0 + CNB) * J.lda + (k0 + CNB);
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
-            // the strip runs on the chain's own stream, behind panel k (same stream) and behind the last
-            // trailing update of THIS matrix (which wrote the strip's columns): it does not queue behind
-            // the other matrices' updates on the caller's stream
+            // The chain of a matrix is two streams (diagonal look-ahead).  What the NEXT diagonal block needs of
+            // panel k is only its first block row, so per panel the critical recurrence is
+            //     diagonal block update (256 x 256 x kp) -> diagonal-block kernel -> first block row of the panel
+            // on ln.side, while ln.side2 applies the pending panels to the rows below (the strip) and computes the
+            // rest of the panel, one step behind; neither queues behind the other matrices' updates, both wait for
+            // the last trailing update of THIS matrix (which wrote the strip's columns).  The strip and the panel
+            // rows were on the one chain stream before: 0.6 ms per panel in the chain-bound tail instead of ...
+            const int64_t c = k0 + CNB;
+            if (right > nw) {   // strip, rows below the diagonal block: behind panel k (all rows) on this stream
+                if (syrk_recorded[i] && hipStreamWaitEvent(ln.side2, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
+                rc = gemm_op_t(0, 1, 0, right - nw, nw, kp, -1.0, P + nw * J.lda, J.lda, P, J.lda, 1.0, C + nw * J.lda,
+                               J.lda, ln.side2);
+                if (rc != SSA_OK) return rc;
+                if (hipEventRecord(ln.ev_below, ln.side2) != hipSuccess) return SSA_ERR_HIP;
+            }
             if (syrk_recorded[i] && hipStreamWaitEvent(ln.side, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
-            rc = gemm_op_t(0, 1, 0, right, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, ln.side);
+            rc = gemm_op_t(0, 1, 0, nw, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, ln.side);
             if (rc != SSA_OK) return rc;
-            rc = chol_factor_panel(J, k0 + CNB, ln.side);
+            rc = chol_panel_diag(J, c, ln.side);
             if (rc != SSA_OK) return rc;
-            if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+            if (hipEventRecord(ln.ev_diag, ln.side) != hipSuccess) return SSA_ERR_HIP;
+            if (right > nw) {
+                if (hipStreamWaitEvent(ln.side, ln.ev_below, 0) != hipSuccess) return SSA_ERR_HIP;
+                rc = chol_panel_rows(J, c, c + CNB, std::min<int64_t>(c + 2 * CNB, J.n), ln.side);
+                if (rc != SSA_OK) return rc;
+            }
+            if (hipEventRecord(ln.ev_top, ln.side) != hipSuccess || hipStreamWaitEvent(ln.side2, ln.ev_diag, 0) != hipSuccess)
+                return SSA_ERR_HIP;
+            rc = chol_panel_rows(J, c, c + 2 * CNB, J.n, ln.side2);
+            if (rc != SSA_OK) return rc;
+            if (hipStreamWaitEvent(ln.side2, ln.ev_top, 0) != hipSuccess || hipEventRecord(ln.ev_panel, ln.side2) != hipSuccess)
+                return SSA_ERR_HIP;
             // every other panel of a large trailing matrix keeps its update pending: the next one then
             // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
             // (the phase comes from the matrix' own size, not from its place in the batch: the result

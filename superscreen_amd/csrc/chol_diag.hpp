@@ -53,9 +53,9 @@ template <typename T>
 struct Ge64Smem {
     T cb[2][4][32 + 2];
     T mb[2][4][16 + 2];
-    T lout[64][64 + 1];  // the block on its way in, the finished columns of L on their way out
-    T wout[64][64 + 1];  // W_ss on its way out
-};
+    T lout[64][64 + 1];  // the block on its way in, then the finished columns of L and W_ss in turn on their way out
+};  // 36 KB (float64): small on purpose -- beside the CU-holding placeholder of the schedule (cu_hold_kernel,
+    // common.hpp) the kernel must fit where a 64+ KB GEMM workgroup does not
 
 // [L, W] of the 64 x 64 block at D (leading dimension ld); L overwrites the lower triangle of D,
 // W (full block, zero above the diagonal) goes to Wout.  All 256 threads.
@@ -132,14 +132,21 @@ __device__ __forceinline__ void ge64(T *D, int ld, T *Wout, int ldw, Ge64Smem<T>
         for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
         a[15] = T(0);
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i] * myinv;
+    // results leave through the one LDS tile in whole 512-byte rows: L, then W
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int rr = wave + 4 * it;
         if (lane <= rr) D[rr * ld + lane] = sm.lout[rr][lane];
-        Wout[rr * ldw + lane] = sm.wout[rr][lane];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm.lout[r][4 * i + q] = m[i] * myinv;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = wave + 4 * it;
+        Wout[rr * ldw + lane] = sm.lout[rr][lane];
     }
 }
 
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void chol_diag256_kernel(T *D, int lda, T *
                                                            , long long *tstamp
 #endif
 ) {
-    extern __shared__ __attribute__((aligned(16))) char cholk_smem_raw[];  // sizeof(Ge64Smem<T>), > 64 KB
+    extern __shared__ __attribute__((aligned(16))) char cholk_smem_raw[];  // sizeof(Ge64Smem<T>)
     Ge64Smem<T> &sm = *reinterpret_cast<Ge64Smem<T> *>(cholk_smem_raw);
     const int wave = threadIdx.x >> 6;
     using acc_t = typename Mfma<T>::acc_t;

@@ -24,6 +24,8 @@
 // i?amax does -- is what ?getf2 would produce.  Inter-workgroup hand-offs follow the CDNA4
 // recipe: sc1 payload stores, per-wave vmcnt(0) drain, relaxed agent-scope counter,
 // relaxed poll, sc1 loads; every spin is bounded.
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 
@@ -569,8 +571,45 @@ int lu_block_inverse(const T *A, int64_t lda, int64_t r0, int64_t sz, T *inv, in
     return gemm_t<T>(h, r, h, -1.0, inv, ldi, tmp, r, 0.0, inv + h, ldi, st);
 }
 
+// The block inverses of the full LSB blocks [b0, b1) of L and U from their inverted 256-leaves, level by level
+// (pairs of h-blocks -> 2h-blocks), all pairs of all blocks of a level in one batched launch.
 template <typename T>
-int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_t st, bool leaves_done = false) {
+int lu_finish_full_blocks(const T *A, int64_t n, int64_t lda, T *aux, int64_t b0, int64_t b1, hipStream_t st) {
+    const LuAux al = lu_aux_layout(n);
+    if (b0 < 0 || b1 > al.nfull || b0 >= b1) return SSA_OK;
+    const int nb = static_cast<int>(b1 - b0);
+    const T *A0 = A + b0 * LSB * (lda + 1);
+    T *invL = aux + al.invL + b0 * LSB * LSB, *invU = aux + al.invU + b0 * LSB * LSB;
+    T *tmp = aux + al.tmp + b0 * (LSB * LSB / 4);
+    int rc;
+    for (int64_t h = NB; h < LSB; h *= 2) {
+        const int ppb = static_cast<int>(LSB / (2 * h));
+        const int64_t pair_l = 2 * h * (lda + 1), blk_l = LSB * (lda + 1);
+        const int64_t pair_i = 2 * h * (LSB + 1), blk_i = LSB * LSB;
+        const int64_t pair_t = h * h, blk_t = LSB * LSB / 4;
+        const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+        const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
+        // L: tmp = L21 inv11 ; inv21 = -inv22 tmp
+        rc = gemm_batched_x(h, h, h, 1.0, A0 + h * lda, lda, invL, LSB, 0.0, tmp, h, ppb, nb, s1, 1, st);
+        if (rc != SSA_OK) return rc;
+        rc = gemm_batched_x(h, h, h, -1.0, invL + h * (LSB + 1), LSB, tmp, h, 0.0, invL + h * LSB, LSB, ppb, nb, s2, 2,
+                            st);
+        if (rc != SSA_OK) return rc;
+        // U: tmp = U12 inv22 ; inv12 = -inv11 tmp
+        const int64_t s3[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+        rc = gemm_batched_x(h, h, h, 1.0, A0 + h, lda, invU + h * (LSB + 1), LSB, 0.0, tmp, h, ppb, nb, s3, 3, st);
+        if (rc != SSA_OK) return rc;
+        rc = gemm_batched_x(h, h, h, -1.0, invU, LSB, tmp, h, 0.0, invU + h, LSB, ppb, nb, s2, 4, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
+// first_block: the full blocks below it were finished earlier (lu_finish_full_blocks, the no-interchange route
+// finishes a block as soon as its last panel is factored)
+template <typename T>
+int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_t st, bool leaves_done = false,
+                          int64_t first_block = 0) {
     const LuAux al = lu_aux_layout(n);
     T *invL = aux + al.invL, *invU = aux + al.invU, *tmp = aux + al.tmp;
     int rc;
@@ -600,29 +639,8 @@ int lu_build_solve_blocks(const T *A, int64_t n, int64_t lda, T *aux, hipStream_
                                         kb, kb, 1, st);
         if (rc != SSA_OK) return rc;
     }
-    if (al.nfull > 0) {
-        const int nb = static_cast<int>(al.nfull);
-        for (int64_t h = NB; h < LSB; h *= 2) {
-            const int ppb = static_cast<int>(LSB / (2 * h));
-            const int64_t pair_l = 2 * h * (lda + 1), blk_l = LSB * (lda + 1);
-            const int64_t pair_i = 2 * h * (LSB + 1), blk_i = LSB * LSB;
-            const int64_t pair_t = h * h, blk_t = LSB * LSB / 4;
-            const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
-            const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
-            // L: tmp = L21 inv11 ; inv21 = -inv22 tmp
-            rc = gemm_batched_x(h, h, h, 1.0, A + h * lda, lda, invL, LSB, 0.0, tmp, h, ppb, nb, s1, 1, st);
-            if (rc != SSA_OK) return rc;
-            rc = gemm_batched_x(h, h, h, -1.0, invL + h * (LSB + 1), LSB, tmp, h, 0.0, invL + h * LSB, LSB, ppb, nb, s2,
-                                2, st);
-            if (rc != SSA_OK) return rc;
-            // U: tmp = U12 inv22 ; inv12 = -inv11 tmp
-            const int64_t s3[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
-            rc = gemm_batched_x(h, h, h, 1.0, A + h, lda, invU + h * (LSB + 1), LSB, 0.0, tmp, h, ppb, nb, s3, 3, st);
-            if (rc != SSA_OK) return rc;
-            rc = gemm_batched_x(h, h, h, -1.0, invU, LSB, tmp, h, 0.0, invU + h, LSB, ppb, nb, s2, 4, st);
-            if (rc != SSA_OK) return rc;
-        }
-    }
+    rc = lu_finish_full_blocks<T>(A, n, lda, aux, first_block, al.nfull, st);
+    if (rc != SSA_OK) return rc;
     if (n % LSB != 0) {
         const int64_t r0 = al.nfull * LSB;
         T *t2 = tmp + al.nfull * (LSB * LSB / 4);
@@ -834,8 +852,8 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 // as info = -2 and the caller factors the matrix again with ssa_lu_factor (full partial pivoting).
 constexpr int kMaxLuLanes = 16;
 struct LuLane {
-    hipStream_t side = nullptr, upd = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr;
+    hipStream_t side = nullptr, upd = nullptr, fin = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr, ev_fin = nullptr;
 };
 struct LuLaneSet {
     LuLane lanes[kMaxLuLanes];
@@ -855,6 +873,8 @@ inline int get_lu_lanes(int count, LuLaneSet **out) {
         if (lanes[i].side != nullptr) continue;
         if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
+            hipStreamCreateWithPriority(&lanes[i].fin, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_fin, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_rest, hipEventDisableTiming) != hipSuccess ||
@@ -872,11 +892,15 @@ int lu_shutdown() {
         std::lock_guard<std::mutex> enq(g_lu_lane_sets[d].enqueue);
         for (LuLane &ln : g_lu_lane_sets[d].lanes) {
             if (ln.side == nullptr) continue;
-            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
-            hipEvent_t evs[4] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd};
+            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess ||
+                hipStreamSynchronize(ln.fin) != hipSuccess)
+                rc = SSA_ERR_HIP;
+            hipEvent_t evs[5] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd, ln.ev_fin};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
+            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess ||
+                hipStreamDestroy(ln.fin) != hipSuccess)
+                rc = SSA_ERR_HIP;
             ln = LuLane{};
         }
     }
@@ -1027,6 +1051,9 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     constexpr int kDelayDepth = 2;            // as in the Cholesky schedule: two panels per trailing update
     constexpr int64_t kDelayMinCols = 8192;   // while the trailing matrix is large
     int64_t pending_from[kMaxLuLanes] = {};
+    int64_t blocks_finished[kMaxLuLanes] = {};
+    const char *fin_env = getenv("SSA_LU_EARLY_FINISH");   // development switch: 0 = all block inverses after the last panel
+    const bool early_finish = fin_env == nullptr || fin_env[0] != '0';
     bool rest_recorded[kMaxLuLanes] = {};
     for (int64_t k0 = 0; k0 + NB < nmax; k0 += NB) {
         for (int i = 0; i < count; ++i) {
@@ -1061,6 +1088,18 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
                 rest_recorded[i] = true;
             }
             if (!delay) pending_from[i] = k0 + NB;
+            // The block inverses of the solve phase (lu_finish_full_blocks) of the LSB blocks whose panels are all
+            // factored: on a low-priority stream of their own once the factorization is bound by its panel chain
+            // (trailing matrix below kDelayMinCols: the chip is mostly idle then), instead of after the last panel,
+            // where nothing hides them.  (Behind the trailing updates on ln.upd they delay the next panel by their
+            // 3 ms per block; earlier, beside the large updates, they slow the chains: both measured)
+            const int64_t blocks_closed = std::min((k0 + NB) / LSB, J.n / LSB);
+            if (early_finish && right <= kDelayMinCols && blocks_closed > blocks_finished[i]) {
+                if (hipStreamWaitEvent(ln.fin, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+                rc = lu_finish_full_blocks<T>(J.A, J.n, J.lda, J.aux, blocks_finished[i], blocks_closed, ln.fin);
+                if (rc != SSA_OK) return rc;
+                blocks_finished[i] = blocks_closed;
+            }
         }
     }
     // Every matrix finishes on its own update stream (behind its last panel and its last trailing update): the
@@ -1068,11 +1107,13 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     for (int i = 0; i < count; ++i) {
         const NpJob<T> &J = jobs[i];
         LuLane &ln = lanes[i];
-        if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+        if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess || hipEventRecord(ln.ev_fin, ln.fin) != hipSuccess ||
+            hipStreamWaitEvent(ln.upd, ln.ev_fin, 0) != hipSuccess)
+            return SSA_ERR_HIP;
         hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, ln.upd,
                            J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info, J.ipiv);
         SSA_RETURN_IF_LAUNCH_FAILED();
-        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, ln.upd, true);
+        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, ln.upd, true, blocks_finished[i]);
         if (rc != SSA_OK) return rc;
         if (hipEventRecord(ln.ev_upd, ln.upd) != hipSuccess || hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess)
             return SSA_ERR_HIP;

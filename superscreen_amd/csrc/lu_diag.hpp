@@ -6,13 +6,16 @@
 // straight-line code that runs at instruction-fetch speed: 70 us alone, 460 us beside a trailing update),
 // rotating register arrays, MFMA block products with operands straight from L2:
 //
-//   for s = 0..3:  [L_ss \ U_ss, WL_ss] = ge64_lu(D_ss)      Gaussian elimination on [D_ss | I], registers,
-//                                                            one LDS hop + one barrier per column
-//                  WU_ss = I U_ss^-1,  L_is = D_is U_ss^-1   row-wise substitution against the static U_ss in
-//                                          (i > s)           LDS: NO barrier (every row is independent)
+//   for s = 0..3:  [L_ss \ U_ss, WL_ss, WU_ss] = ge64_lu(D_ss)   Gaussian elimination on [D_ss | I] in registers,
+//                                                            one LDS hop + one barrier per column, with the
+//                                                            substitution X U_ss = I fused into the same loop
+//                  L_is = D_is WU_ss                (i > s)  MFMA
 //                  U_sj = WL_ss D_sj                (j > s)  MFMA
 //                  D_ij -= L_is U_sj             (i, j > s)  MFMA
 //   for d = 1..3:  WL_ij = -WL_ii sum_t L_it WL_tj  (i - j = d),   WU_ij = -WU_ii sum_t U_it WU_tj  (j - i = d)
+//
+// (The first version ran the substitutions U_ss^-1 and D_is U_ss^-1 as ten more 64-step loops per launch:
+// 1.1 ms per launch beside the trailing updates, the bottleneck of the whole route.)
 //
 // LAPACK's partial pivoting would keep every diagonal entry iff no multiplier exceeds 1 in magnitude; the
 // multipliers are the entries of L, which np_check_kernel inspects on the finished factor, so nothing is
@@ -35,10 +38,9 @@ template <typename T>
 struct LuSmem {
     T ra[2][4][16 + 2];   // row J of the D half   (slot k of residue q: column 4 (I0 + k) + q)
     T mb[2][4][16 + 2];   // row J of the eliminated identity (absolute slot i: column 4 i + q)
-    T lout[64][64 + 1];   // the block on its way in; L \ U of the block on its way out; U for the substitutions
-    T wout[64][64 + 1];   // staging of results on their way out
-    T rdiag[64];          // 1 / u_JJ
-};
+    T lout[64][64 + 1];   // the block on its way in, then L \ U, WL, WU in turn on their way out
+};  // 36 KB (float64): small on purpose -- beside the CU-holding placeholder of the schedule (cu_hold_kernel,
+    // common.hpp) the kernel must fit where a 64+ KB GEMM workgroup does not
 
 // broadcast of lane (4 * (lane / 4) + S) inside every quad (DPP quad_perm), 64- and 32-bit payloads
 template <int S>
@@ -80,11 +82,16 @@ __device__ __forceinline__ float rcp_acc(float x) {
     return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
 }
 
-// L \ U of the 64 x 64 block at D (overwritten, also left in sm.lout), WL = L^-1 (unit lower, full block with
-// zeros above the diagonal) to Wout, reciprocals of the pivots in sm.rdiag.  All 256 threads: thread (r, q)
-// holds columns q + 4 i of row r of [D | I].
+// L \ U of the 64 x 64 block at D (overwritten), WL = L^-1 (unit lower) to WLout and WU = U^-1 (upper) to WUout,
+// both as full blocks with zeros in the other triangle.  All 256 threads: thread (r, q) holds columns q + 4 i
+// of row r of [D | I | I].  The third part is the row-wise substitution X U = I fused into the elimination: at
+// column J the row J of U that every thread reads anyway (sm.ra) is final, x_rJ = b_rJ / u_JJ is passed round the
+// quad by DPP like the multiplier, and the rest of the row of X updated with the same LDS operands -- U^-1 costs
+// 16 more FMAs per column instead of a second 64-step loop.  The register array of X is rotated like the D
+// half, with the finished entry of every fourth column parked in the slot that falls off the end (the published
+// row is zero there: the parked values are left alone), so that after 16 rotations b[i] is column 4 i + q.
 template <typename T>
-__device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T> &sm, bool &bad) {
+__device__ __forceinline__ void ge64_lu(T *D, int ld, T *WLout, T *WUout, int ldw, LuSmem<T> &sm, bool &bad) {
     const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
     const int lane = t & 63, wave = t >> 6;
     {   // all 16 row loads of a wave in flight at once (a rolled loop waits for every load in turn)
@@ -95,11 +102,12 @@ __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T
         for (int it = 0; it < 16; ++it) sm.lout[wave + 4 * it][lane] = tmp[it];
     }
     __syncthreads();
-    T a[16], m[16];
+    T a[16], m[16], b[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         a[i] = sm.lout[r][q + 4 * i];
         m[i] = (q + 4 * i == r) ? T(1) : T(0);
+        b[i] = m[i];
     }
     __syncthreads();
 #pragma unroll 1
@@ -117,92 +125,80 @@ __device__ __forceinline__ void ge64_lu(T *D, int ld, T *Wout, int ldw, LuSmem<T
             __syncthreads();
             const T pv = sm.ra[par][S][0];
             bad = bad || (pv == T(0));
-            const T acol = quad_bcast_s<T>(a[0], S);                 // this row's entry in column J
-            const T l = (r > J) ? acol * rcp_acc(pv) : T(0);    // multiplier
+            const T rp = rcp_acc(pv);
+            const T acol = quad_bcast_s<T>(a[0], S);      // this row's entry in column J of D ...
+            const T bcol = quad_bcast_s<T>(b[0], S);      // ... and of the right-hand side of X U = I
+            const T l = (r > J) ? acol * rp : T(0);       // multiplier
+            const T x = (r <= J) ? bcol * rp : T(0);      // x_rJ (rows below J: zero, X is upper triangular)
             {   // slot 0 = column group I0: column 4 I0 + q is J iff q == S, right of J iff q > S
-                const T upd = a[0] - l * sm.ra[par][q][0];
+                const T u0 = sm.ra[par][q][0];
+                const T upd = a[0] - l * u0, updb = b[0] - x * u0;
                 a[0] = (q > S) ? upd : ((q == S && r > J) ? l : a[0]);
+                b[0] = (q > S) ? updb : ((q == S) ? x : b[0]);
             }
 #pragma unroll
-            for (int k = 1; k < 16; ++k) a[k] -= l * sm.ra[par][q][k];
+            for (int k = 1; k < 16; ++k) {
+                const T u = sm.ra[par][q][k];
+                a[k] -= l * u;
+                b[k] -= x * u;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) m[i] -= l * sm.mb[par][q][i];
         }
         sm.lout[r][4 * I0 + q] = a[0];
+        const T done = b[0];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
+        for (int k = 0; k < 15; ++k) {
+            a[k] = a[k + 1];
+            b[k] = b[k + 1];
+        }
         a[15] = T(0);
+        b[15] = done;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sm.wout[r][4 * i + q] = m[i];
+    // results leave through the one LDS tile in whole 512-byte rows: L \ U, then WL, then WU
     __syncthreads();
-    if (t < 64) {
-        const T d = sm.lout[t][t];
-        sm.rdiag[t] = (d != T(0)) ? rcp_acc(d) : T(1);
-    }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int rr = wave + 4 * it;
         D[rr * ld + lane] = sm.lout[rr][lane];
-        Wout[rr * ldw + lane] = sm.wout[rr][lane];
-    }
-    __syncthreads();
-}
-
-// X = B U^-1 for the 64 x 64 upper triangular U in sm.lout (diagonal included; reciprocals in sm.rdiag) and a
-// 64-row block B: thread (r, q) owns columns q + 4 i of row r.  Column by column, x_J = b_J / u_JJ is passed
-// round the quad by DPP and the rest of the row updated with row J of U from LDS -- U does not change, so no
-// barrier is needed inside the loop.  B = identity if Bsrc == nullptr (X = U^-1).  X goes to Xdst (may alias Bsrc).
-template <typename T>
-__device__ __forceinline__ void trsm_right_upper64(const T *Bsrc, int ldb, T *Xdst, int ldx, LuSmem<T> &sm) {
-    const int t = opaque(threadIdx.x), r = t >> 2, q = t & 3;
-    const int lane = t & 63, wave = t >> 6;
-    if (Bsrc != nullptr) {
-        T tmp[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) tmp[it] = Bsrc[(wave + 4 * it) * ldb + lane];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) sm.wout[wave + 4 * it][lane] = tmp[it];
-        __syncthreads();
-    }
-    T b[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) b[i] = (Bsrc != nullptr) ? sm.wout[r][q + 4 * i] : ((q + 4 * i == r) ? T(1) : T(0));
-    __syncthreads();
-#pragma unroll 1
-    for (int I0 = 0; I0 < 16; ++I0) {
-#pragma unroll
-        for (int S = 0; S < 4; ++S) {
-            const int J = 4 * I0 + S;
-            const T x = quad_bcast_s<T>(b[0], S) * sm.rdiag[J];
-            {
-                const T upd = b[0] - x * sm.lout[J][4 * I0 + q];
-                b[0] = (q > S) ? upd : ((q == S) ? x : b[0]);
-            }
-#pragma unroll
-            for (int k = 1; k < 16; ++k) {
-                const int c = 4 * (I0 + k) + q;                       // columns beyond the block: nothing to update
-                const T u = (c < 64) ? sm.lout[J][c < 64 ? c : 63] : T(0);
-                b[k] -= x * u;
-            }
-        }
-        sm.wout[r][4 * I0 + q] = b[0];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) b[k] = b[k + 1];
-        b[15] = T(0);
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 16; ++it) Xdst[(wave + 4 * it) * ldx + lane] = sm.wout[wave + 4 * it][lane];
+    for (int i = 0; i < 16; ++i) sm.lout[r][4 * i + q] = m[i];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = wave + 4 * it;
+        WLout[rr * ldw + lane] = sm.lout[rr][lane];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm.lout[r][4 * i + q] = b[i];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rr = wave + 4 * it;
+        WUout[rr * ldw + lane] = sm.lout[rr][lane];
+    }
     __syncthreads();
 }
 
 // D: the 256 x 256 diagonal block (leading dimension lda), overwritten with L \ U; WL, WU: the inverses of the
-// two factors (leading dimension ldw, full 256 x 256 with explicit zeros in the other triangle); scratch:
+// two factors (leading dimension ldw, full 256 x 256; the 64 x 64 blocks of the other triangle are NOT written:
+// the caller hands in zeroed memory -- the solve-phase buffer, zeroed once per factorization); scratch:
 // 6 * 64 * 64 elements; a zero pivot sets *info = -2 (the caller falls back to the pivoting route).
+#ifdef LUK_TIMING
+#define LUK_STAMP(i) do { if (threadIdx.x == 0) tstamp[i] = wall_clock64(); } while (0)
+#else
+#define LUK_STAMP(i) do { } while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL, T *WU, int ldw, T *scratch,
-                                                            int32_t *info) {
+                                                            int32_t *info
+#ifdef LUK_TIMING
+                                                            , long long *tstamp
+#endif
+) {
     extern __shared__ __attribute__((aligned(16))) char luk_smem_raw[];
     LuSmem<T> &sm = *reinterpret_cast<LuSmem<T> *>(luk_smem_raw);
     const int wave = threadIdx.x >> 6;
@@ -211,21 +207,24 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
     bool bad = false;
     auto blk = [&](T *base, int ld, int bi, int bj) { return base + (bi * ld + bj) * SB; };
 
-    // the inverses are written block by block: start from zero (upper blocks of WL, lower blocks of WU)
-    for (int e = threadIdx.x; e < 256 * 256; e += 256) {
-        const int i = e >> 8, j = e & 255;
-        if ((i >> 6) < (j >> 6)) WL[i * ldw + j] = T(0);
-        if ((i >> 6) > (j >> 6)) WU[i * ldw + j] = T(0);
-    }
+    LUK_STAMP(0);
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
-        ge64_lu<T>(blk(D, lda, s, s), lda, blk(WL, ldw, s, s), ldw, sm, bad);
-        trsm_right_upper64<T>(nullptr, 0, blk(WU, ldw, s, s), ldw, sm);             // WU_ss = U_ss^-1
-#pragma unroll 1
-        for (int i = s + 1; i < 4; ++i)                                             // L_is = D_is U_ss^-1
-            trsm_right_upper64<T>(blk(D, lda, i, s), lda, blk(D, lda, i, s), lda, sm);
+        ge64_lu<T>(blk(D, lda, s, s), lda, blk(WL, ldw, s, s), blk(WU, ldw, s, s), ldw, sm, bad);
+        LUK_STAMP(1 + 3 * s);
         const int lane = opaque(threadIdx.x) & 63;
-        // U_sj = WL_ss D_sj: a slab of the result needs ALL rows of D_sj, so the four slabs of a block are
+        const int nb = 3 - s;
+        // L_is = D_is WU_ss (i > s): a slab needs only its own rows, in place
+#pragma unroll 1
+        for (int task = wave; task < nb * 4; task += 4) {
+            const int i = s + 1 + task / 4, slab = task % 4;
+            acc_t acc[4];
+            slab_zero<T>(acc);
+            T *rowp = blk(D, lda, i, s) + 16 * slab * lda;
+            slab_gemm<T, false>(acc, rowp, lda, blk(WU, ldw, s, s), ldw, T(1), lane);
+            slab_store<T>(acc, rowp, lda, lane);
+        }
+        // U_sj = WL_ss D_sj (j > s): a slab of the result needs ALL rows of D_sj, so the four slabs of a block are
         // computed (one per wave), then stored behind a barrier
 #pragma unroll 1
         for (int j = s + 1; j < 4; ++j) {
@@ -236,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
             slab_store<T>(acc, blk(D, lda, s, j) + 16 * wave * lda, lda, lane);
             __syncthreads();
         }
+        LUK_STAMP(2 + 3 * s);
         // D_ij -= L_is U_sj
-        const int nb = 3 - s;
 #pragma unroll 1
         for (int task = wave; task < nb * nb * 4; task += 4) {
             const int p = task / 4, slab = task % 4;
@@ -249,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
             slab_store<T>(acc, crow, lda, lane);
         }
         __syncthreads();
+        LUK_STAMP(3 + 3 * s);
     }
     if (bad && threadIdx.x == 0) atomicMin(info, -2);
 
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
             }
         }
         __syncthreads();
+        LUK_STAMP(11 + 2 * d);
 #pragma unroll 1
         for (int task = wave; task < 2 * npairs * 4; task += 4) {
             const bool upper = task >= npairs * 4;
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
             }
         }
         __syncthreads();
+        LUK_STAMP(12 + 2 * d);
     }
 }
 
