@@ -852,8 +852,9 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 // as info = -2 and the caller factors the matrix again with ssa_lu_factor (full partial pivoting).
 constexpr int kMaxLuLanes = 16;
 struct LuLane {
-    hipStream_t side = nullptr, upd = nullptr, fin = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr, ev_fin = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr, upd = nullptr, fin = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr, ev_fin = nullptr,
+               ev_diag = nullptr, ev_top = nullptr, ev_below = nullptr;
 };
 struct LuLaneSet {
     LuLane lanes[kMaxLuLanes];
@@ -872,6 +873,10 @@ inline int get_lu_lanes(int count, LuLaneSet **out) {
     for (int i = 0; i < count; ++i) {
         if (lanes[i].side != nullptr) continue;
         if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&lanes[i].side2, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_diag, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_top, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_below, hipEventDisableTiming) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].fin, hipStreamNonBlocking, lo) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fin, hipEventDisableTiming) != hipSuccess ||
@@ -892,14 +897,14 @@ int lu_shutdown() {
         std::lock_guard<std::mutex> enq(g_lu_lane_sets[d].enqueue);
         for (LuLane &ln : g_lu_lane_sets[d].lanes) {
             if (ln.side == nullptr) continue;
-            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess ||
-                hipStreamSynchronize(ln.fin) != hipSuccess)
+            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.side2) != hipSuccess ||
+                hipStreamSynchronize(ln.upd) != hipSuccess || hipStreamSynchronize(ln.fin) != hipSuccess)
                 rc = SSA_ERR_HIP;
-            hipEvent_t evs[5] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd, ln.ev_fin};
+            hipEvent_t evs[8] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd, ln.ev_fin, ln.ev_diag, ln.ev_top, ln.ev_below};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess ||
-                hipStreamDestroy(ln.fin) != hipSuccess)
+            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.side2) != hipSuccess ||
+                hipStreamDestroy(ln.upd) != hipSuccess || hipStreamDestroy(ln.fin) != hipSuccess)
                 rc = SSA_ERR_HIP;
             ln = LuLane{};
         }
@@ -979,36 +984,75 @@ __global__ __launch_bounds__(256) void np_check_kernel(const T *__restrict__ A, 
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicMin(info, -2);
 }
 
-// One outer panel of one matrix on stream s: the diagonal-block kernel (lu_diag.hpp: L11 \ U11 in place and the
-// inverses WL, WU of the two factors), then L21 = A21 WU and U12 = WL A12 as in-place MFMA GEMMs.  WU is upper and WL lower triangular: the second 128 columns of L21 need all 256
-// columns of A21 (done first), the first 128 only the first 128 -- every workgroup reads and writes its own
-// 128 rows, which makes the in-place product safe; U12 likewise by rows.
+// One outer panel of one matrix in pieces: the diagonal-block kernel (lu_diag.hpp: L11 \ U11 in place and the inverses
+// WL, WU of the two factors), and L21 = A21 WU for a range of rows / U12 = WL A12 for a range of columns as in-place
+// MFMA GEMMs.  WU is upper and WL lower triangular: the second 128 columns of L21 need all 256 columns of A21 (done
+// first), the first 128 only the first 128 -- every workgroup reads and writes its own rows, which makes the in-place
+// product safe; U12 likewise by rows of WL.
 template <typename T>
-int np_panel(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, hipStream_t s) {
-    T *A = J.A;
-    const int64_t lda = J.lda;
-    const int64_t kend = k0 + NB;
-    int rc;
-    T *D = A + k0 * (lda + 1);
+struct NpLeaves {
+    T *WL, *WU;
+};
+template <typename T>
+NpLeaves<T> np_leaves(const NpJob<T> &J, int64_t k0) {
     // WL, WU land in the solve-phase buffer: they are the inverted 256-leaves of the LSB block inverses
     const LuAux al = lu_aux_layout(J.n);
     const int64_t leaf = (k0 / LSB) * LSB * LSB + (k0 % LSB) * (LSB + 1);
-    T *WL = J.aux + al.invL + leaf, *WU = J.aux + al.invU + leaf;
-    const int64_t ldw = LSB;
-    hipLaunchKernelGGL((luk::lu_diag256_kernel<T>), dim3(1), dim3(256), sizeof(luk::LuSmem<T>), s, D,
-                       static_cast<int>(lda), WL, WU, static_cast<int>(ldw), S.dscratch, J.info);
+    return {J.aux + al.invL + leaf, J.aux + al.invU + leaf};
+}
+template <typename T>
+int np_diag(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, hipStream_t s) {
+    const NpLeaves<T> w = np_leaves(J, k0);
+    hipLaunchKernelGGL((luk::lu_diag256_kernel<T>), dim3(1), dim3(256), sizeof(luk::LuSmem<T>), s,
+                       J.A + k0 * (J.lda + 1), static_cast<int>(J.lda), w.WL, w.WU, static_cast<int>(LSB), S.dscratch,
+                       J.info);
     SSA_RETURN_IF_LAUNCH_FAILED();
-    const int64_t M = J.np - kend;
+    return SSA_OK;
+}
+// rows [r0, r1) of L21 of the panel at column k0 (r0 >= k0 + NB)
+template <typename T>
+int np_rows(const NpJob<T> &J, int64_t k0, int64_t r0, int64_t r1, hipStream_t s) {
+    const int64_t M = r1 - r0, lda = J.lda;
     if (M <= 0) return SSA_OK;
-    T *A21 = A + kend * lda + k0;
-    rc = gemm_t<T>(M, 128, 256, 1.0, A21, lda, WU + 128, ldw, 0.0, A21 + 128, lda, s);
+    const T *WU = np_leaves(J, k0).WU;
+    T *A21 = J.A + r0 * lda + k0;
+    int rc = gemm_t<T>(M, 128, 256, 1.0, A21, lda, WU + 128, LSB, 0.0, A21 + 128, lda, s);
     if (rc != SSA_OK) return rc;
-    rc = gemm_t<T>(M, 128, 128, 1.0, A21, lda, WU, ldw, 0.0, A21, lda, s);
+    return gemm_t<T>(M, 128, 128, 1.0, A21, lda, WU, LSB, 0.0, A21, lda, s);
+}
+// columns [c0, c1) of U12 of the panel at column k0 (c0 >= k0 + NB)
+template <typename T>
+int np_cols(const NpJob<T> &J, int64_t k0, int64_t c0, int64_t c1, hipStream_t s) {
+    const int64_t M = c1 - c0, lda = J.lda;
+    if (M <= 0) return SSA_OK;
+    const T *WL = np_leaves(J, k0).WL;
+    T *A12 = J.A + k0 * lda + c0;
+    int rc = gemm_t<T>(128, M, 256, 1.0, WL + 128 * LSB, LSB, A12, lda, 0.0, A12 + 128 * lda, lda, s);
     if (rc != SSA_OK) return rc;
-    T *A12 = A + k0 * lda + kend;
-    rc = gemm_t<T>(128, M, 256, 1.0, WL + 128 * ldw, ldw, A12, lda, 0.0, A12 + 128 * lda, lda, s);
+    return gemm_t<T>(128, M, 128, 1.0, WL, LSB, A12, lda, 0.0, A12, lda, s);
+}
+// panel k0 on the two chain streams of a lane: diagonal kernel and the first block row / column on ln.side (what the
+// next diagonal block needs), the rest of the panel on ln.side2; ev_panel = all of it
+template <typename T>
+int np_panel_two_streams(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, LuLane &ln, bool wait_below) {
+    const int64_t kend = k0 + NB, top = std::min<int64_t>(kend + NB, J.np);
+    int rc = np_diag(J, S, k0, ln.side);
     if (rc != SSA_OK) return rc;
-    return gemm_t<T>(128, M, 128, 1.0, WL, ldw, A12, lda, 0.0, A12, lda, s);
+    if (hipEventRecord(ln.ev_diag, ln.side) != hipSuccess) return SSA_ERR_HIP;
+    if (wait_below && hipStreamWaitEvent(ln.side, ln.ev_below, 0) != hipSuccess) return SSA_ERR_HIP;
+    rc = np_rows(J, k0, kend, top, ln.side);
+    if (rc != SSA_OK) return rc;
+    rc = np_cols(J, k0, kend, top, ln.side);
+    if (rc != SSA_OK) return rc;
+    if (hipEventRecord(ln.ev_top, ln.side) != hipSuccess || hipStreamWaitEvent(ln.side2, ln.ev_diag, 0) != hipSuccess)
+        return SSA_ERR_HIP;
+    rc = np_rows(J, k0, top, J.np, ln.side2);
+    if (rc != SSA_OK) return rc;
+    rc = np_cols(J, k0, top, J.np, ln.side2);
+    if (rc != SSA_OK) return rc;
+    if (hipStreamWaitEvent(ln.side2, ln.ev_top, 0) != hipSuccess || hipEventRecord(ln.ev_panel, ln.side2) != hipSuccess)
+        return SSA_ERR_HIP;
+    return SSA_OK;
 }
 
 template <typename T>
@@ -1042,11 +1086,11 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             hipMemsetAsync(J.aux, 0, static_cast<size_t>(lu_aux_layout(J.n).tmp) * sizeof(T), st) != hipSuccess)
             return SSA_ERR_HIP;
         if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_fork, 0) != hipSuccess ||
+            hipStreamWaitEvent(ln.side2, ln.ev_fork, 0) != hipSuccess ||
             hipStreamWaitEvent(ln.upd, ln.ev_fork, 0) != hipSuccess)
             return SSA_ERR_HIP;
-        rc = np_panel(J, scratch[i], 0, ln.side);
+        rc = np_panel_two_streams(J, scratch[i], 0, ln, false);
         if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
     }
     constexpr int kDelayDepth = 2;            // as in the Cholesky schedule: two panels per trailing update
     constexpr int64_t kDelayMinCols = 8192;   // while the trailing matrix is large
@@ -1067,17 +1111,26 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             const T *PU = J.A + pend0 * J.lda + (k0 + NB);   // pending U panels, columns of the trailing matrix
             T *C = J.A + (k0 + NB) * (J.lda + 1);
             if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;   // panel k done
-            // the strips of the next panel need this matrix' last rest update (it wrote their entries)
-            if (rest_recorded[i] && hipStreamWaitEvent(ln.side, ln.ev_rest, 0) != hipSuccess) return SSA_ERR_HIP;
-            rc = gemm_t<T>(right, nw, kp, -1.0, PL, J.lda, PU, J.lda, 1.0, C, J.lda, ln.side);
-            if (rc != SSA_OK) return rc;
+            // The chain of a matrix is two streams (diagonal look-ahead, as in chol.hip): the next diagonal block
+            // needs only the first block row and column of a panel, so
+            //     diagonal block update (256 x 256 x kp) -> diagonal-block kernel -> first block row / column
+            // is the critical recurrence on ln.side, while ln.side2 applies the pending panels to the rest of the
+            // two strips and computes the rest of the panel one step behind.  Both wait for this matrix' last rest
+            // update (it wrote the strips' entries).
             if (right > nw) {
-                rc = gemm_t<T>(nw, right - nw, kp, -1.0, PL, J.lda, PU + nw, J.lda, 1.0, C + nw, J.lda, ln.side);
+                if (rest_recorded[i] && hipStreamWaitEvent(ln.side2, ln.ev_rest, 0) != hipSuccess) return SSA_ERR_HIP;
+                rc = gemm_t<T>(right - nw, nw, kp, -1.0, PL + nw * J.lda, J.lda, PU, J.lda, 1.0, C + nw * J.lda, J.lda,
+                               ln.side2);
                 if (rc != SSA_OK) return rc;
+                rc = gemm_t<T>(nw, right - nw, kp, -1.0, PL, J.lda, PU + nw, J.lda, 1.0, C + nw, J.lda, ln.side2);
+                if (rc != SSA_OK) return rc;
+                if (hipEventRecord(ln.ev_below, ln.side2) != hipSuccess) return SSA_ERR_HIP;
             }
-            rc = np_panel(J, scratch[i], k0 + NB, ln.side);
+            if (rest_recorded[i] && hipStreamWaitEvent(ln.side, ln.ev_rest, 0) != hipSuccess) return SSA_ERR_HIP;
+            rc = gemm_t<T>(nw, nw, kp, -1.0, PL, J.lda, PU, J.lda, 1.0, C, J.lda, ln.side);
             if (rc != SSA_OK) return rc;
-            if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
+            rc = np_panel_two_streams(J, scratch[i], k0 + NB, ln, right > nw);
+            if (rc != SSA_OK) return rc;
             const bool delay = kp < kDelayDepth * NB && right > kDelayMinCols &&
                                ((k0 + J.np) / NB) % kDelayDepth != kDelayDepth - 1;
             if (right > nw && !delay) {
