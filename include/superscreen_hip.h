@@ -332,8 +332,12 @@ int ssa_gemm_ex(int opA, int opB, int lower_only, int64_t M, int64_t N, int64_t 
  *           entries on / below the diagonal: K * M * (M + 1))
  *   kind 2: gemm_op_kernel<double, N, T>, all tiles   (the Cholesky chain's strips and L21 = A21 W^T
  *           panel products; 2 M N K)
+ * ssa_profile_begin_kinds(mask) brackets only the kinds whose bit is set in `mask` (bit k = kind k): an
+ * event pair costs a few microseconds on its stream, which matters for the ~ 1300 short launches of kind 2
+ * per factorization and not for the ~ 100 trailing updates; ssa_profile_begin() = all kinds.
  */
 int ssa_profile_begin(void);
+int ssa_profile_begin_kinds(unsigned kinds_mask);
 int ssa_profile_read(int kind, double *ms, double *flops, int64_t *launches);
 int ssa_profile_end(void);
 

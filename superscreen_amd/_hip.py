@@ -79,6 +79,7 @@ SIGNATURES = {
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),
     "ssa_mfma_probe": (c_int, [c_int, P, P, P]),
     "ssa_profile_begin": (c_int, []),
+    "ssa_profile_begin_kinds": (c_int, [ctypes.c_uint]),
     "ssa_profile_end": (c_int, []),
     "ssa_rccl_unique_id": (c_int, [P]),
     "ssa_rccl_comm_create": (c_int, [P, c_int, c_int, P]),

@@ -429,9 +429,10 @@ struct FinishPlan {
 // With one matrix this is plain look-ahead (the chain is then the critical path for n ~ 20k);
 // with two or more the chains hide behind the other films' updates.
 //
-// Per matrix and outer step k:   strip   C[:, 0:256]   -= P P[0:256]^T       (side stream, after panel k and
-//                                                                              the matrix' last update)
-//                                panel k+1 factored                           (side stream)
+// Per matrix and outer step k:   diagonal block C[0:256, 0:256] -= P[0:256] P[0:256]^T, diagonal-block kernel of
+//                                panel k+1, first block row of panel k+1      (side stream: the critical chain)
+//                                strip C[256:, 0:256] -= P[256:] P[0:256]^T, rest of panel k+1
+//                                                                             (second side stream, one step behind)
 //                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream; for a large
 //                                        trailing matrix every other step: P = the last two panels, K = 512)
 template <typename T>
@@ -488,8 +489,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
     // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' strips
-    constexpr int kDelayDepth = 2;
-    constexpr int64_t kDelayMinCols = 8192;
+    constexpr int kDelayDepth = 2;            // (3 panels, K = 768: 114.5 vs 109.5 ms with the two-stream chains)
+    constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 12288: 108.4 ... 109.3 ms, flat)
     bool syrk_recorded[kMaxLanes] = {};
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
         for (int i = 0; i < count; ++i) {
@@ -527,8 +528,9 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             //     diagonal block update (256 x 256 x kp) -> diagonal-block kernel -> first block row of the panel
             // on ln.side, while ln.side2 applies the pending panels to the rows below (the strip) and computes the
             // rest of the panel, one step behind; neither queues behind the other matrices' updates, both wait for
-            // the last trailing update of THIS matrix (which wrote the strip's columns).  The strip and the panel
-            // rows were on the one chain stream before: 0.6 ms per panel in the chain-bound tail instead of ...
+            // the last trailing update of THIS matrix (which wrote the strip's columns).  (Strip, diagonal kernel and
+            // panel rows were one serial chain before: 0.6 ms per panel in the chain-bound tail, now 0.35-0.55 ms;
+            // config H 114 -> 109.6 ms.)
             const int64_t c = k0 + CNB;
             if (right > nw) {   // strip, rows below the diagonal block: behind panel k (all rows) on this stream
                 if (syrk_recorded[i] && hipStreamWaitEvent(ln.side2, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;

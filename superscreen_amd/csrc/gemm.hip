@@ -751,11 +751,14 @@ extern "C" int ssa_mfma_probe(int iters, void *sink, double *flops_out, void *st
     return SSA_OK;
 }
 
-extern "C" int ssa_profile_begin(void) {
+extern "C" int ssa_profile_begin_kinds(unsigned kinds_mask) {
     g_prof.used = 0;
+    g_prof.kinds = kinds_mask;
     g_prof.enabled = true;
     return SSA_OK;
 }
+
+extern "C" int ssa_profile_begin(void) { return ssa_profile_begin_kinds(~0u); }
 
 extern "C" int ssa_profile_read(int kind, double *ms_out, double *flops_out, int64_t *launches_out) {
     if (kind < 0 || kind >= kProfileKinds) return SSA_ERR_INVALID_ARGUMENT;

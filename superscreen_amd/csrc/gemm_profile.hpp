@@ -1,6 +1,9 @@
 // Optional instrumentation shared by the MFMA GEMM kernels: between ssa_profile_begin() and
 // ssa_profile_end() every launch of the f64 full-tile kernels is bracketed by HIP events on its
-// own stream (what bench.py's `roofline` object is computed from).
+// own stream (what bench.py's `roofline` object is computed from).  ssa_profile_begin_kinds() restricts the
+// bracketing to some kinds: a timing event pair costs a few microseconds on its stream, which the ~ 1300 short
+// products of the panel chains per config-H factorization feel (bench step 148 -> 138 ms without them) and the
+// ~ 100 trailing updates do not.
 #pragma once
 #include <vector>
 
@@ -17,6 +20,7 @@ enum ProfileKind : int {
 
 struct GemmProfile {
     bool enabled = false;
+    unsigned kinds = ~0u;   // bit k: launches of kind k are bracketed (ssa_profile_begin_kinds)
     std::vector<hipEvent_t> start, stop;
     std::vector<double> flops;
     std::vector<int> kind;
@@ -28,7 +32,7 @@ struct ProfileScope {
     bool active;
     hipStream_t st;
     ProfileScope(bool wanted, int kind, double flops, hipStream_t s) : active(false), st(s) {
-        if (!g_prof.enabled || !wanted) return;
+        if (!g_prof.enabled || !wanted || ((g_prof.kinds >> kind) & 1u) == 0) return;
         if (g_prof.used == g_prof.start.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;

@@ -1067,11 +1067,18 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     if (rc != SSA_OK) return rc;
     std::lock_guard<std::mutex> enqueue_lock(lane_set->enqueue);
     LuLane *lanes = lane_set->lanes;
+    // The trailing updates of two matrices alternate on ONE stream, as in the Cholesky schedule (two concurrent
+    // full-chip GEMMs halve each other's L2 reach: config H 205.6 -> 200.5 ms); three or more matrices keep one update
+    // stream each (a matrix' chain would wait behind the updates of all the others).  SSA_LU_UPD_STREAMS=0 / 1 forces
+    // the shared / the per-matrix form.
+    const char *upd_env = getenv("SSA_LU_UPD_STREAMS");
+    const bool shared_updates = upd_env != nullptr ? upd_env[0] == '0' : count < 3;
     NpScratch<T> scratch[kMaxLuLanes];
     int64_t nmax = 0;
     for (int i = 0; i < count; ++i) {
         const NpJob<T> &J = jobs[i];
         LuLane &ln = lanes[i];
+        hipStream_t us = shared_updates ? lanes[0].upd : ln.upd;   // where this matrix' trailing updates run
         if (J.np % NB != 0 || J.lda < J.np || J.lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets in the block kernel
         if (J.np > nmax) nmax = J.np;
         scratch[i] = np_carve<T>(J.workspace, J.np);
@@ -1087,7 +1094,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             return SSA_ERR_HIP;
         if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_fork, 0) != hipSuccess ||
             hipStreamWaitEvent(ln.side2, ln.ev_fork, 0) != hipSuccess ||
-            hipStreamWaitEvent(ln.upd, ln.ev_fork, 0) != hipSuccess)
+            hipStreamWaitEvent(us, ln.ev_fork, 0) != hipSuccess)
             return SSA_ERR_HIP;
         rc = np_panel_two_streams(J, scratch[i], 0, ln, false);
         if (rc != SSA_OK) return rc;
@@ -1103,6 +1110,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
         for (int i = 0; i < count; ++i) {
             const NpJob<T> &J = jobs[i];
             LuLane &ln = lanes[i];
+        hipStream_t us = shared_updates ? lanes[0].upd : ln.upd;   // where this matrix' trailing updates run
             if (k0 + NB >= J.np) continue;
             const int64_t right = J.np - k0 - NB;   // order of the trailing matrix (a multiple of NB)
             const int64_t nw = NB;
@@ -1110,7 +1118,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             const T *PL = J.A + (k0 + NB) * J.lda + pend0;   // pending L panels, rows of the trailing matrix
             const T *PU = J.A + pend0 * J.lda + (k0 + NB);   // pending U panels, columns of the trailing matrix
             T *C = J.A + (k0 + NB) * (J.lda + 1);
-            if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;   // panel k done
+            if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;   // panel k done
             // The chain of a matrix is two streams (diagonal look-ahead, as in chol.hip): the next diagonal block
             // needs only the first block row and column of a panel, so
             //     diagonal block update (256 x 256 x kp) -> diagonal-block kernel -> first block row / column
@@ -1135,16 +1143,16 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
                                ((k0 + J.np) / NB) % kDelayDepth != kDelayDepth - 1;
             if (right > nw && !delay) {
                 rc = gemm_t<T>(right - nw, right - nw, kp, -1.0, PL + nw * J.lda, J.lda, PU + nw, J.lda, 1.0,
-                               C + nw * (J.lda + 1), J.lda, ln.upd);
+                               C + nw * (J.lda + 1), J.lda, us);
                 if (rc != SSA_OK) return rc;
-                if (hipEventRecord(ln.ev_rest, ln.upd) != hipSuccess) return SSA_ERR_HIP;
+                if (hipEventRecord(ln.ev_rest, us) != hipSuccess) return SSA_ERR_HIP;
                 rest_recorded[i] = true;
             }
             if (!delay) pending_from[i] = k0 + NB;
             // The block inverses of the solve phase (lu_finish_full_blocks) of the LSB blocks whose panels are all
             // factored: on a low-priority stream of their own once the factorization is bound by its panel chain
             // (trailing matrix below kDelayMinCols: the chip is mostly idle then), instead of after the last panel,
-            // where nothing hides them.  (Behind the trailing updates on ln.upd they delay the next panel by their
+            // where nothing hides them.  (Behind the trailing updates on us they delay the next panel by their
             // 3 ms per block; earlier, beside the large updates, they slow the chains: both measured)
             const int64_t blocks_closed = std::min((k0 + NB) / LSB, J.n / LSB);
             if (early_finish && right <= kDelayMinCols && blocks_closed > blocks_finished[i]) {
@@ -1160,15 +1168,16 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     for (int i = 0; i < count; ++i) {
         const NpJob<T> &J = jobs[i];
         LuLane &ln = lanes[i];
-        if (hipStreamWaitEvent(ln.upd, ln.ev_panel, 0) != hipSuccess || hipEventRecord(ln.ev_fin, ln.fin) != hipSuccess ||
-            hipStreamWaitEvent(ln.upd, ln.ev_fin, 0) != hipSuccess)
+        hipStream_t us = shared_updates ? lanes[0].upd : ln.upd;   // where this matrix' trailing updates run
+        if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess || hipEventRecord(ln.ev_fin, ln.fin) != hipSuccess ||
+            hipStreamWaitEvent(us, ln.ev_fin, 0) != hipSuccess)
             return SSA_ERR_HIP;
-        hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, ln.upd,
+        hipLaunchKernelGGL((np_check_kernel<T>), dim3(static_cast<unsigned>(ceil_div(J.n, 16))), dim3(256), 0, us,
                            J.A, J.lda, J.n, scratch[i].flags, scratch[i].nsub, J.info, J.ipiv);
         SSA_RETURN_IF_LAUNCH_FAILED();
-        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, ln.upd, true, blocks_finished[i]);
+        rc = lu_build_solve_blocks<T>(J.A, J.n, J.lda, J.aux, us, true, blocks_finished[i]);
         if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ln.ev_upd, ln.upd) != hipSuccess || hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess)
+        if (hipEventRecord(ln.ev_upd, us) != hipSuccess || hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess)
             return SSA_ERR_HIP;
     }
     return SSA_OK;
