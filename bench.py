@@ -63,8 +63,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILES = ("r02_syrk_pmc.json", "r01_v7_syrk_pmc.json")
-PMC_MFMA_FILES = ("r02_syrk_mfma_pmc.json", "r01_v7_syrk_mfma_pmc.json")
+PMC_TRAFFIC_FILES = ("r02b_syrk_pmc.json", "r02_syrk_pmc.json", "r01_v7_syrk_pmc.json")
+PMC_MFMA_FILES = ("r02b_syrk_mfma_pmc.json", "r02_syrk_mfma_pmc.json", "r01_v7_syrk_mfma_pmc.json")
 
 
 def chol_schedule(unknowns, elem=8):
