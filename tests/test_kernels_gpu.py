@@ -331,7 +331,7 @@ def test_cholesky_block_solves(K, n):
 def test_cholesky_batch_equals_single(K):
     """ssa_chol_factor_batch (films interleaved on one schedule) is bit-identical to separate calls."""
     rng = np.random.default_rng(5)
-    sizes = [1500, 4400, 700, 256]
+    sizes = [1500, 4400, 700, 256, 500]   # 256 / 500 / 700: one, two, three panels (edges of the two-stream chain)
     mats = []
     for n in sizes:
         U = rng.standard_normal((n, 16))
@@ -606,7 +606,7 @@ def _nopivot_buffer(K, A, dtype):
 
 
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-3)])
-@pytest.mark.parametrize("n", [3, 64, 257, 1500, 4500, 9011])
+@pytest.mark.parametrize("n", [3, 64, 257, 500, 700, 1500, 4500, 9011])   # 2 / 3 panels: the two-stream chain's edges
 def test_lu_nopivot_matches_lapack_on_dominant_matrices(K, dtype, tol, n):
     """The look-ahead route without interchanges (ssa_lu_factor_nopivot_batch) on row-diagonally-dominant,
     NON-symmetric matrices: LAPACK's getrf returns ipiv == arange for them and the factors must agree."""
@@ -677,3 +677,40 @@ def test_gemm_nt_small_tile_path(K, dtype, tol, shape):
         ref = A.astype(np.float64) @ W[128:, :].astype(np.float64).T
         got = A21.cpu().numpy()
         assert relerr(got[:, 128:], ref) < tol * 10 and np.array_equal(got[:, :128], A[:, :128])
+
+
+def test_profile_kinds_mask(K):
+    """ssa_profile_begin_kinds brackets only the selected kernel kinds (bench.py keeps the event pairs off the panel
+    chains inside its timed region)."""
+    import ctypes
+    from superscreen_amd import _hip
+    lib = _hip.load_library()
+    rng = np.random.default_rng(0)
+    n = 1024
+    U = rng.standard_normal((n, 16))
+    S = np.tril(U @ U.T / 16 + np.diag(1.5 + rng.random(n)))
+
+    def factor():
+        t = torch.zeros((n, K.padded_ld(n, "float64")), dtype=torch.float64, device="cuda")
+        t[:n, :n] = dev(S)
+        assert K.chol_factor(t, n).info == 0
+        torch.cuda.synchronize()
+
+    def counts():
+        out = []
+        for kind in range(3):
+            ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+            _hip.check(lib.ssa_profile_read(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)), "read")
+            out.append(cnt.value)
+        return out
+
+    _hip.check(lib.ssa_profile_begin(), "begin")
+    factor()
+    everything = counts()
+    _hip.check(lib.ssa_profile_end(), "end")
+    assert everything[1] > 0 and everything[2] > 0            # trailing updates and chain products
+    _hip.check(lib.ssa_profile_begin_kinds(0b010), "begin_kinds")
+    factor()
+    only_syrk = counts()
+    _hip.check(lib.ssa_profile_end(), "end")
+    assert only_syrk == [0, everything[1], 0]
