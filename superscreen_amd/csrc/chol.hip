@@ -454,8 +454,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     const bool split_updates = (update_stream_mode < 0) ? count >= 3 : (update_stream_mode == 1 && count > 1);
-    // outer steps (per matrix) that are chain bound: the last ~6k columns at this panel speed
-    constexpr int64_t kTailCols = 6144;
+    // outer steps (per matrix) that are chain bound: the early finishing steps are slipped into the last 16 of them
+    constexpr int64_t kTailCols = 4096;
     FinishPlan<T> plans[kMaxLanes];
     int64_t nmax = 0;
     for (int i = 0; i < count; ++i) {
