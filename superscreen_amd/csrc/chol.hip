@@ -13,9 +13,10 @@
 // falls back to the LU path (lu.hip).
 //
 // Factorization: 256-column outer panels.  Panel = one diagonal-block kernel (chol_diag.hpp: L11
-// and W = L11^-1) + L21 = A21 W^T as two in-place MFMA GEMMs; trailing update = one MFMA SYRK
-// with K = 256; panel k+1 runs on a side stream beside update k (look-ahead), and the films of a
-// device are factored in one interleaved schedule (potrf_batch).
+// and W = L11^-1) + L21 = A21 W^T as in-place MFMA GEMMs; trailing update = one MFMA SYRK with
+// K = 256 or 512; the panels run on two high-priority side streams per matrix beside the updates
+// (look-ahead: the diagonal recurrence on one, the strip and the rest of the panel on the other),
+// and the films of a device are factored in one interleaved schedule (potrf_batch).
 //
 // Solve: the factor buffer ends up holding L below and L^T above the diagonal, and `aux` the
 // inverses (and their transposes) of the SNB x SNB diagonal blocks of L, so that both triangular

@@ -833,16 +833,14 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 // returns ipiv == arange for them.  Without interchanges the factorization has the structure of the
 // Cholesky route (chol.hip) and takes the same schedule:
 //
-//   per matrix and 256-column panel k           chain (high-priority side stream)        update stream
-//   ------------------------------------------------------------------------------------------------------
-//   column strip  C[:, 0:256]  -= L21p U12p[:, 0:256]     (pending panels p, K = 256 / 512)
-//   row strip     C[0:256, 256:] -= L21p[0:256] U12p[:, 256:]
-//   diagonal block: L11 \ U11 in place, WL = inv(L11), WU = inv(U11)    (lu_diag256_kernel, lu_diag.hpp:
-//                   one workgroup, 64-column Gaussian eliminations in registers + MFMA block products)
-//   L21 = A21 WU, U12 = WL A12                  (two in-place MFMA GEMMs each)
-//                                                                             rest  C[256:, 256:] -= L21p U12p
-//                                                                             (every other panel with K = 512
-//                                                                              for large trailing matrices)
+//   per matrix and 256-column panel k (two high-priority chain streams, one update stream):
+//   chain 1   diagonal block  C[0:256, 0:256] -= L21p[0:256] U12p[:, 0:256]     (pending panels p, K = 256 / 512)
+//             diagonal block: L11 \ U11 in place, WL = inv(L11), WU = inv(U11)  (lu_diag256_kernel, lu_diag.hpp:
+//                             one workgroup, 64-column Gaussian eliminations in registers + MFMA block products)
+//             first block row of L21 = A21 WU, first block column of U12 = WL A12   (all the next diagonal block needs)
+//   chain 2   column strip  C[256:, 0:256] -= L21p[256:] U12p[:, 0:256],  row strip  C[0:256, 256:] -= ...
+//             rest of L21 = A21 WU and of U12 = WL A12   (two in-place MFMA GEMMs each; one step behind chain 1)
+//   update    rest  C[256:, 256:] -= L21p U12p   (every other panel with K = 512 for large trailing matrices)
 //
 // i.e. panel k + 1 is factored while the rest of update k runs (look-ahead), the matrices of a batch hide
 // each other's chains, and the trailing update is one NN GEMM.  What makes the result LAPACK's: partial
