@@ -2,6 +2,16 @@
 // CSR gradient SpMV, gathers / scatters, scaling; plus the HBM fill probe used by bench.py.
 #include "common.hpp"
 
+#ifndef SSA_TRMV_ROWS
+#define SSA_TRMV_ROWS 2
+#endif
+#ifndef SSA_GEMV_T4
+#define SSA_GEMV_T4 12288   // rows from which a GEMV runs 4 rows per wave
+#endif
+#ifndef SSA_GEMV_T2
+#define SSA_GEMV_T2 6144    // ... 2 rows per wave (fewer: 1)
+#endif
+
 namespace ssa {
 
 // ---------------------------------------------------------------------------------------
@@ -87,18 +97,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int6
     }
 }
 
-template <typename T>
-int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *x,
-                const void *xscale, const int64_t *xidx, void *y, double alpha, double beta,
-                hipStream_t st) {
-    constexpr int ROWS = 4;
+template <typename T, int ROWS>
+int launch_gemv_rows(const T *Mp, int64_t nr, int64_t nc, int64_t ldm, const T *xp, const T *sp, const int64_t *xidx,
+                     T *yp, double alpha, double beta, bool aligned, hipStream_t st) {
     const dim3 grid(static_cast<unsigned>(ceil_div(nr, 4 * ROWS)));
-    const bool aligned = (reinterpret_cast<uintptr_t>(M) % 16 == 0) &&
-                         ((ldm * sizeof(T)) % 16 == 0);
-    const T *Mp = static_cast<const T *>(M);
-    const T *xp = static_cast<const T *>(x);
-    const T *sp = static_cast<const T *>(xscale);
-    T *yp = static_cast<T *>(y);
     if (aligned) {
         hipLaunchKernelGGL((gemv_kernel<T, ROWS, true>), grid, dim3(256), 0, st, Mp, nr, nc, ldm,
                            xp, sp, xidx, yp, static_cast<T>(alpha), static_cast<T>(beta));
@@ -110,14 +112,33 @@ int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *
     return SSA_OK;
 }
 
+template <typename T>
+int launch_gemv(const void *M, int64_t nr, int64_t nc, int64_t ldm, const void *x,
+                const void *xscale, const int64_t *xidx, void *y, double alpha, double beta,
+                hipStream_t st) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(M) % 16 == 0) &&
+                         ((ldm * sizeof(T)) % 16 == 0);
+    const T *Mp = static_cast<const T *>(M);
+    const T *xp = static_cast<const T *>(x);
+    const T *sp = static_cast<const T *>(xscale);
+    T *yp = static_cast<T *>(y);
+    // Rows per wave: 4 (every x element fetched from L2 is used four times) needs >= 16 000 rows to put four
+    // workgroups on every CU; a block of the triangular solves with fewer rows has too few loads in flight to
+    // reach the HBM rate (4 035 x 4096: 2.9 TB/s with 4 rows per wave), so it gets more, smaller waves.  A row's
+    // sum is accumulated in the same order whatever the choice: the result does not depend on it.
+    if (nr >= SSA_GEMV_T4) return launch_gemv_rows<T, 4>(Mp, nr, nc, ldm, xp, sp, xidx, yp, alpha, beta, aligned, st);
+    if (nr >= SSA_GEMV_T2) return launch_gemv_rows<T, 2>(Mp, nr, nc, ldm, xp, sp, xidx, yp, alpha, beta, aligned, st);
+    return launch_gemv_rows<T, 1>(Mp, nr, nc, ldm, xp, sp, xidx, yp, alpha, beta, aligned, st);
+}
+
 // y = alpha * M x + beta * y for a triangular M (tri = 1 lower, 2 upper): chol.hip applies the
 // inverted diagonal blocks with it.
 template <typename T>
 int launch_trmv(const T *M, int64_t nr, int64_t nc, int64_t ldm, const T *x, T *y, double alpha, double beta,
                 int tri, hipStream_t st) {
-    // 2 rows per wave (not 4 as in the rectangular GEMV): an inverse block has only 4096 rows, half
+    // few rows per wave (not 4 as in the large rectangular GEMV): an inverse block has only 4096 rows, half
     // of them short; more, smaller waves keep enough loads in flight to approach the HBM rate
-    constexpr int ROWS = 2;
+    constexpr int ROWS = SSA_TRMV_ROWS;
     if (nr <= 0) return SSA_OK;
     const dim3 grid(static_cast<unsigned>(ceil_div(nr, 4 * ROWS)));
     const bool aligned = (reinterpret_cast<uintptr_t>(M) % 16 == 0) && ((ldm * sizeof(T)) % 16 == 0);
