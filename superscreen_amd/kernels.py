@@ -102,6 +102,14 @@ class CholFactors:
         return self.L.shape[1]
 
 
+def fetch_chol_infos(factors: Sequence[CholFactors]) -> None:
+    """One device-to-host round trip for the ``info`` of several factorizations (instead of one per access)."""
+    todo = [f for f in factors if f._info is None]
+    if todo:
+        for f, v in zip(todo, torch.cat([f.info_device for f in todo]).cpu().tolist()):
+            f._info = int(v)
+
+
 def chol_padded_n(n: int) -> int:
     """Rows / leading dimension the buffer handed to :func:`chol_factor` must provide."""
     return int(load_library().ssa_chol_padded_n(n))

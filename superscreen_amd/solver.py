@@ -453,6 +453,10 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     # the other films' updates.
     with_S = [p for p in pending if p[4] is not None]
     chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S])))
+    # what the Cholesky systems need besides the factor is enqueued BEFORE the host waits for the pivot reports
+    # (one device-to-host copy for all films): nothing is left to launch between the factorization and the solve
+    neg_w = {p[0]: (-p[7].w_t[p[2]]).contiguous() for p in with_S}
+    kernels.fetch_chol_infos(list(chols.values()))
     # the films that take the LU route (method="lu", Lambda(x, y), a failed Cholesky) are factored together,
     # one stream per film: the panel chain of one film runs beside the trailing updates of the others
     lu_keys = [p[0] for p in pending if p[3] > 0 and (chols.get(p[0]) is None or chols[p[0]].info != 0)]
@@ -480,7 +484,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             if chol.info == 0:
                 system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,
                                       grad_Lambda_term=grad_Lambda_term,
-                                      neg_w_device=(-fd.w_t[ix_d]).contiguous(),
+                                      neg_w_device=neg_w[key],
                                       _lu_factorize=lu_route, _assemble=host_A)
             else:
                 if method == "cholesky":
@@ -969,7 +973,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
         if Hz.ndim != 1:
             raise ValueError(f"Expected applied_field to return a 1D vector, got a {Hz.shape[1]}D vector.")
         applied_h[film] = Hz
-        applied_d[film] = torch.from_numpy(np.ascontiguousarray(Hz)).to(model.film_data[film].device)
+        applied_d[film] = _h2d(Hz, model.film_data[film].device)
     vflux = vortex_flux(current_units, device.length_units)  # solve.py:441-442
 
     solution_kwargs = dict(applied_field_func=applied_field, field_units=field_units,
