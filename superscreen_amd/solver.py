@@ -456,6 +456,10 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     # what the Cholesky systems need besides the factor is enqueued BEFORE the host waits for the pivot reports
     # (one device-to-host copy for all films): nothing is left to launch between the factorization and the solve
     neg_w = {p[0]: (-p[7].w_t[p[2]]).contiguous() for p in with_S}
+    # the mesh rows that are not unknowns of a film system (the self field's all-pairs rows, _solve_film_device):
+    # host set arithmetic + upload, done here under the running factorization instead of inside the first pass
+    exterior_d = {p[0]: _h2d(np.setdiff1d(np.arange(p[7].n, dtype=np.int64), p[1]), p[7].device)
+                  for p in pending if p[3] > 0 and p[0][1] == "film"}
     kernels.fetch_chol_infos(list(chols.values()))
     # the films that take the LU route (method="lu", Lambda(x, y), a failed Cholesky) are factored together,
     # one stream per film: the panel chain of one film runs beside the trailing updates of the others
@@ -484,7 +488,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             if chol.info == 0:
                 system = LinearSystem(indices=interior, chol=chol, indices_device=ix_d,
                                       grad_Lambda_term=grad_Lambda_term,
-                                      neg_w_device=neg_w[key],
+                                      neg_w_device=neg_w[key], exterior_device=exterior_d.get(key),
                                       _lu_factorize=lu_route, _assemble=host_A)
             else:
                 if method == "cholesky":
@@ -499,7 +503,8 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
             factors = lu_route(factors=lu_batch[key])
             system = LinearSystem(indices=interior, factors=factors, indices_device=ix_d,
                                   grad_Lambda_term=grad_Lambda_term,
-                                  rhs_indices_device=ix_d[factors.perm].contiguous(), _assemble=host_A)
+                                  rhs_indices_device=ix_d[factors.perm].contiguous(), _assemble=host_A,
+                                  exterior_device=exterior_d.get(key))
         if role == "film":
             film_systems[name] = system
             if name in terminal_systems:
