@@ -179,8 +179,8 @@ def _h2d(a: np.ndarray, dev):
     import torch
 
     t = torch.from_numpy(np.ascontiguousarray(a))
-    if dev.type != "cuda" or t.numel() == 0:
-        return t.to(dev)
+    if dev.type != "cuda" or t.numel() == 0 or t.numel() * t.element_size() > (1 << 20):
+        return t.to(dev)   # (large arrays: staging them through a fresh pinned buffer costs more than it hides)
     return t.pin_memory().to(dev, non_blocking=True)
 
 
