@@ -60,6 +60,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP multiplexes a process' streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level; the
+# factorization schedules use two high-priority chain streams per film, so the 4-film stack of config 5 wants 8
+# (DESIGN.md section 9).  An application-level choice: set here, before the HIP runtime starts, not by the package.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
@@ -140,12 +144,18 @@ def physical_cores():
         return None
 
 
-def cpu_baseline(K: int, iterations: int, budget_s: float):
+def cpu_baseline(K: int, iterations: int, budget_s: float, gpu_solutions=None, gpu_field_mT=None):
     """One cold self-consistent solve of the K-ring two-film device by the CPU oracle, phase by phase, on
     this box's host cores: dense Q in float64 (OpenMP C port of the numba kernel, distance.py:87-115),
     A = Q[ix, ix] w - Lambda Del2 (solve_film.py:296-305), scipy lu_factor(-A) (:279), then 1 + iterations
     passes of solve_film (lu_solve, Q @ (w g), sparse gradients; :440-574) and `iterations` rounds of the
-    all-pairs coupling (solve.py:28-73, OpenMP C port).  Nothing is extrapolated."""
+    all-pairs coupling (solve.py:28-73, OpenMP C port).  Nothing is extrapolated.
+
+    With ``gpu_solutions`` (the Solutions of the last timed GPU step, applied field ``gpu_field_mT``) the oracle
+    then runs that very solve -- the reference's ``gf = lu_solve(lu_piv, h)`` on ``lu_factor(-A)`` with
+    ``A = Q[ix, ix] w - Lambda Del2`` (solve_film.py:296-305, 526-531) inside the Jacobi loop of solve.py:491-536,
+    every iterate -- and the returned dict carries ``parity``: the stream-function max-rel-error
+    ``max|g_gpu - g_ref| / max|g_ref|`` per film and iterate AT THE BENCHMARK SIZE (north_star: < 1e-6)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import build_oracle
     import cpu_kernels
@@ -235,6 +245,9 @@ def cpu_baseline(K: int, iterations: int, budget_s: float):
                     film1_J=sols[src.name].current_density, film2_sites=sites, film2_z0=tgt.z0)
 
         t_cpl, r_cpl, _ = median_timed(coupling_round, spent)
+        parity = None
+        if gpu_solutions is not None:
+            parity = oracle_parity(orc, cpu_kernels, films, gpu_field_mT, iterations, gpu_solutions)
     # the device has one mesh per film (device.meshes, device/device.py): Q is built per film
     per_solve = 2 * t_q + t_a + t_lu + (iterations + 1) * t_pass + iterations * t_cpl
     return {
@@ -242,6 +255,7 @@ def cpu_baseline(K: int, iterations: int, budget_s: float):
         "unit": "solves/s",
         "cores": threads,
         "kind": "port",
+        "parity": parity,
         "measurement": "measured at the benchmark size, no extrapolation",
         "sample": (f"CPU oracle (numpy/scipy LAPACK + OpenMP C ports of the numba kernels) on the SAME K={K} two-film "
                    f"device (n={n}/film, n_i={len(films[0].film_indices)}+{len(films[1].film_indices)}), every phase "
@@ -257,6 +271,186 @@ def cpu_baseline(K: int, iterations: int, budget_s: float):
         "physical_cores": phys,
         "lu_thread_sweep_GFLOPs_n6000": {str(k): v for k, v in sweep.items()},
     }
+
+
+def oracle_parity(orc, cpu_kernels, films, field_mT, iterations, gpu_solutions):
+    """The oracle's own self-consistent solve of the benchmark device (first pass + `iterations` Jacobi rounds,
+    solve.py:459-536; all sources use the previous iterate) against the GPU Solutions of the same solve."""
+    t0 = time.perf_counter()
+    trace = orc.solve(films, field_mT, iterations=iterations, biot_savart=cpu_kernels.biot_savart_film_to_film)
+    gpu_names = list(gpu_solutions[0].film_solutions)            # device.films order = oracle film order
+    assert len(gpu_names) == len(films) and len(gpu_solutions) == len(trace) == iterations + 1
+    worst = {"stream": 0.0, "current_density": 0.0, "self_field": 0.0, "field_from_other_films": 0.0}
+    per_film = {nm: 0.0 for nm in gpu_names}
+    per_iterate = []
+
+    def rel(a, b):
+        return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+    for it, sols in enumerate(trace):
+        err_it = 0.0
+        for f, nm in zip(films, gpu_names):
+            ref, got = sols[f.name], gpu_solutions[it].film_solutions[nm]
+            e = rel(got.stream, ref.stream)
+            per_film[nm] = max(per_film[nm], e)
+            err_it = max(err_it, e)
+            worst["stream"] = max(worst["stream"], e)
+            worst["current_density"] = max(worst["current_density"], rel(got.current_density, ref.current_density))
+            worst["self_field"] = max(worst["self_field"], rel(got.self_field, ref.self_field))
+            if it:
+                worst["field_from_other_films"] = max(worst["field_from_other_films"],
+                                                      rel(got.field_from_other_films, ref.field_from_other_films))
+        per_iterate.append(err_it)
+    return {
+        "max_rel_err_stream": worst["stream"],
+        "per_film": per_film,
+        "per_iterate_stream": per_iterate,
+        "max_rel_err_current_density": worst["current_density"],
+        "max_rel_err_self_field": worst["self_field"],
+        "max_rel_err_field_from_other_films": worst["field_from_other_films"],
+        "iterations": iterations,
+        "applied_field_mT": field_mT,
+        "tolerance": 1e-6,
+        "passed": bool(worst["stream"] < 1e-6),
+        "definition": "max|g_gpu - g_ref| / max|g_ref| per film and iterate, all iterates of the last timed GPU step",
+        "reference": ("CPU oracle: scipy lu_factor(-A) / lu_solve (solve_film.py:279, 526-531), A = Q[ix,ix] w - "
+                      "Lambda Del2 (:296-305), Jacobi loop of solve.py:491-536, at the benchmark size"),
+        "oracle_seconds": time.perf_counter() - t0,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 2 and 3 (one GPU) and the other reading of the headline (2 x 50 311 vertices)
+# ---------------------------------------------------------------------------------------------------
+def config2_single_film(sc, torch, kernels):
+    """Config 2: single-film 50 311-vertex disk (K = 129, 41 419 unknowns): (i) Q assembly alone (20.25 GB),
+    (ii) the fused A assembly, (iii) the factorization, (iv) one solve_film."""
+    from superscreen_amd import synthetic
+
+    K2 = int(os.environ.get("BENCH_CONFIG2_K", "129"))            # testing aid: smaller meshes
+    device = synthetic.make_stack_device(K2, ("disk",), solve_dtype="float64")
+    name = list(device.films)[0]
+    n = len(device.meshes[name].sites)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    model = sc.factorize_model(device=device, current_units="uA")            # warm-up: allocator, caches
+    fd, system = model.film_data[name], model.film_systems[name]
+    ni = len(system.indices)
+    used_chol = system.chol is not None
+    res = {"config2_vertices": n, "config2_unknowns": ni}
+    ld = kernels.padded_ld(n, "float64")
+    Q = torch.empty((n, ld), dtype=torch.float64, device="cuda")
+    C = torch.from_numpy(device.meshes[name].operators.C).cuda()
+    t = timed(lambda: kernels.q_assemble(fd.xy, fd.w, C, "float64", out=Q, ld=ld))
+    res["config2_q_assembly_ms"] = t
+    res["config2_q_assembly_GBps"] = n * n * 8 / (t * 1e-3) / 1e9
+    res["config2_q_assembly_frac_of_hbm_peak"] = res["config2_q_assembly_GBps"] / HBM_PEAK_GBPS
+    del Q
+    ix = system.indices_device
+    # the reference's A (every entry, solve_film.py:296-305) and the form the Cholesky consumes (diag(w) A, lower tiles)
+    t = timed(lambda: kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix, ix, sign=-1.0,
+                                              dtype="float64"))
+    res["config2_a_assembly_ms"] = t
+    res["config2_a_assembly_GBps"] = ni * ni * 8 / (t * 1e-3) / 1e9
+    torch.cuda.empty_cache()
+    tf = []
+    for _ in range(2):
+        model = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model = sc.factorize_model(device=device, current_units="uA")
+        torch.cuda.synchronize()
+        tf.append((time.perf_counter() - t1) * 1e3)
+    res["config2_factorize_ms"] = float(np.median(tf))
+    flops = ni ** 3 / 3.0 if used_chol else 2.0 * ni ** 3 / 3.0
+    res["config2_factorization_TFLOPs"] = flops / (res["config2_factorize_ms"] * 1e-3) / 1e12
+    res["config2_factorization_route"] = "cholesky of diag(w) A" if used_chol else "lu of -A"
+    sc.solve(model=model, applied_field=sc.ConstantField(1.0), progress_bar=False)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sc.solve(model=model, applied_field=sc.ConstantField(1.0), progress_bar=False)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t1) * 1e3)
+    res["config2_solve_film_ms"] = float(np.median(ts))
+    res["config2_cold_solves_per_s"] = 1e3 / (res["config2_factorize_ms"] + res["config2_solve_film_ms"])
+    del model
+    torch.cuda.empty_cache()
+    return res
+
+
+def config3_two_films(sc, torch, iterations):
+    """Config 3: washer + shield disk, 19 927 vertices per film (K = 81), one GPU: cold self-consistent solves with
+    the fixed iteration count and "to convergence" (max|dg|/max|g| < 1e-8; the reference has no such test)."""
+    from superscreen_amd import synthetic
+
+    K3 = int(os.environ.get("BENCH_CONFIG3_K", "81"))             # testing aid: smaller meshes
+    device = synthetic.make_stack_device(K3, ("washer", "disk"), solve_dtype="float64")
+
+    def cold(**kw):
+        model = sc.factorize_model(device=device, current_units="uA")
+        return sc.solve(model=model, applied_field=sc.ConstantField(1.0), progress_bar=False, **kw)
+
+    cold(iterations=iterations)                                    # warm-up
+    res = {"config3_vertices_per_film": len(device.meshes[list(device.films)[0]].sites)}
+    for label, kw in (("10iter", dict(iterations=iterations)), ("to_1e-8", dict(iterations=200, tolerance=1e-8))):
+        ts, sols = [], None
+        for _ in range(3):
+            sols = None
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sols = cold(**kw)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        res[f"config3_solves_per_s_{label}"] = 1.0 / float(np.median(ts))
+        if label == "to_1e-8":
+            res["config3_iterations_to_1e-8"] = len(sols) - 1
+    torch.cuda.empty_cache()
+    return res
+
+
+def configH_alt_2x50k(sc, torch, iterations):
+    """The other reading of "50k-vertex 2-film device": 50 311 vertices PER film (K = 129 washer + disk,
+    100 622 vertices in all): one cold self-consistent solve."""
+    from superscreen_amd import synthetic
+
+    Ka = int(os.environ.get("BENCH_CONFIGH_ALT_K", "129"))        # testing aid: smaller meshes
+    device = synthetic.make_stack_device(Ka, ("washer", "disk"), solve_dtype="float64")
+
+    def cold():
+        model = sc.factorize_model(device=device, current_units="uA")
+        unknowns = [int(len(s_.indices)) for s_ in model.film_systems.values()]
+        return unknowns, sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=iterations,
+                                  progress_bar=False)
+
+    cold()                                                         # warm-up (allocator: 2 x 14 GB factors)
+    ts = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        unknowns, sols = cold()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t1)
+        assert len(sols) == iterations + 1
+        del sols
+    t = float(np.median(ts))
+    torch.cuda.empty_cache()
+    return {"configH_alt_2x50k_vertices_per_film": len(device.meshes[list(device.films)[0]].sites),
+            "configH_alt_2x50k_unknowns": unknowns, "configH_alt_2x50k_ms_per_solve": t * 1e3,
+            "configH_alt_2x50k_solves_per_s": 1.0 / t,
+            "configH_alt_2x50k_TFLOPs_factorization_flops_only": sum(u ** 3 / 3.0 for u in unknowns) / t / 1e12}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -428,6 +622,7 @@ def main():
         model, sols = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    parity_sols, parity_field = sols, 0.1 * (1 + rank + world * (args.steps - 1))   # last timed step, for the oracle
     prof = {}
     for kind, label in ((0, "ssa::gemm_kernel<double, true> (NN: LU trailing / in-panel updates)"),
                         (1, "ssa::gemm_op_kernel<double, 0, 1, true> (SYRK on the lower tiles: Cholesky trailing update)"),
@@ -553,10 +748,15 @@ def main():
         # iterations needed for max|dg|/max|g| < 1e-8 (the reference has no convergence test)
         conv = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=200, tolerance=1e-8,
                         return_solutions=True)
-        extras["iterations_to_1e-8"] = len(conv) - 1
+        extras["configH_iterations_to_1e-8"] = len(conv) - 1
         del conv
     model = sols = None
     torch.cuda.empty_cache()
+    if rank == 0 and not args.no_extras:
+        # BASELINE configs 2 and 3 and the 2 x 50 311 reading of the headline, on this rank's GPU
+        extras.update(config3_two_films(sc, torch, args.iterations))
+        extras.update(config2_single_film(sc, torch, kernels))
+        extras.update(configH_alt_2x50k(sc, torch, args.iterations))
     if not args.no_extras:
         # BASELINE configs 4 and 5 on all ranks (collective calls: every rank takes part)
         for fn in (config4_scan, config5_stack):
@@ -636,8 +836,10 @@ def main():
             "extras": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.K, args.iterations, args.cpu_budget_s)
-            out["extras"]["gpu_over_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            base = cpu_baseline(args.K, args.iterations, args.cpu_budget_s, parity_sols, parity_field)
+            out["parity"] = base.pop("parity")
+            out["cpu_baseline"] = base
+            out["extras"]["gpu_over_cpu_baseline"] = value / base["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

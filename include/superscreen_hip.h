@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 1
+#define SSA_ABI_VERSION 2
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);

@@ -562,12 +562,17 @@ def biot_savart_film_to_film(*, film1_sites, film1_z0, film1_areas, film1_J, fil
 
 def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
           circulating_currents: Optional[Dict[str, float]] = None,
-          field_conversion: Optional[float] = None) -> List[Dict[str, OracleFilmSolution]]:
+          field_conversion: Optional[float] = None,
+          biot_savart=None) -> List[Dict[str, OracleFilmSolution]]:
     """solver/solve.py:422-547 -- first pass, then ``iterations`` Jacobi rounds.  Returns the
     per-iteration list (length ``iterations + 1``; 1 for a single film, :486-489).
 
     ``applied_field_mT``: float (uniform field in mT) or callable ``f(x, y, z)``.
+    ``biot_savart``: the film-to-film kernel to use (default: the numpy restatement above; the
+    headline-size checks pass the OpenMP C port ``cpu_kernels.biot_savart_film_to_film``, which the
+    CPU tests hold against the numpy form).
     """
+    pair_field = biot_savart or biot_savart_film_to_film
     conv = field_conversion_mT_to_uA_per_um() if field_conversion is None else field_conversion
     applied = {}
     for f in films:
@@ -595,7 +600,7 @@ def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
         for src, tgt in itertools.product(films, repeat=2):  # :499-515
             if src is tgt:
                 continue
-            other[tgt.name] += biot_savart_film_to_film(
+            other[tgt.name] += pair_field(
                 film1_sites=src.mesh.sites, film1_z0=src.z0, film1_areas=src.weights,
                 film1_J=sols[src.name].current_density, film2_sites=tgt.mesh.sites,
                 film2_z0=tgt.z0,

@@ -4,16 +4,13 @@ Drop-in for the ``Device`` / ``Layer`` / ``Polygon`` / ``factorize_model`` / ``s
 loganbvh/superscreen (reference v0.13.0); the numerics run in hand-written HIP kernels for
 gfx950 behind the C ABI declared in ``include/superscreen_hip.h``.  See DESIGN.md.
 """
-import os as _os
+# Process-global HIP settings are the application's to choose, not this package's: nothing is changed at import.
+# One that matters for stacks of >= 3 films: HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES
+# (default 4) hardware queues per priority level and the factorization schedules keep two high-priority chain
+# streams per film busy (csrc/chol.hip, lu.hip); a four-film stack factors 3 % faster with
+# GPU_MAX_HW_QUEUES=8 set BEFORE the HIP runtime starts (bench.py does that; DESIGN.md section 9).
 
-# The factorization schedules keep two high-priority chain streams per film busy (csrc/chol.hip, lu.hip); HIP
-# multiplexes the streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level, and
-# two streams on one queue run one after the other.  Two films fit the default; a stack of four runs 3 % faster
-# with 8 (395 -> 382 ms, DESIGN.md section 9).  Only a default, and only effective if the HIP runtime has not been
-# initialised yet (it reads the variable once).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from .version import __version__  # noqa: F401,E402
+from .version import __version__  # noqa: F401
 
 _LAZY = {
     "Device": "device", "Layer": "device", "Polygon": "device",

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SSA_LIB_PATH") or os.path.join(_PKG, "lib", "libsuper
 
 SSA_F32 = 0
 SSA_F64 = 1
+ABI_VERSION = 2   # SSA_ABI_VERSION of include/superscreen_hip.h
 
 
 class HipLibraryError(RuntimeError):
@@ -106,6 +107,17 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib = ctypes.CDLL(path)
     except OSError as e:  # missing ROCm runtime etc.
         raise HipLibraryError(f"Could not load {path}: {e}") from e
+    # the version first: a stale build (or another one selected through SSA_LIB_PATH) then fails with a
+    # version message instead of a missing-symbol error further down
+    try:
+        lib.ssa_abi_version.restype = c_int
+        lib.ssa_abi_version.argtypes = []
+        version = lib.ssa_abi_version()
+    except AttributeError as e:
+        raise HipLibraryError(f"{path} does not export ssa_abi_version: not a superscreen_amd library") from e
+    if version != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: {path} reports {version}, this package binds version "
+                              f"{ABI_VERSION} (include/superscreen_hip.h). Rebuild with `python -m superscreen_amd.build`.")
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
@@ -113,8 +125,6 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             raise HipLibraryError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.ssa_abi_version() != 1:
-        raise HipLibraryError(f"ABI version mismatch: library reports {lib.ssa_abi_version()}")
     _lib = lib
     return lib
 

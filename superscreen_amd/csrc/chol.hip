@@ -449,12 +449,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // alternating on the caller's stream: the partially filled last round of tiles of one update then overlaps
     // the next update of another matrix, and a matrix' chain no longer waits behind the updates of all the
     // others (4 x 30 301-vertex stack: 350 -> 317 ms; two matrices: no gain, 156.6 vs 158.7 ms, so they keep the
-    // single stream).  SSA_CHOL_UPD_STREAMS=0 / 1 forces either form.
-    static const int update_stream_mode = [] {
-        const char *e = getenv("SSA_CHOL_UPD_STREAMS");
-        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-    }();
-    const bool split_updates = (update_stream_mode < 0) ? count >= 3 : (update_stream_mode == 1 && count > 1);
+    // single stream).
+    const bool split_updates = count >= 3;
     // outer steps (per matrix) that are chain bound: the early finishing steps are slipped into the last 16 of them
     constexpr int64_t kTailCols = 4096;
     FinishPlan<T> plans[kMaxLanes];

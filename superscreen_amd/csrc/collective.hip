@@ -6,9 +6,12 @@
 // librccl.so is opened lazily with dlopen: libsuperscreen_hip.so has no load-time dependency on RCCL
 // (single-GPU users never touch it), and inside a PyTorch process the name resolves to the RCCL that
 // torch already loaded (same soname), so there is one RCCL per process.
+//
+// The four entry points used are declared HERE, by their public, stable NCCL 2 ABI (opaque communicator pointer,
+// 128-byte unique id passed by value, int-sized enums: ncclSuccess = 0, ncclSum = 0, ncclFloat32 = 7,
+// ncclFloat64 = 8): the library builds on ROCm installations without the RCCL development headers.
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 
@@ -16,6 +19,17 @@
 
 namespace ssa {
 namespace {
+
+struct ncclUniqueId {
+    char internal[SSA_RCCL_UNIQUE_ID_BYTES];
+};
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclRedOp_t ncclSum = 0;
+constexpr ncclDataType_t ncclFloat32 = 7, ncclFloat64 = 8;
 
 struct RcclApi {
     void *handle = nullptr;

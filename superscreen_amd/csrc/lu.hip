@@ -1067,10 +1067,8 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     LuLane *lanes = lane_set->lanes;
     // The trailing updates of two matrices alternate on ONE stream, as in the Cholesky schedule (two concurrent
     // full-chip GEMMs halve each other's L2 reach: config H 205.6 -> 200.5 ms); three or more matrices keep one update
-    // stream each (a matrix' chain would wait behind the updates of all the others).  SSA_LU_UPD_STREAMS=0 / 1 forces
-    // the shared / the per-matrix form.
-    const char *upd_env = getenv("SSA_LU_UPD_STREAMS");
-    const bool shared_updates = upd_env != nullptr ? upd_env[0] == '0' : count < 3;
+    // stream each (a matrix' chain would wait behind the updates of all the others).
+    const bool shared_updates = count < 3;
     NpScratch<T> scratch[kMaxLuLanes];
     int64_t nmax = 0;
     for (int i = 0; i < count; ++i) {
@@ -1101,8 +1099,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     constexpr int64_t kDelayMinCols = 8192;   // while the trailing matrix is large
     int64_t pending_from[kMaxLuLanes] = {};
     int64_t blocks_finished[kMaxLuLanes] = {};
-    const char *fin_env = getenv("SSA_LU_EARLY_FINISH");   // development switch: 0 = all block inverses after the last panel
-    const bool early_finish = fin_env == nullptr || fin_env[0] != '0';
+    constexpr bool early_finish = true;   // block inverses of closed 4096-blocks during the chain-bound tail
     bool rest_recorded[kMaxLuLanes] = {};
     for (int64_t k0 = 0; k0 + NB < nmax; k0 += NB) {
         for (int i = 0; i < count; ++i) {

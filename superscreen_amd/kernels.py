@@ -193,6 +193,36 @@ def lu_factor(A: torch.Tensor, n: int) -> LUFactors:
 
 
 _lu_streams: dict = {}
+_num_cus: dict = {}
+LU_PANEL_ROWS_PER_GROUP = 256   # kPanelThreads of csrc/lu.hip: rows per workgroup of the cooperative panel kernel
+
+
+def _device_cus(dev) -> int:
+    if dev.index not in _num_cus:
+        cus = ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            check(load_library().ssa_device_info(ctypes.byref(cus), None, None, 0), "ssa_device_info")
+        _num_cus[dev.index] = int(cus.value)
+    return _num_cus[dev.index]
+
+
+def lu_concurrency_groups(orders: Sequence[int], num_cus: int) -> List[List[int]]:
+    """Which matrices of a batch may be factored side by side by the pivoting route.  Its exact sub-panel kernel
+    (``lu_panel_kernel``) is cooperative: ``ceil(n / 256)`` workgroups of one CU each (132 KB of LDS) that
+    spin-wait on one another.  Kernels of several matrices that are resident only in part would wait for
+    workgroups that cannot be placed, so matrices share the chip only while the workgroups of ALL their panel
+    kernels fit on it together; the rest waits for the next group.  Consecutive runs, order preserved."""
+    groups, cur, used = [], [], 0
+    for i, n in enumerate(orders):
+        need = -(-int(n) // LU_PANEL_ROWS_PER_GROUP)
+        if cur and used + need > num_cus:
+            groups.append(cur)
+            cur, used = [], 0
+        cur.append(i)
+        used += need
+    if cur:
+        groups.append(cur)
+    return groups
 
 
 def lu_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[LUFactors]:
@@ -200,39 +230,47 @@ def lu_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[LUFacto
     own: a factorization is a strictly sequential chain of latency-bound panel kernels and MFMA trailing
     updates, so the panels of one matrix run beside the updates of the others (the Cholesky route does the
     same inside one schedule, ``ssa_chol_factor_batch``).  Every matrix has its own workspace; the factors
-    do not depend on what they are batched with."""
+    do not depend on what they are batched with.  Matrices whose cooperative panel kernels would not all be
+    resident together are factored group after group (:func:`lu_concurrency_groups`)."""
     lib = load_library()
     if not systems:
         return []
     dev = systems[0][0].device
     main = torch.cuda.current_stream(dev)
+    groups = lu_concurrency_groups([n for _, n in systems], _device_cus(dev))
+    width = max(len(g) for g in groups)
     side = _lu_streams.setdefault(dev.index, [])
-    while len(side) < len(systems) - 1:
+    while len(side) < width - 1:
         side.append(torch.cuda.Stream(device=dev))
-    streams = [main] + side[:len(systems) - 1]
-    start = torch.cuda.Event()
-    start.record(main)
     pending = []
-    for (A, n), st in zip(systems, streams):
-        dt = dtype_code(A.dtype)
-        ipiv = torch.empty(n, dtype=torch.int32, device=dev)
-        info = torch.zeros(1, dtype=torch.int32, device=dev)
-        aux = torch.empty(lib.ssa_lu_aux_bytes(n, dt) // A.element_size(), dtype=A.dtype, device=dev)
-        nbytes = lib.ssa_lu_factor_workspace_bytes(n, dt)
-        ws = _ws(nbytes, dev)
-        pending.append((A, n, ipiv, info, aux, ws, nbytes, dt, st))
-    for A, n, ipiv, info, aux, ws, nbytes, dt, st in pending:
-        if st is not main:
-            st.wait_event(start)          # after the assembly (and the zero-fill of info) on the caller's stream
-            for t in (A, ipiv, info, aux, ws):
-                t.record_stream(st)
-        check(lib.ssa_lu_factor(ptr(A), n, A.shape[1], ptr(ipiv), ptr(info), ptr(aux), dt, ptr(ws), nbytes,
-                                st.cuda_stream), "ssa_lu_factor")
-    for *_, st in pending:
-        if st is not main:
-            done = torch.cuda.Event()
-            done.record(st)
-            main.wait_event(done)
+    for group in groups:
+        streams = [main] + side[:len(group) - 1]
+        for i, st in zip(group, streams):
+            A, n = systems[i]
+            dt = dtype_code(A.dtype)
+            ipiv = torch.empty(n, dtype=torch.int32, device=dev)
+            info = torch.zeros(1, dtype=torch.int32, device=dev)
+            aux = torch.empty(lib.ssa_lu_aux_bytes(n, dt) // A.element_size(), dtype=A.dtype, device=dev)
+            nbytes = lib.ssa_lu_factor_workspace_bytes(n, dt)
+            ws = _ws(nbytes, dev)
+            pending.append((A, n, ipiv, info, aux, ws, nbytes, dt, st))
+        # fork: after the assembly (and the zero-fill of info) on the caller's stream -- and after the join of
+        # the previous group, which is what keeps two groups' panel kernels apart
+        start = torch.cuda.Event()
+        start.record(main)
+        members = pending[-len(group):]
+        for A, n, ipiv, info, aux, ws, nbytes, dt, st in members:
+            if st is not main:
+                st.wait_event(start)
+                for t in (A, ipiv, info, aux, ws):
+                    t.record_stream(st)
+            check(lib.ssa_lu_factor(ptr(A), n, A.shape[1], ptr(ipiv), ptr(info), ptr(aux), dt, ptr(ws), nbytes,
+                                    st.cuda_stream), "ssa_lu_factor")
+        for *_, st in members:
+            if st is not main:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
     out = []
     for A, n, ipiv, info, aux, ws, nbytes, dt, st in pending:
         ipiv_h = np.ascontiguousarray(ipiv.cpu().numpy())  # synchronises the stream

@@ -214,6 +214,11 @@ class FilmDeviceData:
                 lap=(put(lap.indptr.astype(np.int64)), put(lap.indices.astype(np.int64)), put(lap.data)),
                 grad=(put(ptr_), put(idx_), put(vx), put(vy)),
             )
+            # The uploads above are non-blocking copies on the CURRENT stream; what is cached here is used by later
+            # calls that may run under another stream, so the cache only ever holds completed copies.
+            done = torch.cuda.Event()
+            done.record()
+            done.synchronize()
             ops._device_cache[key] = geo
         self.n = len(mesh.sites)
         self.dtype, self.tdtype, self.device = dtype, tdt, dev

@@ -121,6 +121,8 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                 ha = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
                 g1 = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
                 for hole_name, hs in model.hole_systems[name].items():
+                    if len(hs.indices) == 0:   # a hole without a mesh vertex: an empty system (solver.py)
+                        continue
                     kernels.index_add_scalar(g1, hs.indices_device, column_currents[k].get(hole_name, 0))
                     kernels.gemv(hs.A_device, fd.n, len(hs.indices), g1, xidx=hs.indices_device, y=ha,
                                  alpha=-1.0, beta=1.0)
@@ -140,19 +142,23 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
             g1_all, ha_all = hole_terms(name)
             g = g1_all.clone()
             other = None if other_d is None else other_d[name]
-            if system.chol is not None:
+            has_unknowns = len(system.indices) > 0   # a film without unknowns: empty system, g stays at the hole terms
+            if not has_unknowns:
+                gf = None
+            elif system.chol is not None:
                 h = kernels.film_rhs(applied_d[name], other, ha_all, system.indices_device, nvec=nvec)
                 gf = solve_columns(lambda B: kernels.chol_solve(system.chol, B),
                                    kernels.row_scale(h, system.neg_w_device))
             else:
                 h = kernels.film_rhs(applied_d[name], other, ha_all, system.rhs_indices_device, nvec=nvec)
                 gf = solve_columns(lambda B: kernels.lu_solve_permuted(system.factors, B), h)
-            kernels.scatter_add(g, system.indices_device, gf, nvec=nvec)
+            if gf is not None:
+                kernels.scatter_add(g, system.indices_device, gf, nvec=nvec)
             J = kernels.current_density(*fd.grad, g, nvec=nvec)              # [n, nvec, 2]
             sf = None
             if want_self_field:
                 if (model.self_field_mode in ("auto", "london") and fd.tdtype == torch.float64
-                        and not info.lambda_info.inhomogeneous):
+                        and not info.lambda_info.inhomogeneous and has_unknowns):
                     # interior rows from the London equation, the rest by the all-pairs sum (solver.py)
                     if system.exterior_device is None:
                         exterior = np.setdiff1d(np.arange(fd.n, dtype=np.int64), system.indices)
@@ -199,6 +205,8 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
             # an iterate that is not returned only feeds the next solve: its coupling field is needed on
             # the unknowns' rows of the target film (h = Hz[ix] - ..., solve_film.py:529) and nowhere else
             only_unknowns = None if (all_iterations or last) else model.film_systems[tgt].indices_device
+            if only_unknowns is not None and len(model.film_systems[tgt].indices) == 0:
+                continue   # nothing of this iterate's coupling field is used
             kernels.biot_savart_multi(s.xy[b:e], s.w_t[b:e], results[src][1][b:e], t.xy,
                                       info_of[tgt].z0 - info_of[src].z0, other_d[tgt], accumulate=True,
                                       rows=only_unknowns)

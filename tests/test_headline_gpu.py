@@ -267,3 +267,127 @@ def test_four_film_stack_vs_oracle(sc):
             assert relerr(fs.self_field, ref[nm].self_field) < 1e-9, (it, nm)
             if it:
                 assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < 1e-9, (it, nm)
+
+
+# ------------------------------------------------------------------------------------------------
+# (e) the north_star's acceptance number at its own size: config H against the oracle
+# ------------------------------------------------------------------------------------------------
+def _oracle_films_full_size(K, kinds, threads=16):
+    """Oracle films of the K-ring stack at full size: dense Q by the OpenMP C port of ``q_matrix``
+    (distance.py:87-115; held against the numpy restatement by the CPU tests), ``A = Q[ix, ix] w - Lambda Del2``
+    (solve_film.py:296-305) and ``lu_factor(-A)`` (:279) by scipy."""
+    import build_oracle
+    import cpu_kernels
+    from matplotlib.path import Path
+
+    from superscreen_amd import synthetic
+
+    build_oracle.build(verbose=False)
+    sites, elements, dr = synthetic.ring_disk_mesh(K)
+    mesh = orc.make_mesh(sites, elements, build_Q=False)
+    Kf = synthetic.film_rings(K)
+    in_film = Path(synthetic.circle_points((Kf + 0.5) * dr), closed=True).contains_points(sites)
+    in_hole = Path(synthetic.circle_points((Kf // 3 + 0.5) * dr, 201), closed=True).contains_points(sites)
+    q = cpu_kernels.q_matrix(sites)
+    C = orc.C_vector(sites)
+    diag = -(C + np.einsum("ij, j -> i", q, mesh.weights)) / mesh.weights   # device/mesh.py:453-458
+    np.fill_diagonal(q, diag)
+    np.negative(q, out=q)
+    mesh.Q = q
+    films = []
+    for i, kind in enumerate(kinds):
+        holes = {f"hole{i}": in_hole} if kind == "washer" else {}
+        films.append(orc.make_film(f"{kind}{i}", mesh, z0=0.5 * i, Lambda=0.1, in_film=in_film, holes_mask=holes))
+    return films, cpu_kernels
+
+
+def test_configH_full_size_vs_oracle(sc):
+    """BASELINE's headline device (2 x 25 117 vertices, 18 150 + 20 419 unknowns) against the CPU oracle --
+    scipy ``lu_solve(lu_factor(-A), h)`` inside the Jacobi loop (solve_film.py:526-531, solve.py:491-536) --
+    every iterate, stream-function max-rel-error < 1e-9 (north_star: < 1e-6 at this size)."""
+    from threadpoolctl import threadpool_limits
+
+    from superscreen_amd import synthetic
+
+    K, kinds, iters, field = 91, ("washer", "disk"), 10, 0.3
+    device = synthetic.make_stack_device(K, kinds, solve_dtype="float64")
+    sols = sc.solve(device, applied_field=sc.ConstantField(field), iterations=iters, progress_bar=False)
+    with threadpool_limits(limits=16):
+        films, cpu_kernels = _oracle_films_full_size(K, kinds)
+        assert [len(f.film_indices) for f in films] == [18150, 20419]
+        trace = orc.solve(films, field, iterations=iters, biot_savart=cpu_kernels.biot_savart_film_to_film)
+    assert len(sols) == len(trace) == iters + 1
+    worst = 0.0
+    for it, (sol, ref) in enumerate(zip(sols, trace)):
+        for nm in device.films:
+            fs = sol.film_solutions[nm]
+            worst = max(worst, relerr(fs.stream, ref[nm].stream))
+            assert relerr(fs.stream, ref[nm].stream) < 1e-9, (it, nm)
+            assert relerr(fs.current_density, ref[nm].current_density) < 1e-8, (it, nm)
+            assert relerr(fs.self_field, ref[nm].self_field) < 1e-9, (it, nm)
+            if it:
+                assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < 1e-9, (it, nm)
+    print(f"config H vs oracle: stream max-rel-error {worst:.2e} over {iters + 1} iterates")
+
+
+def _host_rows_of_A(sites, weights, C, lap, Lambda, rows_v, cols_v):
+    """Rows of ``A = Q[ix, ix] w[ix] - Lambda[ix] Del2[ix, ix]`` (solve_film.py:296-305) for the vertices
+    ``rows_v`` and the columns ``cols_v``, straight from the definitions (distance.py:87-115,
+    device/mesh.py:435-458): O(n) host work per row, no n^2 object."""
+    out = np.empty((len(rows_v), len(cols_v)))
+    lap = lap.tocsr()
+    for k, i in enumerate(rows_v):
+        d = sites - sites[i]
+        with np.errstate(divide="ignore"):
+            q = (d[:, 0] ** 2 + d[:, 1] ** 2) ** -1.5 / (4 * np.pi)
+        q[i] = 0.0
+        Qrow = -q
+        Qrow[i] = (C[i] + np.dot(q, weights)) / weights[i]
+        lap_row = np.asarray(lap[[i], :].todense()).ravel()
+        out[k] = Qrow[cols_v] * weights[cols_v] - Lambda * lap_row[cols_v]
+    return out
+
+
+@pytest.mark.parametrize("K", [129, 91])
+def test_system_assemble_sampled_rows_at_full_size(sc, K):
+    """``ssa_system_assemble`` at n_i = 41 419 (config 2) / 20 419 (config H): sampled rows -- the first, the last,
+    rows either side of every 2^k and tile boundary a 32-bit index slip would hit, and random ones -- against
+    numpy rows computed on the host from the definitions.  Both forms: the reference's ``A`` and the
+    lower-triangular ``diag(w) A`` the Cholesky route consumes."""
+    from superscreen_amd import kernels, synthetic
+
+    device = synthetic.make_stack_device(K, ("disk",), solve_dtype="float64")
+    name = list(device.films)[0]
+    model = sc.factorize_model(device=device, current_units="uA")
+    fd, system = model.film_data[name], model.film_systems[name]
+    ix = system.indices
+    ni = len(ix)
+    mesh = device.meshes[name]
+    ops = orc.make_mesh(mesh.sites, mesh.elements, build_Q=False)   # the oracle's operators, not the product's
+    rng = np.random.default_rng(3)
+    picks = {0, 1, ni - 1, ni - 2, ni // 2}
+    for b in (255, 256, 4095, 4096, 8191, 8192, 16383, 16384, 32767, 32768):
+        if b < ni:
+            picks.add(b)
+    picks.update(int(v) for v in rng.integers(0, ni, size=12))
+    rows = np.array(sorted(picks), dtype=np.int64)
+    ref = _host_rows_of_A(mesh.sites, ops.weights, orc.C_vector(mesh.sites), ops.laplacian, 0.1, ix[rows], ix)
+    ix_d = system.indices_device
+    A = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0, dtype="float64")
+    got = A[torch.from_numpy(rows).to(A.device), :ni].cpu().numpy()
+    del A
+    assert relerr(got, ref) < 1e-12
+    for r, gr, rr in zip(rows, got, ref):       # row by row: a slip in one row must not hide under the global max
+        assert np.max(np.abs(gr - rr)) / np.max(np.abs(rr)) < 1e-12, int(r)
+    npad = kernels.chol_padded_n(ni)
+    S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0, dtype="float64",
+                                row_scale=fd.w, lower_only=True, ld=kernels.padded_ld(npad, "float64"),
+                                alloc_rows=npad)
+    gotS = S[torch.from_numpy(rows).to(S.device), :ni].cpu().numpy()
+    del S
+    w = ops.weights
+    for r, gr, rr in zip(rows, gotS, ref):
+        want = w[ix[r]] * rr[:r + 1]
+        assert np.max(np.abs(gr[:r + 1] - want)) / np.max(np.abs(want)) < 1e-12, int(r)
+    del model
+    torch.cuda.empty_cache()

@@ -132,7 +132,7 @@ def test_library_exports_every_declared_symbol():
 
         hip_build.build(force=False, verbose=False)  # cross-compiles for gfx950 without a GPU
     lib = _hip.load_library()  # checks every symbol; no compute call is made without a GPU
-    assert lib.ssa_abi_version() == 1
+    assert lib.ssa_abi_version() == _hip.ABI_VERSION == 2
     assert lib.ssa_error_string(-3).decode().startswith("workspace")
     perm = np.empty(4, dtype=np.int64)
     ipiv = np.array([2, 1, 3, 3], dtype=np.int32)
@@ -336,3 +336,18 @@ def test_polygon_and_device_transforms():
     assert device.translate(dz=0.3).mirror_layers(about_z=1.0).layers["base"].z0 == pytest.approx(0.7)
     with pytest.raises(TypeError):
         device.rotate(10, origin=[0, 0])
+
+
+def test_lu_concurrency_groups():
+    """Which matrices the pivoting LU route factors side by side: the cooperative panel kernels of one group
+    (ceil(n / 256) one-CU workgroups each) must fit on the chip together (kernels.lu_concurrency_groups)."""
+    from superscreen_amd.kernels import lu_concurrency_groups
+
+    assert lu_concurrency_groups([], 256) == []
+    assert lu_concurrency_groups([1657], 256) == [[0]]
+    assert lu_concurrency_groups([18150, 20419], 256) == [[0, 1]]                  # 71 + 80
+    assert lu_concurrency_groups([24571] * 4, 256) == [[0, 1], [2, 3]]             # 4 x 96: two at a time
+    assert lu_concurrency_groups([41419, 41419], 256) == [[0], [1]]                # 162 each
+    assert lu_concurrency_groups([70000, 100, 100], 256) == [[0], [1, 2]]          # an oversize matrix runs alone
+    assert lu_concurrency_groups([100, 65000, 100], 256) == [[0, 1, 2]]                 # 1 + 254 + 1
+    assert lu_concurrency_groups([100, 65300, 100], 256) == [[0], [1], [2]]             # 1 | 256 | 1

@@ -30,8 +30,12 @@ def relerr(a, b):
 
 @pytest.mark.parametrize("name,kind", [("disk_K10.npz", "disk"), ("disk_K26.npz", "disk"),
                                        ("washer_K17.npz", "washer")])
-@pytest.mark.parametrize("mode", ["matrix_free", "dense"])
+@pytest.mark.parametrize("mode", ["auto", "london", "matrix_free", "dense"])
 def test_single_film_vs_reference_fixture(sc, golden, name, kind, mode):
+    """Every self-field mode against the REFERENCE's recorded outputs, Lambda in {0, 0.1, 1}: "auto" is what
+    ``factorize_model`` does by default (float64, uniform Lambda: the London equation on the unknowns' rows +
+    the all-pairs sum on the rest, solver.py), so the headline's default path is pinned to the reference here
+    and not to the product's own all-pairs kernel."""
     from superscreen_amd import synthetic
 
     d = golden(name)
@@ -887,3 +891,38 @@ def test_lu_route_falls_back_to_partial_pivoting(monkeypatch):
             assert relerr(b.film_solutions[nm].stream, a.film_solutions[nm].stream) < 1e-12
     lu, piv = model.film_systems["disk1"].lu_piv
     assert np.array_equal(piv, np.arange(len(piv))) and lu.shape == (len(piv), len(piv))
+
+
+@pytest.mark.gpu
+def test_lu_factor_batch_keeps_cooperative_panels_coresident():
+    """The pivoting route's exact sub-panel kernel is cooperative (ceil(n / 256) workgroups of one CU each that
+    spin-wait on one another).  Three GENERAL matrices (every sub-panel needs interchanges, so the cooperative
+    kernel really runs) whose panel kernels together need more workgroups than the chip has CUs: factored side by
+    side they could all be resident only in part and time out (info = -1); ``lu_factor_batch`` runs them group
+    after group instead.  Checked by the residual of a solve with each factor."""
+    from superscreen_amd import kernels
+
+    cus = kernels.device_info()[0]
+    n = 256 * (cus // 3 + 2)                      # 3 x ceil(n / 256) > CUs, 2 x ceil(n / 256) <= CUs
+    orders = [n, n - 77, n - 300]
+    groups = kernels.lu_concurrency_groups(orders, cus)
+    assert groups == [[0, 1], [2]]
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    mats, copies = [], []
+    for m in orders:
+        ld = kernels.padded_ld(m, "float64")
+        A = torch.zeros((m, ld), dtype=torch.float64, device="cuda")
+        A[:, :m] = torch.randn((m, m), dtype=torch.float64, device="cuda", generator=gen)
+        copies.append(A.clone())
+        mats.append(A)
+    factors = kernels.lu_factor_batch([(A, m) for A, m in zip(mats, orders)])
+    for f, A0, m in zip(factors, copies, orders):
+        assert f.info == 0
+        piv = f.ipiv.cpu().numpy()
+        assert (piv != np.arange(m)).sum() > m // 2        # interchanges nearly everywhere
+        b = torch.randn(m, dtype=torch.float64, device="cuda", generator=gen)
+        x = kernels.lu_solve(f, b.clone())
+        r = kernels.gemv(A0, m, m, x) - b
+        assert float(r.abs().max() / b.abs().max()) < 1e-7
+    del mats, copies, factors
+    torch.cuda.empty_cache()
