@@ -45,6 +45,19 @@ inline int raise_dynamic_lds(DeviceFlags &flags, std::initializer_list<std::pair
     return SSA_OK;
 }
 
+// Compute units of the current device (cached per device; 256 on an MI355X), 0 if the query fails.
+inline int device_cu_count() {
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (current_device(&dev) != SSA_OK) return 0;
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

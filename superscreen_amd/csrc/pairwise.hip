@@ -18,6 +18,28 @@ struct alignas(16) Source {
     double x, y, a, b;
 };
 
+// r2^(-3/2) in full double precision: hardware v_rsq_f64 seed (relative error e0 <= 2^-26) and the series
+// (1 - e)^(-3/2) = 1 + e (3/2 + 15/8 e) + O(e^3), e = 1 - r2 y0^2: 6 FP64 operations behind the seed (a corrected
+// 1/sqrt followed by its cube takes 7), with the cube of the SEED off the dependent chain.
+__device__ __forceinline__ double inv_r3(double r2) {
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    const double y2 = y0 * y0;
+    const double e = __builtin_fma(-r2, y2, 1.0);
+    const double y3 = y2 * y0;
+    const double p = __builtin_fma(1.875, e, 1.5);
+    return __builtin_fma(y3 * e, p, y3);
+}
+
+// Register tile: every lane owns kTPL targets (256 apart, so that loads and stores stay coalesced); one LDS
+// broadcast of a staged source (32 bytes) feeds kTPL pair evaluations instead of one, and the kTPL independent
+// dependency chains per lane keep the FP64 pipe issuing while a v_rsq_f64 is in flight.  A workgroup covers
+// 256 * kTPL targets x one source slice; padding entries of a stage are inert sources (far away, zero charge).
+#ifndef SSA_PAIR_TPL
+#define SSA_PAIR_TPL 2
+#endif
+constexpr int kTPL = SSA_PAIR_TPL;   // measured at 25 117 x 25 117 (same box): self field 1.52 / 1.75 / 1.71 Tpair/s for 4 / 2 / 1
+constexpr double kFarAway = 1.0e15;
+
 template <typename T>
 __global__ __launch_bounds__(kPairThreads) void biot_savart_partial_kernel(
     const double *__restrict__ src_xy, const T *__restrict__ src_areas,
@@ -25,12 +47,18 @@ __global__ __launch_bounds__(kPairThreads) void biot_savart_partial_kernel(
     const double *__restrict__ tgt_xy, int64_t nt, double dz2, double *__restrict__ partial) {
     __shared__ Source s_src[kPairThreads];
     const int tid = threadIdx.x;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * (kPairThreads * kTPL) + tid;
     const int64_t j_begin = src_begin + static_cast<int64_t>(blockIdx.y) * slice_len;
     const int64_t j_end = (j_begin + slice_len < src_end) ? j_begin + slice_len : src_end;
-    const int64_t ic = (i < nt) ? i : nt - 1;
-    const double xi = tgt_xy[2 * ic], yi = tgt_xy[2 * ic + 1];
-    double acc = 0.0;
+    double xi[kTPL], yi[kTPL], acc[kTPL];
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) {
+        const int64_t i = i0 + r * kPairThreads;
+        const int64_t ic = (i < nt) ? i : nt - 1;
+        xi[r] = tgt_xy[2 * ic];
+        yi[r] = tgt_xy[2 * ic + 1];
+        acc[r] = 0.0;
+    }
     for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
         const int64_t j = t0 + tid;
         Source s;
@@ -41,23 +69,30 @@ __global__ __launch_bounds__(kPairThreads) void biot_savart_partial_kernel(
             s.a = a * src_J[2 * j];      // (1/4pi) a_j Jx_j
             s.b = a * src_J[2 * j + 1];  // (1/4pi) a_j Jy_j
         } else {
-            s.x = 0.0; s.y = 0.0; s.a = 0.0; s.b = 0.0;
+            s.x = kFarAway; s.y = kFarAway; s.a = 0.0; s.b = 0.0;
         }
         __syncthreads();
         s_src[tid] = s;
         __syncthreads();
         const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
+        const int cnt2 = (cnt + 1) & ~1;   // entries [cnt, 256) of the stage are inert
+#pragma unroll 2
+        for (int k = 0; k < cnt2; ++k) {
             const Source q = s_src[k];
-            const double dx = xi - q.x, dy = yi - q.y;
-            const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
-            const double y = rsqrt_f64(r2);
-            const double cross = __builtin_fma(q.a, dy, -(q.b * dx));  // Jx dy - Jy dx
-            acc = __builtin_fma(cross * y, y * y, acc);
+#pragma unroll
+            for (int r = 0; r < kTPL; ++r) {
+                const double dx = xi[r] - q.x, dy = yi[r] - q.y;
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
+                const double cross = __builtin_fma(q.a, dy, -(q.b * dx));  // Jx dy - Jy dx
+                acc[r] = __builtin_fma(cross, inv_r3(r2), acc[r]);
+            }
         }
     }
-    if (i < nt) partial[static_cast<int64_t>(blockIdx.y) * nt + i] = acc;
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) {
+        const int64_t i = i0 + r * kPairThreads;
+        if (i < nt) partial[static_cast<int64_t>(blockIdx.y) * nt + i] = acc[r];
+    }
 }
 
 // Field of a current sheet at arbitrary points in space (sources/current.py:13-110, the numba
@@ -178,52 +213,88 @@ __global__ void sheet_field_combine_kernel(const double *__restrict__ partial, i
 }
 
 // out[i] = alpha * ( qdiag_i w_i g_i - sum_{j != i} q_ij w_j g_j )   (partials: the sum only)
+// Shared body of the two self-field kernels: the staged tile [t0, t0 + cnt) of sources against the kTPL targets
+// of a lane (vertex indices it[r]).  Only a wave one of whose targets lies inside the tile pays for the
+// j == i test.
+struct alignas(8) Charge {
+    double x, y, c;
+};
+
+__device__ __forceinline__ void self_tile(const double *s_x, const double *s_y, const double *s_c, int64_t t0,
+                                          int cnt, const int64_t (&it)[kTPL], const double (&xi)[kTPL],
+                                          const double (&yi)[kTPL], double (&acc)[kTPL]) {
+    bool hit = false;
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) hit |= (it[r] >= t0 && it[r] < t0 + cnt);
+    const int cnt2 = (cnt + 1) & ~1;
+    if (__any(hit)) {
+#pragma unroll 2
+        for (int k = 0; k < cnt2; ++k) {
+            const double qx = s_x[k], qy = s_y[k], qc = s_c[k];
+#pragma unroll
+            for (int r = 0; r < kTPL; ++r) {
+                const double dx = xi[r] - qx, dy = yi[r] - qy;
+                const double t = qc * inv_r3(__builtin_fma(dx, dx, dy * dy));
+                acc[r] += (t0 + k == it[r]) ? 0.0 : t;
+            }
+        }
+    } else {
+#pragma unroll 2
+        for (int k = 0; k < cnt2; ++k) {
+            const double qx = s_x[k], qy = s_y[k], qc = s_c[k];
+#pragma unroll
+            for (int r = 0; r < kTPL; ++r) {
+                const double dx = xi[r] - qx, dy = yi[r] - qy;
+                acc[r] = __builtin_fma(qc, inv_r3(__builtin_fma(dx, dx, dy * dy)), acc[r]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_charges(const double *__restrict__ xy, const double *__restrict__ w,
+                                              const T *__restrict__ g, int64_t j, int64_t j_end, int tid, double *s_x,
+                                              double *s_y, double *s_c) {
+    double sx = kFarAway, sy = kFarAway, sc = 0.0;   // inert padding
+    if (j < j_end) {
+        sx = xy[2 * j];
+        sy = xy[2 * j + 1];
+        sc = kOneOver4Pi * (w[j] * static_cast<double>(g[j]));
+    }
+    __syncthreads();
+    s_x[tid] = sx; s_y[tid] = sy; s_c[tid] = sc;
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(kPairThreads) void self_field_partial_kernel(
     const double *__restrict__ xy, const double *__restrict__ w, const T *__restrict__ g,
     int64_t n, int64_t slice_len, double *__restrict__ partial) {
     __shared__ double s_x[kPairThreads], s_y[kPairThreads], s_c[kPairThreads];
     const int tid = threadIdx.x;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * (kPairThreads * kTPL) + tid;
     const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
     const int64_t j_end = (j_begin + slice_len < n) ? j_begin + slice_len : n;
-    const int64_t ic = (i < n) ? i : n - 1;
-    const double xi = xy[2 * ic], yi = xy[2 * ic + 1];
-    double acc = 0.0;
-    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
-        const int64_t j = t0 + tid;
-        double sx = 0.0, sy = 0.0, sc = 0.0;
-        if (j < j_end) {
-            sx = xy[2 * j];
-            sy = xy[2 * j + 1];
-            sc = kOneOver4Pi * (w[j] * static_cast<double>(g[j]));
-        }
-        __syncthreads();
-        s_x[tid] = sx; s_y[tid] = sy; s_c[tid] = sc;
-        __syncthreads();
-        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
-        // only the source tile that overlaps this workgroup's own targets can contain j == i
-        const int64_t i_first = static_cast<int64_t>(blockIdx.x) * kPairThreads;
-        if (t0 < i_first + kPairThreads && t0 + cnt > i_first) {
-#pragma unroll 4
-            for (int k = 0; k < cnt; ++k) {
-                const double dx = xi - s_x[k], dy = yi - s_y[k];
-                const double r2 = __builtin_fma(dx, dx, dy * dy);
-                const double y = rsqrt_f64(r2);
-                const double t = (t0 + k == i) ? 0.0 : (s_c[k] * y) * (y * y);
-                acc += t;
-            }
-        } else {
-#pragma unroll 4
-            for (int k = 0; k < cnt; ++k) {
-                const double dx = xi - s_x[k], dy = yi - s_y[k];
-                const double r2 = __builtin_fma(dx, dx, dy * dy);
-                const double y = rsqrt_f64(r2);
-                acc = __builtin_fma(s_c[k] * y, y * y, acc);
-            }
-        }
+    int64_t it[kTPL];
+    double xi[kTPL], yi[kTPL], acc[kTPL];
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) {
+        const int64_t i = i0 + r * kPairThreads;
+        it[r] = (i < n) ? i : n - 1;
+        xi[r] = xy[2 * it[r]];
+        yi[r] = xy[2 * it[r] + 1];
+        acc[r] = 0.0;
     }
-    if (i < n) partial[static_cast<int64_t>(blockIdx.y) * n + i] = acc;
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        stage_charges(xy, w, g, t0 + tid, j_end, tid, s_x, s_y, s_c);
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+        self_tile(s_x, s_y, s_c, t0, cnt, it, xi, yi, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) {
+        const int64_t i = i0 + r * kPairThreads;
+        if (i < n) partial[static_cast<int64_t>(blockIdx.y) * n + i] = acc[r];
+    }
 }
 
 template <typename T>
@@ -260,32 +331,29 @@ __global__ __launch_bounds__(kPairThreads) void self_field_rows_partial_kernel(
     const int64_t *__restrict__ rows, int64_t nr, int64_t slice_len, double *__restrict__ partial) {
     __shared__ double s_x[kPairThreads], s_y[kPairThreads], s_c[kPairThreads];
     const int tid = threadIdx.x;
-    const int64_t k = static_cast<int64_t>(blockIdx.x) * kPairThreads + tid;
-    const int64_t i = rows[(k < nr) ? k : nr - 1];
+    const int64_t k0 = static_cast<int64_t>(blockIdx.x) * (kPairThreads * kTPL) + tid;
     const int64_t j_begin = static_cast<int64_t>(blockIdx.y) * slice_len;
     const int64_t j_end = (j_begin + slice_len < n) ? j_begin + slice_len : n;
-    const double xi = xy[2 * i], yi = xy[2 * i + 1];
-    double acc = 0.0;
-    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
-        const int64_t j = t0 + tid;
-        double sx = 0.0, sy = 0.0, sc = 0.0;
-        if (j < j_end) {
-            sx = xy[2 * j];
-            sy = xy[2 * j + 1];
-            sc = kOneOver4Pi * (w[j] * static_cast<double>(g[j]));
-        }
-        __syncthreads();
-        s_x[tid] = sx; s_y[tid] = sy; s_c[tid] = sc;
-        __syncthreads();
-        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
-#pragma unroll 4
-        for (int q = 0; q < cnt; ++q) {
-            const double dx = xi - s_x[q], dy = yi - s_y[q];
-            const double y = rsqrt_f64(__builtin_fma(dx, dx, dy * dy));
-            acc += (t0 + q == i) ? 0.0 : (s_c[q] * y) * (y * y);
-        }
+    int64_t it[kTPL];
+    double xi[kTPL], yi[kTPL], acc[kTPL];
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) {
+        const int64_t k = k0 + r * kPairThreads;
+        it[r] = rows[(k < nr) ? k : nr - 1];
+        xi[r] = xy[2 * it[r]];
+        yi[r] = xy[2 * it[r] + 1];
+        acc[r] = 0.0;
     }
-    if (k < nr) partial[static_cast<int64_t>(blockIdx.y) * nr + k] = acc;
+    for (int64_t t0 = j_begin; t0 < j_end; t0 += kPairThreads) {
+        stage_charges(xy, w, g, t0 + tid, j_end, tid, s_x, s_y, s_c);
+        const int cnt = (j_end - t0 < kPairThreads) ? static_cast<int>(j_end - t0) : kPairThreads;
+        self_tile(s_x, s_y, s_c, t0, cnt, it, xi, yi, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < kTPL; ++r) {
+        const int64_t k = k0 + r * kPairThreads;
+        if (k < nr) partial[static_cast<int64_t>(blockIdx.y) * nr + k] = acc[r];
+    }
 }
 
 template <typename T>
@@ -363,6 +431,21 @@ inline int pick_slices(int64_t nt, int64_t ns) {
     return static_cast<int>(s);
 }
 
+// Grid of the register-tiled kernels: target blocks of 256 * kTPL x source slices, with the slice count chosen so
+// that ALL workgroups are resident at once and the CUs carry the same number of them -- 4 workgroups (16 waves)
+// per CU: one round, no tail (the one-target-per-lane form ran 2 079 workgroups on 2 048 slots at 25 117 x
+// 25 117).  Slices are at least 64 sources long and at most kMaxSlices in number.
+inline void pick_tile_grid(int64_t nt, int64_t ns, int *slices, int64_t *slice_len) {
+    const int64_t tb = ceil_div(nt, kPairThreads * kTPL);
+    int64_t s = ((kTPL >= 4 ? 4 : 8) * static_cast<int64_t>(device_cu_count())) / tb;
+    const int64_t max_by_len = ceil_div(ns, 64);
+    if (s > max_by_len) s = max_by_len;
+    if (s > kMaxSlices) s = kMaxSlices;
+    if (s < 1) s = 1;
+    *slice_len = ceil_div(ns, s);
+    *slices = static_cast<int>(ceil_div(ns, *slice_len));
+}
+
 }  // namespace ssa
 
 using namespace ssa;
@@ -387,10 +470,9 @@ extern "C" int ssa_biot_savart(const double *src_xy, const void *src_areas, cons
     const int64_t len = src_end - src_begin;
     int slices = 1;
     if (len > 0) {
-        slices = pick_slices(nt, len);
-        const int64_t slice_len = ceil_div(ceil_div(len, slices), kPairThreads) * kPairThreads;
-        slices = static_cast<int>(ceil_div(len, slice_len));
-        const dim3 grid(static_cast<unsigned>(ceil_div(nt, kPairThreads)), slices);
+        int64_t slice_len = 0;
+        pick_tile_grid(nt, len, &slices, &slice_len);
+        const dim3 grid(static_cast<unsigned>(ceil_div(nt, kPairThreads * kTPL)), slices);
         if (dtype == SSA_F64) {
             hipLaunchKernelGGL((biot_savart_partial_kernel<double>), grid, dim3(kPairThreads), 0,
                                st, src_xy, static_cast<const double *>(src_areas), src_J,
@@ -481,10 +563,10 @@ extern "C" int ssa_self_field(const double *xy, const double *w, const double *q
         return SSA_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t st = as_stream(stream);
     double *partial = static_cast<double *>(workspace);
-    int slices = pick_slices(n, n);
-    const int64_t slice_len = ceil_div(ceil_div(n, slices), kPairThreads) * kPairThreads;
-    slices = static_cast<int>(ceil_div(n, slice_len));
-    const dim3 grid(static_cast<unsigned>(ceil_div(n, kPairThreads)), slices);
+    int slices = 1;
+    int64_t slice_len = 0;
+    pick_tile_grid(n, n, &slices, &slice_len);
+    const dim3 grid(static_cast<unsigned>(ceil_div(n, kPairThreads * kTPL)), slices);
     const dim3 cgrid(static_cast<unsigned>(ceil_div(n, 256)));
     if (dtype == SSA_F64) {
         hipLaunchKernelGGL((self_field_partial_kernel<double>), grid, dim3(kPairThreads), 0, st,
@@ -513,10 +595,10 @@ extern "C" int ssa_self_field_rows(const double *xy, const double *w, const doub
     if (!workspace || workspace_bytes < ssa_self_field_workspace_bytes(nr)) return SSA_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t st = as_stream(stream);
     double *partial = static_cast<double *>(workspace);
-    int slices = pick_slices(nr, n);
-    const int64_t slice_len = ceil_div(ceil_div(n, slices), kPairThreads) * kPairThreads;
-    slices = static_cast<int>(ceil_div(n, slice_len));
-    const dim3 grid(static_cast<unsigned>(ceil_div(nr, kPairThreads)), slices);
+    int slices = 1;
+    int64_t slice_len = 0;
+    pick_tile_grid(nr, n, &slices, &slice_len);
+    const dim3 grid(static_cast<unsigned>(ceil_div(nr, kPairThreads * kTPL)), slices);
     const dim3 cgrid(static_cast<unsigned>(ceil_div(nr, 256)));
     if (dtype == SSA_F64) {
         hipLaunchKernelGGL((self_field_rows_partial_kernel<double>), grid, dim3(kPairThreads), 0, st, xy, w,
