@@ -29,6 +29,7 @@
 #include <utility>
 
 #include "chol_diag.hpp"
+#include "chol_diag2.hpp"
 #include "common.hpp"
 
 namespace ssa {
@@ -146,7 +147,9 @@ inline AuxLayout aux_layout(int64_t n) {
     a.invT = a.nblk * SNB * SNB;
     a.tmp = 2 * a.nblk * SNB * SNB;
     a.scratch = a.tmp + a.nblk * (SNB * SNB / 4);
-    a.total = a.scratch + 4 * CPW * CPW;
+    // scratch of the diagonal-block kernels: 4 x 64 x 64 (first form) / one register image per lower 16 x 16 tile of
+    // the 256 x 256 block (second form, chol_diag2.hpp: 34 816 elements)
+    a.total = a.scratch + (4 * CPW * CPW > cholk2::kScratchElems ? 4 * CPW * CPW : cholk2::kScratchElems);
     return a;
 }
 
@@ -339,6 +342,17 @@ int chol_panel_diag(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     const int64_t n = J.n, lda = J.lda;
     T *scratch = J.aux + aux_layout(n).scratch;
     if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
+    if constexpr (sizeof(T) == 8) {   // float64: the tile-layout form (chol_diag2.hpp)
+        static DeviceFlags lds_flags2;
+        if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel),
+                                            sizeof(cholk2::Smem)}}) != SSA_OK)
+            return SSA_ERR_HIP;
+        hipLaunchKernelGGL(cholk2::chol_diag256_v2_kernel, dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem), s,
+                           J.A + k0 * (lda + 1), static_cast<int>(lda), chol_leaf(J, k0), static_cast<int>(SNB), scratch,
+                           J.info, static_cast<int>(k0 + 1));
+        SSA_RETURN_IF_LAUNCH_FAILED();
+        return SSA_OK;
+    }
     static DeviceFlags lds_flags;
     if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<T>),
                                        sizeof(cholk::Ge64Smem<T>)}}) != SSA_OK)
@@ -576,7 +590,11 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             }
             hipStream_t us = cur_us[i];                                    // where this matrix' trailing updates run
             hipStream_t c1 = iso_on[i] ? ln.iso : ln.side;                 // the critical chain
+#ifdef SSA_ISO_CHAIN2
             hipStream_t c2 = iso_on[i] ? ln.iso2 : ln.side2;               // the second chain, one step behind
+#else
+            hipStream_t c2 = ln.side2;                                     // the second chain keeps its priority stream
+#endif
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
             // panels whose update of the trailing matrix is still pending: columns [pend0, k0 + CNB)
             const int64_t pend0 = pending_from[i], kp = k0 + CNB - pend0;
