@@ -212,43 +212,8 @@ struct CholLane {
     hipStream_t side = nullptr, side2 = nullptr, finish = nullptr, upd = nullptr;
     hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr,
                ev_upd = nullptr, ev_diag = nullptr, ev_top = nullptr, ev_below = nullptr;
-    // chain-bound tail (see potrf_batch): the critical chain on a stream confined to a few reserved CUs, everything
-    // else of the matrix on streams confined to the other CUs
-    hipStream_t iso = nullptr, iso2 = nullptr, iso_upd = nullptr;
-    hipEvent_t ev_sw1 = nullptr, ev_sw2 = nullptr, ev_sw3 = nullptr;
 };
 constexpr int kMaxLanes = 16;
-
-// Reserved compute units of the chain-bound tail.  A dependent chain of vector instructions runs 3-6 x slower on a
-// SIMD that also issues another kernel's MFMAs (tools/probes/prim_probe.hip, cumask2_probe.hip: 17 -> 103 ns per
-// link of an FMA chain beside an MFMA burn, 17 ns on CUs the burn is masked away from), and the diagonal-block
-// kernel is little else.  HIP offers CU masks per stream (hipExtStreamCreateWithCUMask; no priorities on such
-// streams): bits 0 .. kIsoCUs - 1 select kIsoCUs / 8 CUs in every XCD of an MI355X (measured: 16 bits -> CUs
-// (se 0, cu 0) and (se 1, cu 1) of each of the 8 XCDs).
-#ifndef SSA_ISO_CUS
-#define SSA_ISO_CUS 16
-#endif
-#ifndef SSA_ISO_COLS
-#define SSA_ISO_COLS 0
-#endif
-constexpr int kIsoCUs = SSA_ISO_CUS;
-constexpr int64_t kIsoCols = SSA_ISO_COLS;   // trailing order from which a matrix' schedule is isolated (0: never)
-
-inline bool make_masked_streams(CholLane &ln) {
-    const int ncu = device_cu_count();
-    if (kIsoCols <= 0 || ncu < 8 * kIsoCUs || ncu > 1024) return false;
-    const int words = (ncu + 31) / 32;
-    uint32_t reserved[32] = {}, rest[32] = {};
-    for (int b = 0; b < ncu; ++b) (b < kIsoCUs ? reserved : rest)[b / 32] |= 1u << (b % 32);
-    if (hipExtStreamCreateWithCUMask(&ln.iso, words, reserved) != hipSuccess) { ln.iso = nullptr; return false; }
-    if (hipExtStreamCreateWithCUMask(&ln.iso2, words, rest) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&ln.iso_upd, words, rest) != hipSuccess ||
-        hipEventCreateWithFlags(&ln.ev_sw1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ln.ev_sw2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ln.ev_sw3, hipEventDisableTiming) != hipSuccess)
-        return false;
-    return true;
-}
 
 // The lanes of one device and the mutex that serialises schedules on that device (the lanes are the
 // schedule's streams and events; other devices of the process enqueue concurrently).  Created on first
@@ -283,11 +248,6 @@ inline int get_lanes(int count, LaneSet **out) {
             hipEventCreateWithFlags(&lanes[i].ev_syrk, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
-        (void)hipGetLastError();
-        if (!make_masked_streams(lanes[i])) {   // no CU masks on this device / runtime: the tail is not isolated
-            (void)hipGetLastError();
-            lanes[i].iso = nullptr;
-        }
     }
     *out = &g_lane_sets[dev];
     return SSA_OK;
@@ -304,11 +264,8 @@ inline int destroy_lanes() {
             if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.side2) != hipSuccess ||
                 hipStreamSynchronize(ln.finish) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess)
                 rc = SSA_ERR_HIP;
-            for (hipStream_t m : {ln.iso, ln.iso2, ln.iso_upd})
-                if (m != nullptr && (hipStreamSynchronize(m) != hipSuccess || hipStreamDestroy(m) != hipSuccess))
-                    rc = SSA_ERR_HIP;
-            hipEvent_t evs[12] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk, ln.ev_upd,
-                                  ln.ev_diag,  ln.ev_top,   ln.ev_below, ln.ev_sw1,   ln.ev_sw2,  ln.ev_sw3};
+            hipEvent_t evs[9] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk,
+                                 ln.ev_upd,   ln.ev_diag,  ln.ev_top,  ln.ev_below};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
             if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.side2) != hipSuccess ||
@@ -546,13 +503,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     constexpr int kDelayDepth = 2;            // (3 panels, K = 768: 114.5 vs 109.5 ms with the two-stream chains)
     constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 12288: 108.4 ... 109.3 ms, flat)
     bool syrk_recorded[kMaxLanes] = {};
-    // Isolation of the chain-bound tail: once the trailing matrix of a film is of order <= kIsoCols its chain no
-    // longer hides behind the updates, the factorization runs at the pace of  diagonal-block update -> diagonal-block
-    // kernel -> first block row  (0.6-0.75 ms per panel while that chain shares its CUs with the updates, the other
-    // chain and the finishing passes; 0.33 ms alone), and the chip is mostly idle.  From there on the critical chain
-    // of the film runs on a stream confined to kIsoCUs reserved CUs and everything else of the film (second chain,
-    // updates, finishing passes) on streams confined to the other CUs.  The switch is three event edges.
-    bool iso_on[kMaxLanes] = {};
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
@@ -579,22 +529,9 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 continue;
             }
             const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
-            if (!iso_on[i] && ln.iso != nullptr && lanes[0].iso != nullptr && kIsoCols > 0 && right <= kIsoCols) {
-                iso_on[i] = true;
-                hipStream_t new_us = split_updates ? ln.iso_upd : lanes[0].iso_upd;
-                if (hipEventRecord(ln.ev_sw1, ln.side) != hipSuccess || hipStreamWaitEvent(ln.iso, ln.ev_sw1, 0) != hipSuccess ||
-                    hipEventRecord(ln.ev_sw2, ln.side2) != hipSuccess || hipStreamWaitEvent(ln.iso2, ln.ev_sw2, 0) != hipSuccess ||
-                    hipEventRecord(ln.ev_sw3, cur_us[i]) != hipSuccess || hipStreamWaitEvent(new_us, ln.ev_sw3, 0) != hipSuccess)
-                    return SSA_ERR_HIP;
-                cur_us[i] = new_us;
-            }
             hipStream_t us = cur_us[i];                                    // where this matrix' trailing updates run
-            hipStream_t c1 = iso_on[i] ? ln.iso : ln.side;                 // the critical chain
-#ifdef SSA_ISO_CHAIN2
-            hipStream_t c2 = iso_on[i] ? ln.iso2 : ln.side2;               // the second chain, one step behind
-#else
-            hipStream_t c2 = ln.side2;                                     // the second chain keeps its priority stream
-#endif
+            hipStream_t c1 = ln.side;                                      // the critical chain
+            hipStream_t c2 = ln.side2;                                     // the second chain, one step behind
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
             // panels whose update of the trailing matrix is still pending: columns [pend0, k0 + CNB)
             const int64_t pend0 = pending_from[i], kp = k0 + CNB - pend0;
