@@ -460,7 +460,7 @@ def config4_scan(sc, torch, dist, rank, world, iterations):
     """64-value applied-field scan of the config-3 device (washer + shield disk, K = 81: 2 x 19 927 vertices)
     through parallel.solve_sweep_sharded.  Every rank factorizes its own replica inside the timed region."""
     from superscreen_amd import synthetic
-    from superscreen_amd.parallel import solve_sweep_sharded
+    from superscreen_amd.parallel import FilmPlacement, SweepGrid, solve_sweep_grid, solve_sweep_sharded
 
     K4 = int(os.environ.get("BENCH_CONFIG4_K", "81"))             # testing aid: smaller meshes
     device = synthetic.make_stack_device(K4, ("washer", "disk"), solve_dtype="float64")
@@ -502,6 +502,49 @@ def config4_scan(sc, torch, dist, rank, world, iterations):
     res["config4_note"] = ("config-3 device, 64 fields linspace(0.1, 6.4) mT, 10 iterations, final iterate returned as "
                            "Solutions; strong = 64 fields over the ranks, weak = 64 fields per rank; each rank's "
                            "factorization is inside the timed region; no data-path collective")
+    # (film owner) x (field shard) grid: a rank factors ONE film and sweeps 64 / shards columns of it; one all-reduce of
+    # the [n, nvec] result arrays per pass inside a shard's group (parallel.SweepGrid).  Cold (factorization inside
+    # the timed region) and with the pre-factorized model (the reference pattern: one factorize_model, many solves).
+    if world > 1:
+        grid = SweepGrid(len(device.films), rank=rank, world=world)
+        solve_sweep_grid(device, scan[:max(2, 64 // world)], grid, iterations=iterations, all_iterations=False)
+        for label in ("cold", "prefactorized"):
+            model = None
+            if label == "prefactorized":
+                model = solve_sweep_grid(device, scan[:2], grid, iterations=iterations, all_iterations=False)[3]
+            barrier()
+            t0 = time.perf_counter()
+            b, e, local, _ = solve_sweep_grid(device, scan, grid, model=model, iterations=iterations, all_iterations=False)
+            torch.cuda.synchronize()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            res[f"config4_grid_{label}_seconds"] = float(tmax.item())
+            res[f"config4_grid_{label}_solves_per_s"] = 64 / float(tmax.item())
+            del local, model
+        res["config4_grid_layout"] = f"{grid.film_ranks} film owners x {grid.shards} field shards"
+    else:
+        # what a rank of the grid does on an 8-GPU node, measured on this GPU: one film's factorization, and the
+        # scan of the pre-factorized model for 64 fields (one GPU) and for 16 fields (one shard of four)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            m1 = sc.factorize_model(device=device, current_units="uA", placement=FilmPlacement(rank=1, world=2))
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+            del m1
+        res["config4_one_film_factorize_ms"] = float(np.median(ts)) * 1e3
+        model = sc.factorize_model(device=device, current_units="uA")
+        for nf in (64, 16):
+            sc.solve_sweep(model, scan[:nf], iterations=iterations, all_iterations=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sc.solve_sweep(model, scan[:nf], iterations=iterations, all_iterations=False)
+            torch.cuda.synchronize()
+            res[f"config4_prefactorized_{nf}_fields_ms"] = (time.perf_counter() - t1) * 1e3
+        del model
     return res
 
 

@@ -271,6 +271,85 @@ class FilmPlacement:
                 off += cnt
 
 
+class SweepGrid:
+    """Two-dimensional placement of a scan (BASELINE config 4) on the ranks of a node: (film owner) x (field shard).
+
+    A scan on replicas (:func:`solve_sweep_sharded`) does not strong-scale: every rank factors EVERY film and then
+    streams every factor for its few columns.  Here the ``world`` ranks form ``shards`` groups of ``film_ranks``
+    ranks (``film_ranks`` = min(number of films, world)); inside a group the films are placed owner-computes
+    (:class:`FilmPlacement` on the group), so a rank factors and sweeps ONE film (of a two-film device), and the
+    group's ranks exchange the ``[n, nvec]`` result arrays with one sum all-reduce per pass; the groups split the
+    fields.  Per rank: 1 / film_ranks of the factorization flops and of the solve traffic, 1 / shards of the
+    columns.  Rank r -> (shard r // film_ranks, film slot r % film_ranks): the ranks of a group are neighbours.
+
+    Every rank of ``group`` must construct the grid (``torch.distributed.new_group`` is collective)."""
+
+    def __init__(self, n_films: int, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                 make_groups: bool = True):
+        if rank is None or world is None:
+            dist = _dist()
+            if not dist.is_initialized():
+                raise RuntimeError("torch.distributed is not initialised.")
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world = rank, world
+        self.film_ranks, self.shards = self.layout(n_films, world)
+        self.active = rank < self.film_ranks * self.shards     # (world not a multiple of film_ranks: the rest idles)
+        self.shard = rank // self.film_ranks if self.active else -1
+        self.film_slot = rank % self.film_ranks if self.active else -1
+        self.subgroup = None
+        if make_groups and self.film_ranks > 1:
+            dist = _dist()
+            for sh in range(self.shards):                       # collective: every rank creates every group
+                members = [self._global(group, sh * self.film_ranks + k) for k in range(self.film_ranks)]
+                g = dist.new_group(ranks=members)
+                if sh == self.shard:
+                    self.subgroup = g
+        self.placement = (FilmPlacement(rank=self.film_slot, world=self.film_ranks, group=self.subgroup)
+                          if self.active else None)
+
+    @staticmethod
+    def layout(n_films: int, world: int) -> Tuple[int, int]:
+        """``(film_ranks, shards)`` for ``world`` ranks and ``n_films`` films."""
+        if n_films < 1 or world < 1:
+            raise ValueError("SweepGrid needs at least one film and one rank.")
+        film_ranks = min(n_films, world)
+        return film_ranks, world // film_ranks
+
+    @staticmethod
+    def _global(group, group_rank: int) -> int:
+        dist = _dist()
+        if group is None or not hasattr(dist, "get_global_rank"):
+            return group_rank
+        return dist.get_global_rank(group, group_rank)
+
+    def field_range(self, n_fields: int) -> Tuple[int, int]:
+        """The fields of this rank's shard (every rank of a shard's group takes the same slice)."""
+        if not self.active:
+            return 0, 0
+        return shard_range(n_fields, self.shard, self.shards)
+
+
+def solve_sweep_grid(device, applied_fields: Sequence, grid: SweepGrid, *, current_units: str = "uA", model=None,
+                     factorize_fn: Optional[Callable] = None, solve_fn: Optional[Callable] = None, **sweep_kwargs):
+    """A scan on a :class:`SweepGrid`: this rank factors the films it owns (``factorize_model(placement=...)``;
+    or pass a ``model`` that was factorized with ``grid.placement`` before -- the reference pattern is ONE
+    ``factorize_model`` and many ``solve(model=...)``, ``device/device.py:619-627``: the factorization then stays
+    out of the scan) and solves its shard's fields with :func:`superscreen_amd.solve_sweep` under the group's
+    placement.  Returns ``(begin, end, local, model)``; every rank of a shard's group returns the same ``local``.
+    ``factorize_fn`` / ``solve_fn`` replace the library calls (the CPU tests inject stand-ins)."""
+    if not grid.active:
+        return 0, 0, [], model
+    if model is None:
+        if factorize_fn is None:
+            from .solver import factorize_model as factorize_fn
+        model = factorize_fn(device=device, current_units=current_units, placement=grid.placement)
+    if solve_fn is None:
+        from .sweep import solve_sweep as solve_fn
+    begin, end = grid.field_range(len(applied_fields))
+    local = solve_fn(model, list(applied_fields[begin:end]), placement=grid.placement, **sweep_kwargs) if end > begin else []
+    return begin, end, local, model
+
+
 def solve_sweep_sharded(model, applied_fields: Sequence, *, rank: Optional[int] = None, world: Optional[int] = None,
                         group=None, summarize: Optional[Callable] = None, solve_fn: Optional[Callable] = None,
                         **sweep_kwargs):

@@ -30,7 +30,7 @@ from .units import field_conversion_factor
 
 def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, field_units: str = "mT",
                 iterations: int = 0, return_solutions: bool = True, all_iterations: bool = True,
-                circulating_currents: Optional[Sequence[dict]] = None,
+                circulating_currents: Optional[Sequence[dict]] = None, placement: Optional[object] = None,
                 _solver: str = "superscreen_amd.solve_sweep") -> Optional[List[List[Solution]]]:
     """Self-consistent solutions for every applied field of a scan.
 
@@ -42,7 +42,12 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
     of a mutual-inductance matrix, ``device/device.py:619-627``); the model is not modified.
     ``all_iterations=False`` keeps only the final iterate (``solve(...)[-1]``): ``result[k]`` then
     has one Solution, and the self field -- an output, not an input of the next iteration
-    (``solver/solve_film.py:565-572``) -- is evaluated for the final pass only."""
+    (``solver/solve_film.py:565-572``) -- is evaluated for the final pass only.
+    ``placement``: a :class:`superscreen_amd.parallel.FilmPlacement` (owner-computes): this rank carries only the
+    films it factored through the passes, evaluates the coupling field of those target films, and the ranks of
+    the placement's group exchange the ``[n, nvec]`` result arrays with ONE sum all-reduce per pass; every rank
+    returns the same Solutions.  With :class:`superscreen_amd.parallel.SweepGrid` the ranks of a node form
+    (film owner) x (field shard) and a scan strong-scales in both directions."""
     import torch
 
     from . import _hip, kernels
@@ -76,6 +81,9 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
     conv = field_conversion_factor(field_units, current_units, length_units=device.length_units)
     dtype = device.solve_dtype
     info_of, fd_of = model.film_info, model.film_data
+    if placement is None:
+        placement = model.__dict__.get("_placement")
+    mine = films if placement is None else placement.mine(films)
 
     # applied fields on the sites: [n, nvec] per film (host evaluation like solve.py:422-436)
     applied_h, applied_d = {}, {}
@@ -137,7 +145,7 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
 
     def run_pass(other_d, want_self_field=True):
         results = {}
-        for name in films:
+        for name in mine:
             fd, info, system = fd_of[name], info_of[name], model.film_systems[name]
             g1_all, ha_all = hole_terms(name)
             g = g1_all.clone()
@@ -169,7 +177,34 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                 else:
                     sf = kernels.self_field_multi(fd.xy, fd.w, fd.qdiag, g)
             results[name] = (g, J, sf)
+        if placement is not None:   # owner-computes: one collective hands every rank every film's arrays
+            results = share_results(results, want_self_field)
         return results
+
+    def share_results(results, with_self_field):
+        keys = ("g", "J", "sf") if with_self_field else ("g", "J")
+        shapes, dtypes, tensors = {}, {}, {}
+        for name in films:
+            fd = fd_of[name]
+            shapes[name] = {"g": (fd.n, nvec), "J": (fd.n, nvec, 2), "sf": (fd.n, nvec)}
+            dtypes[name] = {"g": fd.tdtype, "J": torch.float64, "sf": fd.tdtype}
+            shapes[name] = {k: shapes[name][k] for k in keys}
+            dtypes[name] = {k: dtypes[name][k] for k in keys}
+            if name in results:
+                g, J, sf = results[name]
+                tensors[name] = {"g": g, "J": J}
+                if with_self_field:
+                    tensors[name]["sf"] = sf
+        placement.share(films, tensors, shapes, dtypes, fd_of[films[0]].device)
+        return {name: (tensors[name]["g"], tensors[name]["J"], tensors[name].get("sf")) for name in films}
+
+    def share_coupling(other_d):
+        """The coupling fields of the iterate that is returned: every rank needs them for its Solutions."""
+        shapes = {name: {"o": (fd_of[name].n, nvec)} for name in films}
+        dtypes = {name: {"o": fd_of[name].tdtype} for name in films}
+        tensors = {name: {"o": other_d[name]} for name in films if name in other_d}
+        placement.share(films, tensors, shapes, dtypes, fd_of[films[0]].device)
+        return {name: tensors[name]["o"] for name in films}
 
     def to_host(results, other_d):
         """Field-major host arrays ([nvec, n(, 2)]): every field's slice is then a contiguous view,
@@ -196,9 +231,9 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
     for it in range(n_pass):
         last = it == n_pass - 1
         other_d = {name: torch.zeros((fd_of[name].n, nvec), dtype=fd_of[name].tdtype, device=fd_of[name].device)
-                   for name in films}
+                   for name in mine}
         for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
-            if src == tgt:
+            if src == tgt or tgt not in other_d:   # (owner-computes: the coupling field of this rank's target films)
                 continue
             s, t = fd_of[src], fd_of[tgt]
             b, e = s.src_range  # vertices that can carry current (solver.FilmDeviceData): the rest adds exact zeros
@@ -212,7 +247,7 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
                                       rows=only_unknowns)
         results = run_pass(other_d, all_iterations or last)
         if return_solutions and (all_iterations or last):
-            trace.append(to_host(results, other_d))
+            trace.append(to_host(results, other_d if placement is None else share_coupling(other_d)))
     if not return_solutions:
         torch.cuda.synchronize()
         return None

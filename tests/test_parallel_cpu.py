@@ -210,3 +210,97 @@ def test_film_placement_share_is_one_collective_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in out), out
+
+
+def test_sweep_grid_layout():
+    from superscreen_amd.parallel import SweepGrid
+
+    assert SweepGrid.layout(2, 8) == (2, 4) and SweepGrid.layout(2, 1) == (1, 1) and SweepGrid.layout(4, 8) == (4, 2)
+    assert SweepGrid.layout(2, 5) == (2, 2)                     # one rank idles
+    for n_films, world, n_fields in ((2, 8, 64), (2, 4, 13), (3, 8, 64), (2, 5, 7), (1, 4, 10)):
+        cover = {}
+        for rank in range(world):
+            g = SweepGrid(n_films, rank=rank, world=world, make_groups=False)
+            if not g.active:
+                assert g.field_range(n_fields) == (0, 0) and g.placement is None
+                continue
+            assert g.rank == g.shard * g.film_ranks + g.film_slot and g.placement.world == g.film_ranks
+            b, e = g.field_range(n_fields)
+            cover.setdefault(g.film_slot, []).append((b, e))
+        for slot, pieces in cover.items():                      # every film slot sees every field exactly once
+            pieces.sort()
+            assert pieces[0][0] == 0 and pieces[-1][1] == n_fields
+            assert all(x[1] == y[0] for x, y in zip(pieces, pieces[1:]))
+
+
+def _grid_worker(rank, world, port, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+
+    from superscreen_amd.parallel import SweepGrid, solve_sweep_grid
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        films = ["washer0", "disk1"]
+        grid = SweepGrid(len(films))                 # world 4: two shards of two film owners
+        ok = (grid.film_ranks, grid.shards) == (2, 2) and grid.shard == rank // 2 and grid.film_slot == rank % 2
+        fields = [0.1 * (k + 1) for k in range(9)]   # 9 fields on 2 shards: 5 + 4
+        n = {"washer0": 6, "disk1": 4}
+        factored, exchanged = [], []
+
+        def fake_factorize(device, current_units, placement):
+            mine = placement.mine(films)
+            factored.append(mine)
+            return ("model", tuple(mine))
+
+        def fake_sweep(model, my_fields, placement, iterations=0):
+            # one "pass": every film's [n, nvec] array is produced by its owner only and completed by ONE all-reduce
+            # inside the shard's group (the collective solve_sweep issues through FilmPlacement.share)
+            nvec = len(my_fields)
+            mine = placement.mine(films)
+            tensors = {f: {"g": torch.tensor([[100.0 * films.index(f) + i + v for v in my_fields] for i in range(n[f])],
+                                             dtype=torch.float64)} for f in mine}
+            shapes = {f: {"g": (n[f], nvec)} for f in films}
+            dtypes = {f: {"g": torch.float64} for f in films}
+            calls = []
+            real = dist.all_reduce
+            dist.all_reduce = lambda *a, **kw: (calls.append(kw.get("group")), real(*a, **kw))[1]
+            placement.share(films, tensors, shapes, dtypes, torch.device("cpu"))
+            dist.all_reduce = real
+            exchanged.append(calls)
+            return [{f: tensors[f]["g"][:, k].clone() for f in films} for k in range(nvec)]
+
+        b, e, local, model = solve_sweep_grid("device", fields, grid, factorize_fn=fake_factorize, solve_fn=fake_sweep,
+                                              iterations=3)
+        ok = ok and (b, e) == ((0, 5) if grid.shard == 0 else (5, 9)) and len(local) == e - b
+        ok = ok and factored == [[films[grid.film_slot]]] and model == ("model", (films[grid.film_slot],))
+        ok = ok and len(exchanged) == 1 and len(exchanged[0]) == 1 and exchanged[0][0] is grid.subgroup
+        for k, per_film in enumerate(local):         # every rank holds every film of its shard's fields
+            for f in films:
+                want = torch.tensor([100.0 * films.index(f) + i + fields[b + k] for i in range(n[f])], dtype=torch.float64)
+                ok = ok and torch.equal(per_film[f], want)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sweep_grid_world4_gloo():
+    """BASELINE config 4 on a (film owner) x (field shard) grid, world size 4 on gloo: a rank factors ONE film, the
+    two shards split the fields, and the result arrays travel in one all-reduce per pass INSIDE a shard's group."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in out), out

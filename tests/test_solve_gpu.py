@@ -926,3 +926,25 @@ def test_lu_factor_batch_keeps_cooperative_panels_coresident():
         assert float(r.abs().max() / b.abs().max()) < 1e-7
     del mats, copies, factors
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_sweep_grid_two_ranks_on_one_gpu():
+    """parallel.SweepGrid (film owner x field shard, BASELINE config 4): two ranks share this GPU as the two film
+    owners of one shard; each factors ONE film and exchanges the [n, nvec] result arrays with one all-reduce per
+    pass (gloo here); the scan equals the single-process ``solve_sweep`` to 1e-12."""
+    import socket
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "workers", "sweep_grid_worker.py")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("sweep grid == single process") == 2

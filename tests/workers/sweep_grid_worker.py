@@ -1,0 +1,54 @@
+"""Worker of tests/test_solve_gpu.py::test_sweep_grid_two_ranks_on_one_gpu: launched twice by
+``torch.distributed.run``; both ranks share cuda:0 (gloo carries the collectives).  A 2 x 1 SweepGrid (two film
+owners, one field shard): each rank factors ONE film of the washer + disk device and carries it through the scan,
+one all-reduce per pass; the result must equal the single-process ``solve_sweep``."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import superscreen_amd as sc  # noqa: E402
+from superscreen_amd import synthetic  # noqa: E402
+from superscreen_amd.parallel import SweepGrid, solve_sweep_grid  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = synthetic.make_stack_device(14, ("washer", "disk"), solve_dtype="float64")
+    fields = [0.2 * (k + 1) * (-1) ** k for k in range(10)]
+    grid = SweepGrid(len(device.films))
+    assert (grid.film_ranks, grid.shards) == (2, 1) and grid.film_slot == rank and grid.field_range(10) == (0, 10)
+    worst = 0.0
+    for all_it in (True, False):
+        begin, end, local, model = solve_sweep_grid(device, fields, grid, iterations=3, all_iterations=all_it)
+        assert list(model.film_systems) == [list(device.films)[rank]]          # ONE film factored on this rank
+        ref_model = sc.factorize_model(device=device, current_units="uA")
+        ref = sc.solve_sweep(ref_model, fields, iterations=3, all_iterations=all_it)
+        assert (begin, end) == (0, 10) and len(local) == len(ref) == 10
+        for a_list, b_list in zip(local, ref):
+            assert len(a_list) == len(b_list) == (4 if all_it else 1)
+            for a, b in zip(a_list, b_list):
+                for name in device.films:
+                    fa, fb = a.film_solutions[name], b.film_solutions[name]
+                    pairs = [(fa.stream, fb.stream), (fa.current_density, fb.current_density), (fa.self_field, fb.self_field)]
+                    if fb.field_from_other_films is not None:
+                        pairs.append((fa.field_from_other_films, fb.field_from_other_films))
+                    for x, y in pairs:
+                        worst = max(worst, float(np.max(np.abs(x - y)) / max(np.max(np.abs(y)), 1e-300)))
+    assert worst < 1e-12, worst
+    # a pre-factorized model stays out of the scan (the reference pattern: one factorize_model, many solves)
+    b2, e2, again, _ = solve_sweep_grid(device, fields[:4], grid, model=model, iterations=2, all_iterations=False)
+    assert (b2, e2) == (0, 4) and len(again) == 4
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: sweep grid == single process (max rel diff {worst:.1e})")
+
+
+if __name__ == "__main__":
+    main()
