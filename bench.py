@@ -67,32 +67,34 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILES = ("r02b_syrk_pmc.json", "r02_syrk_pmc.json", "r01_v7_syrk_pmc.json")
-PMC_MFMA_FILES = ("r02b_syrk_mfma_pmc.json", "r02_syrk_mfma_pmc.json", "r01_v7_syrk_mfma_pmc.json")
+PMC_TRAFFIC_FILES = ("r03_syrk_pmc.json", "r02b_syrk_pmc.json", "r02_syrk_pmc.json")
+PMC_MFMA_FILES = ("r03_syrk_mfma_pmc.json", "r02b_syrk_mfma_pmc.json", "r02_syrk_mfma_pmc.json")
 
 
 def chol_schedule(unknowns, elem=8):
     """The trailing-update launches of the Cholesky schedule (chol.hip potrf_batch) for films with the given
-    numbers of unknowns: per launch the lower 128 x 128 tiles of the trailing block behind the next
-    panel are read and written once and the pending panels below them (256 columns, or 512 when the
-    previous step's update was kept pending: large trailing matrices, every other step) are read once.
+    numbers of unknowns: per launch the lower 128 x 128 tiles of the trailing block are read and written once and
+    the pending panels below them (256 columns, or 512 when the previous step's update was kept pending: large
+    trailing matrices, every other step) are read once.  The block starts behind the next panel, or -- skip mode,
+    trailing order <= 8192 -- behind the panel after it.
     Returns (average algorithmic bytes per launch, launches per factorization)."""
     total, launches = 0.0, 0
     for n in unknowns:
         npad = -(-n // 256) * 256
-        pend0 = 0
+        upd0 = 0
         for k0 in range(0, npad - 256, 256):
-            right = npad - k0 - 256
-            nw = min(right, 256)
-            kp = k0 + 256 - pend0
+            c = k0 + 256
+            right = npad - c
+            kp = c - upd0
             delay = kp < 512 and right > 8192 and ((k0 + npad) // 256) % 2 != 1
-            if right > nw and not delay:
-                m = right - nw
+            if right > 256 and not delay:
+                lead = 512 if (right <= 8192 and right > 512) else 256
+                m = npad - (c + lead)
                 nt = m // 128
                 total += 2.0 * (nt * (nt + 1) // 2) * 128 * 128 * elem + m * kp * elem
                 launches += 1
             if not delay:
-                pend0 = k0 + 256
+                upd0 = c
     return total / max(1, launches), launches
 
 

@@ -212,6 +212,7 @@ struct CholLane {
     hipStream_t side = nullptr, side2 = nullptr, finish = nullptr, upd = nullptr;
     hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr,
                ev_upd = nullptr, ev_diag = nullptr, ev_top = nullptr, ev_below = nullptr;
+    hipEvent_t ev_syrk2 = nullptr;   // the trailing updates record ev_syrk and ev_syrk2 in turn (the chains may wait for the one before the last)
 };
 constexpr int kMaxLanes = 16;
 
@@ -246,6 +247,7 @@ inline int get_lanes(int count, LaneSet **out) {
             hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_syrk, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_syrk2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
@@ -264,8 +266,8 @@ inline int destroy_lanes() {
             if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.side2) != hipSuccess ||
                 hipStreamSynchronize(ln.finish) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess)
                 rc = SSA_ERR_HIP;
-            hipEvent_t evs[9] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk,
-                                 ln.ev_upd,   ln.ev_diag,  ln.ev_top,  ln.ev_below};
+            hipEvent_t evs[10] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk,
+                                  ln.ev_upd,   ln.ev_diag,  ln.ev_top,  ln.ev_below,  ln.ev_syrk2};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
             if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.side2) != hipSuccess ||
@@ -501,8 +503,21 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
     // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' strips
     constexpr int kDelayDepth = 2;            // (3 panels, K = 768: 114.5 vs 109.5 ms with the two-stream chains)
-    constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 12288: 108.4 ... 109.3 ms, flat)
-    bool syrk_recorded[kMaxLanes] = {};
+    constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 12288: flat within 1 %, round 2 and again with the skip mode below)
+    // Skip mode (chain-bound tail).  The next panel's block column b_c is made current by the chains, the rest of the
+    // trailing matrix by the update stream; while update k - 1 also wrote b_c, the chains of step k had to wait for
+    // it: in the tail, where nothing hides the chains, every round then was  ... -> panel -> update (80-300 us) ->
+    // diagonal-block update -> diagonal-block kernel.  Below kSkipMaxCols an update leaves out the block column
+    // after the next as well (it starts at column c + 512) and the chains apply the last TWO panels (K = 512) to
+    // their block column: the update the chains wait for is then the one before the last, a full round old.  Each
+    // update is remembered with the first row / column it touched, the panels it had applied and its event; the
+    // chains of b_c start from the last update that covered b_c.
+    constexpr int64_t kSkipMaxCols = 8192;   // (0 / 4096 / 8192 / 12288: 102.1 / 102.6 / 101.6 / 101.2 ms on one box)
+    struct UpdateRecord {
+        int64_t rstart = -1, upto = 0;   // rows / columns >= rstart were updated with the panels [.., upto)
+        hipEvent_t ev = nullptr;
+    };
+    UpdateRecord last_upd[kMaxLanes], prev_upd[kMaxLanes];
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
@@ -533,10 +548,15 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             hipStream_t c1 = ln.side;                                      // the critical chain
             hipStream_t c2 = ln.side2;                                     // the second chain, one step behind
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
-            // panels whose update of the trailing matrix is still pending: columns [pend0, k0 + CNB)
-            const int64_t pend0 = pending_from[i], kp = k0 + CNB - pend0;
-            const T *P = J.A + (k0 + CNB) * J.lda + pend0;    // those panels below the diagonal block of panel k
-            T *C = J.A + (k0 + CNB) * J.lda + (k0 + CNB);
+            const int64_t c = k0 + CNB;
+            // panels the chains still have to apply to the block column b_c: everything after the last trailing
+            // update that covered b_c; the update stream itself continues where its last update stopped
+            const UpdateRecord *cover = (last_upd[i].rstart >= 0 && last_upd[i].rstart <= c) ? &last_upd[i]
+                                        : ((prev_upd[i].rstart >= 0 && prev_upd[i].rstart <= c) ? &prev_upd[i] : nullptr);
+            const int64_t pend0 = cover ? cover->upto : 0, kp = c - pend0;
+            const int64_t upd0 = pending_from[i], kpu = c - upd0;   // panels pending for the update stream
+            const T *P = J.A + c * J.lda + pend0;             // the chains' panels below the diagonal block of panel k
+            T *C = J.A + c * J.lda + c;
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
             // The chain of a matrix is two streams (diagonal look-ahead).  What the NEXT diagonal block needs of
             // panel k is only its first block row, so per panel the critical recurrence is
@@ -546,15 +566,14 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             // the last trailing update of THIS matrix (which wrote the strip's columns).  (Strip, diagonal kernel and
             // panel rows were one serial chain before: 0.6 ms per panel in the chain-bound tail, now 0.35-0.55 ms;
             // config H 114 -> 109.6 ms.)
-            const int64_t c = k0 + CNB;
             if (right > nw) {   // strip, rows below the diagonal block: behind panel k (all rows) on this stream
-                if (syrk_recorded[i] && hipStreamWaitEvent(c2, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
+                if (cover && hipStreamWaitEvent(c2, cover->ev, 0) != hipSuccess) return SSA_ERR_HIP;
                 rc = gemm_op_t(0, 1, 0, right - nw, nw, kp, -1.0, P + nw * J.lda, J.lda, P, J.lda, 1.0, C + nw * J.lda,
                                J.lda, c2);
                 if (rc != SSA_OK) return rc;
                 if (hipEventRecord(ln.ev_below, c2) != hipSuccess) return SSA_ERR_HIP;
             }
-            if (syrk_recorded[i] && hipStreamWaitEvent(c1, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
+            if (cover && hipStreamWaitEvent(c1, cover->ev, 0) != hipSuccess) return SSA_ERR_HIP;
             rc = gemm_op_t(0, 1, 0, nw, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, c1);
             if (rc != SSA_OK) return rc;
             rc = chol_panel_diag(J, c, c1);
@@ -575,15 +594,21 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
             // (the phase comes from the matrix' own size, not from its place in the batch: the result
             // of a matrix does not depend on what else is factored with it)
-            const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
+            const bool delay = kpu < kDelayDepth * CNB && right > kDelayMinCols &&
                                ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
-            if (right > nw && !delay) {  // rest of the trailing update: lower tiles of the (right - nw) block
-                const T *P2 = P + nw * J.lda;
-                rc = gemm_op_t(0, 1, 1, right - nw, right - nw, kp, -1.0, P2, J.lda, P2, J.lda, 1.0,
-                               C + nw * J.lda + nw, J.lda, us);
+            if (right > nw && !delay) {  // rest of the trailing update: lower tiles behind the next panel's block column
+                // (skip mode: behind the block column after it as well)
+                const int64_t lead = (kSkipMaxCols > 0 && right <= kSkipMaxCols && right > 2 * nw) ? 2 * nw : nw;
+                const int64_t rstart = c + lead, M = J.n - rstart;
+                const T *P2 = J.A + rstart * J.lda + upd0;
+                rc = gemm_op_t(0, 1, 1, M, M, kpu, -1.0, P2, J.lda, P2, J.lda, 1.0, J.A + rstart * (J.lda + 1), J.lda, us);
                 if (rc != SSA_OK) return rc;
-                if (hipEventRecord(ln.ev_syrk, us) != hipSuccess) return SSA_ERR_HIP;
-                syrk_recorded[i] = true;
+                hipEvent_t ev = (last_upd[i].ev == ln.ev_syrk) ? ln.ev_syrk2 : ln.ev_syrk;
+                if (hipEventRecord(ev, us) != hipSuccess) return SSA_ERR_HIP;
+                prev_upd[i] = last_upd[i];
+                last_upd[i].rstart = rstart;
+                last_upd[i].upto = c;
+                last_upd[i].ev = ev;
             }
             if (!delay) pending_from[i] = k0 + CNB;
             // one early finishing step per outer step once its inputs (panels <= k, which this

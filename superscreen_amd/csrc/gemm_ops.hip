@@ -353,6 +353,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_small_kernel(int64_t K8,
                                                                     int64_t ldb8, T beta, T *__restrict__ C, int64_t ldc,
                                                                     int64_t ntm) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // These launches are the products of the factorization's panel chains: few workgroups, each on a CU it shares
+    // with the trailing update's waves.  Instruction arbitration on a SIMD goes by priority, then by age -- and the
+    // update's waves are always the older ones.
+    __builtin_amdgcn_s_setprio(3);
     const int64_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
     const int64_t tm = wg % ntm, tn = wg / ntm;   // consecutive ids share the B panel
     tile_small_nt<T>(K8, alpha, A, lda8, B, ldb8, beta, C, ldc, tm * SBM, tn * BN, smem_raw);
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     int64_t ntn, int aligned) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int64_t tm, tn;
+    if constexpr (!LOWER) __builtin_amdgcn_s_setprio(2);   // strips and panel products of the chains (see gemm_nt_small_kernel)
     if constexpr (LOWER) {
         // Lower-triangular tile enumeration in bands of 8 tile rows, column by column inside a
         // band: 64 consecutive ids (= what one XCD runs at a time) touch 8 row blocks + 8 column

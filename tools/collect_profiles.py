@@ -150,6 +150,43 @@ def main():
                 "TFLOP/s assumes 2.4 GHz; under FP64 MFMA load the chip holds a lower clock (DVFS)",
     }, open(os.path.join(prof, f"{tag}_syrk_mfma_pmc.json"), "w"), indent=1)
 
+    # the all-pairs kernels (inter-film coupling, self field on the rows that are not unknowns): vector-ALU issue and
+    # LDS counters on the solves of tools/hbm_kernels.py
+    dp, _ = run_pass("pairs", ["--pmc", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+                               "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace"],
+                     out_dir, [], script="tools/hbm_kernels.py")
+    pairs = {}
+    trace = {r["Dispatch_Id"]: (r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+             for r in rows(find(dp, "kernel_trace.csv"))}
+    for needle, label, npairs in (("biot_savart_partial_kernel<double", "biot_savart_partial_kernel<double> (inter-film coupling)", None),
+                                  ("self_field_rows_partial_kernel<double", "self_field_rows_partial_kernel<double>", None)):
+        per = {}
+        for r in rows(find(dp, "counter_collection.csv")):
+            if needle in r["Kernel_Name"]:
+                per.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
+        sel = [(c, trace[i][1]) for i, c in per.items() if i in trace]
+        if not sel:
+            continue
+        tot = {k: sum(c.get(k, 0.0) for c, _ in sel) for k in sel[0][0]}
+        secs = sum(t for _, t in sel)
+        gui = tot.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
+        pairs[label] = {
+            "launches": len(sel), "avg_launch_us": secs / len(sel) * 1e6,
+            "effective_clock_GHz": gui / secs / 1e9 if secs else None,
+            "valu_instructions_per_launch": tot.get("SQ_INSTS_VALU", 0.0) / len(sel),
+            "valu_active_quad_cycles_per_launch": tot.get("SQ_ACTIVE_INST_VALU", 0.0) / len(sel),
+            "wave_quad_cycles_per_launch": tot.get("SQ_WAVE_CYCLES", 0.0) / len(sel),
+            "valu_active_fraction_of_wave_cycles": (tot.get("SQ_ACTIVE_INST_VALU", 0.0) / tot["SQ_WAVE_CYCLES"]
+                                                    if tot.get("SQ_WAVE_CYCLES") else None),
+            "lds_instructions_per_launch": tot.get("SQ_INSTS_LDS", 0.0) / len(sel),
+            "lds_bank_conflict_cycles_per_launch": tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / len(sel),
+            "lds_active_cycles_per_launch": tot.get("SQ_LDS_IDX_ACTIVE", 0.0) / len(sel),
+        }
+    pairs["note"] = ("rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
+                     "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass of tools/hbm_kernels.py (config H's films, five "
+                     "11-pass solves: 25 117 x ~22 000 pairs per coupling launch); SQ_* activity counters are quad-cycles")
+    json.dump(pairs, open(os.path.join(prof, f"{tag}_biot_savart_pmc.json"), "w"), indent=1)
+
     p = subprocess.run(["python3", os.path.join(ROOT, "bench.py")], cwd=ROOT, capture_output=True, text=True)
     full = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if full:
