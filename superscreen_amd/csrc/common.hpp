@@ -86,10 +86,29 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 
 constexpr double kOneOver4Pi = 0.07957747154594767;  // 1 / (4 pi)
 
+// r2^(-3/2) in full double precision: hardware v_rsq_f64 seed y0 (relative error e0 <= 2^-26) and the series
+// (1 - e)^(-3/2) = 1 + e (3/2 + 15/8 e) + O(e^3), e = 1 - r2 y0^2: 6 FP64 operations behind the seed (a corrected
+// 1/sqrt followed by its cube takes 7), with the cube of the SEED off the dependent chain.  Measured issue costs
+// (tools/probes/valu_probe.hip, 4 waves per SIMD): v_fma/mul/add_f64 2.3 ns per wave-instruction, v_rsq_f64 7.3 ns;
+// an f32 seed (v_cvt_f32_f64 2.05 + v_rsq_f32 3.6 + v_cvt_f64_f32 2.06 ns) costs the same 7.7 ns and needs the same
+// series, so it buys nothing.
+__device__ __forceinline__ double inv_r3(double r2) {
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    const double y2 = y0 * y0;
+    const double e = __builtin_fma(-r2, y2, 1.0);
+    const double y3 = y2 * y0;
+    const double p = __builtin_fma(1.875, e, 1.5);
+    return __builtin_fma(y3 * e, p, y3);
+}
+
 // q = (1/4pi) * r2^(-3/2)
 __device__ __forceinline__ double inv_r3_over_4pi(double r2) {
-    double y = rsqrt_f64(r2);
-    return (kOneOver4Pi * y) * (y * y);
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    const double y2 = y0 * y0;
+    const double e = __builtin_fma(-r2, y2, 1.0);
+    const double k3 = (kOneOver4Pi * y2) * y0;
+    const double p = __builtin_fma(1.875, e, 1.5);
+    return __builtin_fma(k3 * e, p, k3);
 }
 
 template <typename T>

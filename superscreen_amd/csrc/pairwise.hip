@@ -18,18 +18,6 @@ struct alignas(16) Source {
     double x, y, a, b;
 };
 
-// r2^(-3/2) in full double precision: hardware v_rsq_f64 seed (relative error e0 <= 2^-26) and the series
-// (1 - e)^(-3/2) = 1 + e (3/2 + 15/8 e) + O(e^3), e = 1 - r2 y0^2: 6 FP64 operations behind the seed (a corrected
-// 1/sqrt followed by its cube takes 7), with the cube of the SEED off the dependent chain.
-__device__ __forceinline__ double inv_r3(double r2) {
-    const double y0 = __builtin_amdgcn_rsq(r2);
-    const double y2 = y0 * y0;
-    const double e = __builtin_fma(-r2, y2, 1.0);
-    const double y3 = y2 * y0;
-    const double p = __builtin_fma(1.875, e, 1.5);
-    return __builtin_fma(y3 * e, p, y3);
-}
-
 // Register tile: every lane owns kTPL targets (256 apart, so that loads and stores stay coalesced); one LDS
 // broadcast of a staged source (32 bytes) feeds kTPL pair evaluations instead of one, and the kTPL independent
 // dependency chains per lane keep the FP64 pipe issuing while a v_rsq_f64 is in flight.  A workgroup covers
@@ -135,8 +123,7 @@ __global__ __launch_bounds__(kPairThreads) void sheet_field_partial_kernel(
             const Source q = s_src[k];
             const double dx = xi - q.x, dy = yi - q.y;
             const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
-            const double y = rsqrt_f64(r2);
-            const double y3 = y * (y * y);
+            const double y3 = inv_r3(r2);
             az = __builtin_fma(__builtin_fma(q.a, dy, -(q.b * dx)), y3, az);
             if (NC == 3) {
                 sa = __builtin_fma(q.a, y3, sa);

@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void pair_mfma_kernel(const double *__restrict
             for (int mb = 0; mb < 2; ++mb) {
                 const double dx = xi[mb] - sxy.x, dy = yi[mb] - sxy.y;
                 const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
-                const double y = rsqrt_f64(r2);
-                const double y3 = y * (y * y);
+                const double y3 = inv_r3(r2);
                 if constexpr (SELF) {
                     a0[mb] = (s0 + k == ti[mb]) ? 0.0 : y3;
                     a1[mb] = 0.0;
@@ -252,8 +251,7 @@ __global__ __launch_bounds__(256) void pair_mfma4_kernel(const double *__restric
             for (int mb = 0; mb < 2; ++mb) {
                 const double dx = xi[mb] - sxy.x, dy = yi[mb] - sxy.y;
                 const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz2));
-                const double y = rsqrt_f64(r2);
-                const double y3 = y * (y * y);
+                const double y3 = inv_r3(r2);
                 if constexpr (SELF) {
                     a0[mb] = (s0 + k == ti[mb]) ? 0.0 : y3;
                     a1[mb] = 0.0;
