@@ -22,10 +22,7 @@ struct alignas(16) Source {
 // broadcast of a staged source (32 bytes) feeds kTPL pair evaluations instead of one, and the kTPL independent
 // dependency chains per lane keep the FP64 pipe issuing while a v_rsq_f64 is in flight.  A workgroup covers
 // 256 * kTPL targets x one source slice; padding entries of a stage are inert sources (far away, zero charge).
-#ifndef SSA_PAIR_TPL
-#define SSA_PAIR_TPL 2
-#endif
-constexpr int kTPL = SSA_PAIR_TPL;   // measured at 25 117 x 25 117 (same box): self field 1.52 / 1.75 / 1.71 Tpair/s for 4 / 2 / 1
+constexpr int kTPL = 2;   // measured at 25 117 x 25 117 (same box): self field 1.52 / 1.75 / 1.71 Tpair/s for 4 / 2 / 1
 constexpr double kFarAway = 1.0e15;
 
 template <typename T>
