@@ -301,12 +301,12 @@ int chol_panel_diag(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     const int64_t n = J.n, lda = J.lda;
     T *scratch = J.aux + aux_layout(n).scratch;
     if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
-    if constexpr (sizeof(T) == 8) {   // float64: the tile-layout form (chol_diag2.hpp)
+    {   // the tile-layout form (chol_diag2.hpp), both precisions
         static DeviceFlags lds_flags2;
-        if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel),
-                                            sizeof(cholk2::Smem)}}) != SSA_OK)
+        if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel<T>),
+                                            sizeof(cholk2::Smem<T>)}}) != SSA_OK)
             return SSA_ERR_HIP;
-        hipLaunchKernelGGL(cholk2::chol_diag256_v2_kernel, dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem), s,
+        hipLaunchKernelGGL((cholk2::chol_diag256_v2_kernel<T>), dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem<T>), s,
                            J.A + k0 * (lda + 1), static_cast<int>(lda), chol_leaf(J, k0), static_cast<int>(SNB), scratch,
                            J.info, static_cast<int>(k0 + 1));
         SSA_RETURN_IF_LAUNCH_FAILED();

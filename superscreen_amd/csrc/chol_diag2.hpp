@@ -1,4 +1,4 @@
-// Diagonal-block kernel of the blocked Cholesky, second form (float64): one workgroup of 4 waves factors the
+// Diagonal-block kernel of the blocked Cholesky, second form: one workgroup of 4 waves factors the
 // 256 x 256 diagonal block D of an outer panel, D = L L^T, and inverts the factor, W = L^-1 -- the step every
 // panel of a factorization has to wait for (chol.hip: diagonal-block update -> this kernel -> first block row of
 // the panel), and for the last third of a factorization the step that sets its pace.
@@ -8,7 +8,9 @@
 // with operands fetched from L2 by four waves.  Here everything is 16 x 16 tiles in the register layout of
 // v_mfma_f64_16x16x4_f64 itself:
 //
-//   tile layout "S":  lane (i = lane & 15, g = lane >> 4), register r  <->  element [i][g + 4 r]
+//   tile layout "S":  lane (i = lane & 15, g = lane >> 4), register r  <->  element [i][col(g, r)],
+//                      col(g, r) = g + 4 r for float64, 4 g + r for float32 (the two instructions number the rows of
+//                      their accumulators differently: mfma_traits.hpp)
 //
 //   * Z = X Y^T for tiles in S layout is four MFMAs on the registers as they stand, acc = mfma(Y.r, X.r, acc):
 //     the contraction index of instruction r in lane group g is g + 4 r for BOTH operands (any bijection will do
@@ -45,91 +47,129 @@ constexpr int kRows = 4;   // tile rows per wave
 constexpr int NT = 16;                          // 16 x 16 tiles of 16 x 16
 constexpr int kScratchElems = (NT * (NT + 1) / 2) * 256;  // the lower tiles of the block as register images
 
-typedef f64x4 Tile;   // the four registers of a lane
+template <typename T>
+using Tile = typename Mfma<T>::acc_t;   // the four registers of a lane
 
+// column of register r in lane group g: the row numbering of the instruction's accumulator
+template <typename T>
+__device__ __forceinline__ constexpr int col_of(int g, int r) { return sizeof(T) == 8 ? g + 4 * r : 4 * g + r; }
+
+template <typename T>
 struct Smem {
-    double w[256];             // W_jj of the current step (register image)
-    double lp[NT][256];        // column j of L, one register image per tile row
-    double wdiag[NT][256];     // every W_jj (the W phase needs them again)
+    T w[256];             // W_jj of the current step (register image)
+    T lp[NT][256];        // column j of L, one register image per tile row
+    T wdiag[NT][256];     // every W_jj (the W phase needs them again)
 };
 
 // ---- tile primitives --------------------------------------------------------------------------------------
-__device__ __forceinline__ void tile_zero(Tile &t) {
+template <typename T>
+__device__ __forceinline__ void tile_zero(Tile<T> &t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = 0.0;
+    for (int r = 0; r < 4; ++r) t[r] = T(0);
 }
 // acc += X Y^T  (all three in S layout; acc passed and returned as the MFMA accumulator)
-__device__ __forceinline__ f64x4 mma_xyT(f64x4 acc, const Tile &X, const Tile &Y) {
+template <typename T>
+__device__ __forceinline__ Tile<T> mma_xyT(Tile<T> acc, const Tile<T> &X, const Tile<T> &Y) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[r], X[r], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) acc = Mfma<T>::run(Y[r], X[r], acc);
     return acc;
 }
-__device__ __forceinline__ f64x4 to_acc(const Tile &t) { return t; }
-__device__ __forceinline__ Tile from_acc(const f64x4 &a) { return a; }
-__device__ __forceinline__ Tile negated(const Tile &t) { return -t; }
+template <typename T>
+__device__ __forceinline__ Tile<T> zero_tile() {
+    return Tile<T>{T(0), T(0), T(0), T(0)};
+}
 
-__device__ __forceinline__ void image_store(double *img, const Tile &t, int lane) {
+template <typename T>
+__device__ __forceinline__ void image_store(T *img, const Tile<T> &t, int lane) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) img[r * 64 + lane] = t[r];
 }
-__device__ __forceinline__ Tile image_load(const double *img, int lane) {
-    Tile t;
+template <typename T>
+__device__ __forceinline__ Tile<T> image_load(const T *img, int lane) {
+    Tile<T> t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = img[r * 64 + lane];
     return t;
 }
-// S layout of the TRANSPOSE of the tile whose register image is img: element [g + 4 r][i] of the tile
-__device__ __forceinline__ Tile image_load_transposed(const double *img, int lane) {
+// S layout of the TRANSPOSE of the tile whose register image is img: element [col(g, r)][i] of the tile, which the
+// image holds in lane (col(g, r), g') register r' with col(g', r') = i
+template <typename T>
+__device__ __forceinline__ Tile<T> image_load_transposed(const T *img, int lane) {
     const int i = lane & 15, g = lane >> 4;
-    Tile t;
+    const int gp = sizeof(T) == 8 ? (i & 3) : (i >> 2), rp = sizeof(T) == 8 ? (i >> 2) : (i & 3);
+    Tile<T> t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = img[(i >> 2) * 64 + (g + 4 * r) + 16 * (i & 3)];
+    for (int r = 0; r < 4; ++r) t[r] = img[rp * 64 + col_of<T>(g, r) + 16 * gp];
     return t;
 }
 // tile (bi, bj) of a row-major matrix, S layout
-__device__ __forceinline__ Tile global_load(const double *A, int ld, int bi, int bj, int lane) {
+template <typename T>
+__device__ __forceinline__ Tile<T> global_load(const T *A, int ld, int bi, int bj, int lane) {
     const int i = lane & 15, g = lane >> 4;
-    const int off = (16 * bi + i) * ld + 16 * bj + g;   // 32-bit element offset from the (uniform) base
-    Tile t;
+    const int off = (16 * bi + i) * ld + 16 * bj;   // 32-bit element offset from the (uniform) base
+    Tile<T> t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = A[off + 4 * r];
+    for (int r = 0; r < 4; ++r) t[r] = A[off + col_of<T>(g, r)];
     return t;
 }
 // a diagonal tile, read from its lower triangle only (element [i][k] with k > i comes from [k][i])
-__device__ __forceinline__ Tile global_load_sym(const double *A, int ld, int b, int lane) {
+template <typename T>
+__device__ __forceinline__ Tile<T> global_load_sym(const T *A, int ld, int b, int lane) {
     const int i = lane & 15, g = lane >> 4;
     const int base = (16 * b) * ld + 16 * b;
-    Tile t;
+    Tile<T> t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int k = g + 4 * r;
+        const int k = col_of<T>(g, r);
         t[r] = A[base + ((k > i) ? k * ld + i : i * ld + k)];
     }
     return t;
 }
-__device__ __forceinline__ void global_store(double *A, int ld, int bi, int bj, const Tile &t, int lane) {
+template <typename T>
+__device__ __forceinline__ void global_store(T *A, int ld, int bi, int bj, const Tile<T> &t, int lane) {
     const int i = lane & 15, g = lane >> 4;
-    const int off = (16 * bi + i) * ld + 16 * bj + g;
+    const int off = (16 * bi + i) * ld + 16 * bj;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) A[off + 4 * r] = t[r];
+    for (int r = 0; r < 4; ++r) A[off + col_of<T>(g, r)] = t[r];
 }
-// the tile whose TRANSPOSE is held in S layout: element [g + 4 r][i] = t[r]  (128-byte runs per (g, r))
-__device__ __forceinline__ void global_store_transposed(double *A, int ld, int bi, int bj, const Tile &t, int lane) {
+// the tile whose TRANSPOSE is held in S layout: element [col(g, r)][i] = t[r]
+template <typename T>
+__device__ __forceinline__ void global_store_transposed(T *A, int ld, int bi, int bj, const Tile<T> &t, int lane) {
     const int i = lane & 15, g = lane >> 4;
-    const int off = (16 * bi + g) * ld + 16 * bj + i;
+    const int off = (16 * bi) * ld + 16 * bj + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) A[off + 4 * r * ld] = t[r];
+    for (int r = 0; r < 4; ++r) A[off + col_of<T>(g, r) * ld] = t[r];
 }
 
-__device__ __forceinline__ double bperm64(double v, int byte_addr) {
+__device__ __forceinline__ double bperm(double v, int byte_addr) {
     const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double readlane64(double v, int src_lane) {
+__device__ __forceinline__ float bperm(float v, int byte_addr) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+__device__ __forceinline__ double readlane(double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+// 1 / x and 1 / sqrt(x) to working precision: hardware seed + one Newton step (float64: the cubic step of common.hpp)
+__device__ __forceinline__ double recip(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ float recip(float x) {
+    const float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+}
+__device__ __forceinline__ double rsqrt_w(double x) { return rsqrt_f64(x); }
+__device__ __forceinline__ float rsqrt_w(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    return y * (1.5f - 0.5f * x * y * y);
 }
 
 // Tile rows of a wave: w, 7 - w, 8 + w, 15 - w (long rows paired with short ones); the inverse map for row j.
@@ -179,53 +219,63 @@ __device__ __forceinline__ void lds_barrier() {
 // above the diagonal), w = L^-1.  Gaussian elimination without pivoting on [D | I]: the multipliers are the
 // Cholesky factor up to the column scaling 1 / sqrt(pivot), the eliminated identity is the inverse of the unit
 // lower factor, W = diag(1 / sqrt(pivot)) times it.  bad: some pivot was not positive.
-__device__ __forceinline__ void chol16inv(Tile &d, Tile &w, bool &bad, int lane) {
+template <typename T>
+__device__ __forceinline__ void chol16inv(Tile<T> &d, Tile<T> &w, bool &bad, int lane) {
     const int i = lane & 15, g = lane >> 4;
-    double m[4];
+    T m[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) m[r] = (g + 4 * r == i) ? 1.0 : 0.0;
-    double myinv = 0.0;
+    for (int r = 0; r < 4; ++r) m[r] = (col_of<T>(g, r) == i) ? T(1) : T(0);
+    T myinv = T(0);
     const int row_base = (lane & 48) << 2;   // byte address of lane 0 of this lane's 16-lane row
 #pragma unroll
     for (int J = 0; J < 16; ++J) {
-        const int gJ = J & 3, rJ = J >> 2;
+        // lane group and register of column J
+        const int gJ = sizeof(T) == 8 ? (J & 3) : (J >> 2), rJ = sizeof(T) == 8 ? (J >> 2) : (J & 3);
         // every lane permute of the step is issued before anything waits for one of them (in source order the
         // compiler waited for each pair before it issued the next: six LDS round trips per step)
         const int src = row_base + (J << 2);                      // lane J of this 16-lane row: holds row J
-        const double cJ = bperm64(d[rJ], (i + 16 * gJ) << 2);   // D[i][J] of this lane's row
-        double pr[4], pm[4];
+        const T cJ = bperm(d[rJ], (i + 16 * gJ) << 2);            // D[i][J] of this lane's row
+        T pr[4], pm[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pr[r] = (r >= rJ) ? bperm64(d[r], src) : 0.0;         // D[J][g + 4 r]: the pivot row, columns >= J
-            pm[r] = (r <= rJ) ? bperm64(m[r], src) : 0.0;         // row J of the eliminated identity
+            // float64: register r holds columns g + 4 r, so only r >= rJ (r <= rJ) can hold a column >= J (<= J)
+            const bool need_d = sizeof(T) == 8 ? (r >= rJ) : true, need_m = sizeof(T) == 8 ? (r <= rJ) : true;
+            pr[r] = need_d ? bperm(d[r], src) : T(0);             // D[J][col]: the pivot row, columns >= J
+            pm[r] = need_m ? bperm(m[r], src) : T(0);             // row J of the eliminated identity
         }
-        const double p = readlane64(d[rJ], J + 16 * gJ);         // pivot, wave-uniform
-        bad = bad || !(p > 0.0);
+        const T p = readlane(d[rJ], J + 16 * gJ);                 // pivot, wave-uniform
+        bad = bad || !(p > T(0));
         // The dependent chain from one pivot to the next is  1 / p  ->  multiplier  ->  update  (a dependent FP64
         // instruction costs 13-17 ns alone, 40 ns beside another kernel's MFMAs: tools/probes/prim_probe.hip);
         // 1 / sqrt(p) only scales the finished column of L and the row of W and stays off that chain.
-        double ip = __builtin_amdgcn_rcp(p);
-        ip = __builtin_fma(__builtin_fma(-p, ip, 1.0), ip, ip);
-        const double rinv = rsqrt_f64(p);
+        const T ip = recip(p);
+        const T rinv = rsqrt_w(p);
         int ii = i;
         asm volatile("" : "+v"(ii));   // lane predicates are computed here, not hoisted into 80 scalar registers
-        const double lJ = cJ * rinv;                               // L[i][J]  (i >= J)
-        const double f = (ii > J) ? cJ * ip : 0.0;                 // D[i][J] / pivot
+        const T lJ = cJ * rinv;                                    // L[i][J]  (i >= J)
+        const T f = (ii > J) ? cJ * ip : T(0);                     // D[i][J] / pivot
         myinv = (ii == J) ? rinv : myinv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (r > rJ) {
-                d[r] = __builtin_fma(-f, pr[r], d[r]);
-            } else if (r == rJ) {
-                const double upd = __builtin_fma(-f, pr[r], d[r]);
-                d[r] = (g == gJ) ? ((ii >= J) ? lJ : 0.0) : ((g > gJ) ? upd : d[r]);
+            if constexpr (sizeof(T) == 8) {
+                if (r > rJ) {
+                    d[r] = __builtin_fma(-f, pr[r], d[r]);
+                } else if (r == rJ) {
+                    const T upd = __builtin_fma(-f, pr[r], d[r]);
+                    d[r] = (g == gJ) ? ((ii >= J) ? lJ : T(0)) : ((g > gJ) ? upd : d[r]);
+                }
+                if (r <= rJ) m[r] = __builtin_fma(-f, pm[r], m[r]);
+            } else {
+                const int kap = col_of<T>(g, r);                   // per-lane column of this register
+                const T upd = d[r] - f * pr[r];
+                d[r] = (kap == J) ? ((ii >= J) ? lJ : T(0)) : ((kap > J) ? upd : d[r]);
+                m[r] = m[r] - f * pm[r];                           // (columns > J of row J of the identity are zero)
             }
-            if (r <= rJ) m[r] = __builtin_fma(-f, pm[r], m[r]);
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (g + 4 * r > i) d[r] = 0.0;
+        if (col_of<T>(g, r) > i) d[r] = T(0);
         w[r] = m[r] * myinv;
     }
 }
@@ -240,11 +290,11 @@ __device__ __forceinline__ void chol16inv(Tile &d, Tile &w, bool &bad, int lane)
 #define CHOLK2_STAMP(i) do { } while (0)
 #define CHOLK2_TIMING_ARG
 #endif
-__global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D, int lda, double *W, int ldw,
-                                                                     double *scratch, int32_t *info,
-                                                                     int col1 CHOLK2_TIMING_ARG) {
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int lda, T *W, int ldw, T *scratch,
+                                                                     int32_t *info, int col1 CHOLK2_TIMING_ARG) {
     extern __shared__ __attribute__((aligned(16))) char cholk2_smem_raw[];
-    Smem &sm = *reinterpret_cast<Smem *>(cholk2_smem_raw);
+    Smem<T> &sm = *reinterpret_cast<Smem<T> *>(cholk2_smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __builtin_amdgcn_s_setprio(3);
     bool bad = false;
@@ -256,15 +306,15 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
         const int row = row_of(wave, h);
 #pragma unroll 1
         for (int K = 0; K <= row; K += 4) {   // four tiles in flight
-            Tile t[4];
+            Tile<T> t[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int Kq = (K + q <= row) ? K + q : row;
-                t[q] = (Kq == row) ? global_load_sym(D, lda, row, lane) : global_load(D, lda, row, Kq, lane);
+                t[q] = (Kq == row) ? global_load_sym<T>(D, lda, row, lane) : global_load<T>(D, lda, row, Kq, lane);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (K + q <= row) image_store(scratch + img_of(row, K + q), t[q], lane);
+                if (K + q <= row) image_store<T>(scratch + img_of(row, K + q), t[q], lane);
         }
     }
     // (a wave reads back only images it wrote itself until the first barrier below)
@@ -273,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
     // always the column of the current step: the columns are rotated left after every step, so that the step loop has
     // ONE body (one copy of the unrolled diagonal-tile code; straight-line code that is executed once runs at
     // instruction-fetch speed).
-    Tile P[kRows][4];
+    Tile<T> P[kRows][4];
 
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
@@ -284,8 +334,8 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
             const int row = row_of(wave, h);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (row >= c0 && c0 + c <= row) P[h][c] = image_load(scratch + img_of(row, c0 + c), lane);
-                else tile_zero(P[h][c]);
+                if (row >= c0 && c0 + c <= row) P[h][c] = image_load<T>(scratch + img_of(row, c0 + c), lane);
+                else tile_zero<T>(P[h][c]);
             }
         }
 #pragma unroll 1
@@ -293,34 +343,32 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
             const int j = c0 + jj;                 // global tile column of this step
             const int hj = slot_of(j), wj = wave_of(j);   // slot / owner wave of tile row j
             if (wave == wj) {                      // diagonal tile: factor and invert
-                Tile dt, wt;
+                Tile<T> dt, wt;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     dt[r] = hj == 0 ? P[0][0][r] : (hj == 1 ? P[1][0][r] : (hj == 2 ? P[2][0][r] : P[3][0][r]));
 #ifdef CHOLK2_TIMING
                 const long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
-                chol16inv(dt, wt, bad, lane);
+                chol16inv<T>(dt, wt, bad, lane);
 #ifdef CHOLK2_TIMING
                 if (lane == 0) tstamp[16 + j] = __builtin_amdgcn_s_memtime() - tb0;
 #endif
-                global_store(D, lda, j, j, dt, lane);
-                image_store(sm.w, wt, lane);
-                image_store(sm.wdiag[j], wt, lane);
+                global_store<T>(D, lda, j, j, dt, lane);
+                image_store<T>(sm.w, wt, lane);
+                image_store<T>(sm.wdiag[j], wt, lane);
             }
             lds_barrier();
             {   // L_ij = D_ij W_jj^T for this wave's rows below j
-                const Tile wjj = image_load(sm.w, lane);
+                const Tile<T> wjj = image_load<T>(sm.w, lane);
 #pragma unroll
                 for (int h = 0; h < kRows; ++h) {
                     const int row = row_of(wave, h);
                     if (row > j) {
-                        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-                        acc = mma_xyT(acc, P[h][0], wjj);
-                        P[h][0] = from_acc(acc);
-                        image_store(sm.lp[row], P[h][0], lane);
-                        image_store(scratch + img_of(row, j), P[h][0], lane);
-                        global_store(D, lda, row, j, P[h][0], lane);
+                        P[h][0] = mma_xyT<T>(zero_tile<T>(), P[h][0], wjj);
+                        image_store<T>(sm.lp[row], P[h][0], lane);
+                        image_store<T>(scratch + img_of(row, j), P[h][0], lane);
+                        global_store<T>(D, lda, row, j, P[h][0], lane);
                     }
                 }
             }
@@ -331,11 +379,11 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
             for (int cc = 1; cc < 4; ++cc) {
                 const int c = j + cc;
                 if (jj + cc < 4) {
-                    const Tile nlc = negated(image_load(sm.lp[c], lane));
+                    const Tile<T> nlc = -image_load<T>(sm.lp[c], lane);
 #pragma unroll
                     for (int h = 0; h < kRows; ++h) {
                         const int row = row_of(wave, h);
-                        if (row >= c) P[h][cc] = from_acc(mma_xyT(to_acc(P[h][cc]), P[h][0], nlc));
+                        if (row >= c) P[h][cc] = mma_xyT<T>(P[h][cc], P[h][0], nlc);
                     }
                 }
             }
@@ -353,28 +401,29 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
         for (int h = 0; h < kRows; ++h) {
             const int row = row_of(wave, h);
             if (row < c0 + 4) continue;
-            Tile n[4];
+            Tile<T> n[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) n[c] = negated(image_load(scratch + img_of(row, c0 + c), lane));
+            for (int c = 0; c < 4; ++c) n[c] = -image_load<T>(scratch + img_of(row, c0 + c), lane);
             // Software pipeline over three register sets: the operands of the next two tiles are in flight while a
             // tile is computed; no register copies between rounds (a copy of a register that is being loaded is a wait
             // for the load).  Rounds past the last tile repeat it: same values to the same addresses.
             const int K0 = c0 + 4;
-            auto trail_load = [&](int K, Tile (&l)[4], Tile &dk) {
+            auto trail_load = [&](int K, Tile<T> (&l)[4], Tile<T> &dk) {
                 const int Kc = K < row ? K : row;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) l[c] = image_load(scratch + img_of(Kc, c0 + c), lane);
-                dk = image_load(scratch + img_of(row, Kc), lane);
+                for (int c = 0; c < 4; ++c) l[c] = image_load<T>(scratch + img_of(Kc, c0 + c), lane);
+                dk = image_load<T>(scratch + img_of(row, Kc), lane);
             };
-            auto trail_tile = [&](int K, const Tile (&l)[4], const Tile &dk) {
-                f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                acc0 = mma_xyT(acc0, n[0], l[0]);
-                acc1 = mma_xyT(acc1, n[1], l[1]);
-                acc0 = mma_xyT(acc0, n[2], l[2]);
-                acc1 = mma_xyT(acc1, n[3], l[3]);
-                image_store(scratch + img_of(row, K < row ? K : row), dk + (acc0 + acc1), lane);
+            auto trail_tile = [&](int K, const Tile<T> (&l)[4], const Tile<T> &dk) {
+                Tile<T> acc0 = zero_tile<T>(), acc1 = zero_tile<T>();
+                acc0 = mma_xyT<T>(acc0, n[0], l[0]);
+                acc1 = mma_xyT<T>(acc1, n[1], l[1]);
+                acc0 = mma_xyT<T>(acc0, n[2], l[2]);
+                acc1 = mma_xyT<T>(acc1, n[3], l[3]);
+                const Tile<T> res = dk + (acc0 + acc1);
+                image_store<T>(scratch + img_of(row, K < row ? K : row), res, lane);
             };
-            Tile la[4], lb[4], lc[4], da, db, dc;
+            Tile<T> la[4], lb[4], lc[4], da, db, dc;
             trail_load(K0, la, da);
             trail_load(K0 + 1, lb, db);
 #pragma unroll 1
@@ -399,37 +448,37 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(double *D,
 #pragma unroll 1
     for (int pass = 0; pass < kRows; ++pass) {
         const int c = row_of(wave, pass == 0 ? 0 : (pass == 1 ? 3 : (pass == 2 ? 1 : 2)));   // w, 15 - w, 7 - w, 8 + w
-        Tile U[NT];
-        U[0] = image_load_transposed(sm.wdiag[c], lane);                     // U_c
-        const Tile wcc = image_load(sm.wdiag[c], lane);
+        Tile<T> U[NT];
+        U[0] = image_load_transposed<T>(sm.wdiag[c], lane);                     // U_c
+        const Tile<T> wcc = image_load<T>(sm.wdiag[c], lane);
         // the products of the column as one stream k = u (u - 1) / 2 + v; the L tile of product k + 8 is requested when
         // product k starts
         constexpr int kRing = 8;
-        Tile Q[kRing];
+        Tile<T> Q[kRing];
 #pragma unroll
-        for (int k = 0; k < kRing; ++k) Q[k] = image_load(scratch + img_of(min(c + kTriU[k], NT - 1), c + kTriV[k]), lane);
+        for (int k = 0; k < kRing; ++k) Q[k] = image_load<T>(scratch + img_of(min(c + kTriU[k], NT - 1), c + kTriV[k]), lane);
 #pragma unroll
         for (int u = 1; u < NT; ++u) {
             if (c + u < NT) {
-                f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                Tile<T> acc0 = zero_tile<T>(), acc1 = zero_tile<T>();
 #pragma unroll
                 for (int v = 0; v < u; ++v) {
                     const int k = u * (u - 1) / 2 + v;
-                    const Tile l = Q[k % kRing];
+                    const Tile<T> l = Q[k % kRing];
                     if (k + kRing < kTriCount)
-                        Q[k % kRing] = image_load(scratch + img_of(min(c + kTriU[k + kRing], NT - 1), c + kTriV[k + kRing]), lane);
-                    if (v & 1) acc1 = mma_xyT(acc1, U[v], l);
-                    else acc0 = mma_xyT(acc0, U[v], l);
+                        Q[k % kRing] = image_load<T>(scratch + img_of(min(c + kTriU[k + kRing], NT - 1), c + kTriV[k + kRing]), lane);
+                    if (v & 1) acc1 = mma_xyT<T>(acc1, U[v], l);
+                    else acc0 = mma_xyT<T>(acc0, U[v], l);
                 }
-                const Tile wii = image_load(sm.wdiag[c + u], lane);
-                f64x4 out = {0.0, 0.0, 0.0, 0.0};
-                U[u] = mma_xyT(out, -(acc0 + acc1), wii);
+                const Tile<T> wii = image_load<T>(sm.wdiag[c + u], lane);
+                const Tile<T> nacc = -(acc0 + acc1);
+                U[u] = mma_xyT<T>(zero_tile<T>(), nacc, wii);
             }
         }
-        global_store(W, ldw, c, c, wcc, lane);                               // W_cc as it is
+        global_store<T>(W, ldw, c, c, wcc, lane);                               // W_cc as it is
 #pragma unroll
         for (int u = 1; u < NT; ++u)
-            if (c + u < NT) global_store_transposed(W, ldw, c + u, c, U[u], lane);
+            if (c + u < NT) global_store_transposed<T>(W, ldw, c + u, c, U[u], lane);
         if (wave == 0) CHOLK2_STAMP(13 + (pass & 1));
     }
     __syncthreads();

@@ -61,7 +61,7 @@ int main() {
     hipMalloc(&dD0, hD.size() * 8); hipMalloc(&dD, hD.size() * 8); hipMalloc(&dW, size_t(n) * ldw * 8);
     hipMalloc(&dS, 1 << 20); hipMalloc(&dinfo, 4);
     hipMemcpy(dD0, hD.data(), hD.size() * 8, hipMemcpyHostToDevice);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(cholk2::Smem));
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(cholk2::Smem<double>));
     hipFuncSetAttribute(reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(cholk::Ge64Smem<double>));
     auto check = [&](const char *name) {
         std::vector<double> gD(n * lda), gW(size_t(n) * ldw);
@@ -87,7 +87,7 @@ int main() {
                eL / mL, wi, wj, eW / mW, upW);
     };
     auto run_v2 = [&]() {
-        hipLaunchKernelGGL(cholk2::chol_diag256_v2_kernel, dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem), 0, dD, lda, dW, ldw, dS,
+        hipLaunchKernelGGL((cholk2::chol_diag256_v2_kernel<double>), dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem<double>), 0, dD, lda, dW, ldw, dS,
                            dinfo, 1, dT);
     };
     auto run_v1 = [&]() {
