@@ -75,8 +75,7 @@ def chol_schedule(unknowns, elem=8):
     """The trailing-update launches of the Cholesky schedule (chol.hip potrf_batch) for films with the given
     numbers of unknowns: per launch the lower 128 x 128 tiles of the trailing block are read and written once and
     the pending panels below them (256 columns, or 512 when the previous step's update was kept pending: large
-    trailing matrices, every other step) are read once.  The block starts behind the next panel, or -- skip mode,
-    trailing order <= 8192 -- behind the panel after it.
+    trailing matrices, every other step) are read once.  The block starts behind the next panel.
     Returns (average algorithmic bytes per launch, launches per factorization)."""
     total, launches = 0.0, 0
     for n in unknowns:
@@ -88,8 +87,7 @@ def chol_schedule(unknowns, elem=8):
             kp = c - upd0
             delay = kp < 512 and right > 8192 and ((k0 + npad) // 256) % 2 != 1
             if right > 256 and not delay:
-                lead = 512 if (right <= 8192 and right > 512) else 256
-                m = npad - (c + lead)
+                m = npad - (c + 256)
                 nt = m // 128
                 total += 2.0 * (nt * (nt + 1) // 2) * 128 * 128 * elem + m * kp * elem
                 launches += 1
@@ -748,6 +746,12 @@ def main():
         t_fact = float(np.median(tf))
         fact_flops = sum(u ** 3 / 3.0 for u in unknowns) if used_chol else sum(2.0 * u ** 3 / 3.0 for u in unknowns)
         extras["factorization_ms"] = t_fact * 1e3
+        # what a dependent launch costs on the panel-chain streams the schedule uses, as the library measured them on
+        # this device against the caller's stream (chol.hip calibrate_chain_streams); the first entries are the
+        # ones in use
+        chain_us, chain_pipe = kernels.chol_chain_stream_costs()
+        extras["chain_stream_dependent_launch_us"] = [round(v, 1) for v in chain_us]
+        extras["chain_stream_pipe_group"] = chain_pipe
         extras["factorization_TFLOPs"] = fact_flops / t_fact / 1e12
         extras["factorization_frac"] = fact_flops / t_fact / 1e12 / FP64_MFMA_PEAK_TFLOPS
         extras["step_TFLOPs_factorization_flops_only"] = fact_flops / (elapsed / args.steps) / 1e12

@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 2
+#define SSA_ABI_VERSION 3
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);
@@ -173,6 +173,19 @@ int ssa_chol_factor_batch(int count, void *const *S, const int64_t *n, const int
 size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
 int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
                    int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+/*
+ * Diagnostics of the factorization schedule (no reference counterpart).  The panel chains run on internal
+ * high-priority streams; which hardware queue / command-processor pipe the runtime gives a stream decides what a
+ * dependent launch on it costs beside the trailing updates (2-4 us, or 35-40 us when it shares the pipe of the
+ * caller's stream or of another chain), so the first ssa_chol_factor* call on a device measures its chain streams
+ * against the caller's stream and against each other (about 10 ms, once) and gives every film's chain a pipe of its
+ * own as far as there are pipes.  ssa_chol_chain_stream_costs writes, for up to `capacity` chain streams of the
+ * current device in the order in which the schedule uses them, the measured cost of a dependent launch
+ * (microseconds, alone beside the caller's stream) and the group of streams it shares a pipe with (0 = the caller's
+ * pipe, 1, 2, ... = others); either pointer may be NULL.  Returns the number of chain streams (0 before the first
+ * factorization on this device).
+ */
+int ssa_chol_chain_stream_costs(double *microseconds, int32_t *pipe_group, int capacity);
 
 /*
  * Replaces the numba kernels _biot_savart_2d_z / _biot_savart_2d_vector

@@ -206,15 +206,40 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
 }
 
 // Per concurrently factored matrix (look-ahead lane): the high-priority side stream of the panel chain
-// with its two events, and a low-priority stream on which a matrix that is done before the others
-// (a smaller film) builds its solve-phase blocks while the tail of the others still runs.
+// (one of the device's chain streams, see below), its events, and a low-priority stream on which a matrix that is
+// done before the others (a smaller film) builds its solve-phase blocks while the tail of the others still runs.
 struct CholLane {
-    hipStream_t side = nullptr, side2 = nullptr, finish = nullptr, upd = nullptr;
+    hipStream_t side = nullptr, finish = nullptr, upd = nullptr;
     hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr,
-               ev_upd = nullptr, ev_diag = nullptr, ev_top = nullptr, ev_below = nullptr;
-    hipEvent_t ev_syrk2 = nullptr;   // the trailing updates record ev_syrk and ev_syrk2 in turn (the chains may wait for the one before the last)
+               ev_upd = nullptr;
 };
 constexpr int kMaxLanes = 16;
+
+// Which high-priority stream a panel chain runs on matters: the runtime maps the streams of a process onto hardware
+// queues and those onto the four pipes of the command processor.  A queue that shares its pipe with the queue of the
+// trailing updates waits for the pipe while an update's workgroups are being dispatched - every dependent launch of
+// the chain then costs 35-40 us instead of 2-4 us - and so do two chains that share a pipe with each other
+// (tools/probes/pipe_probe.hip, profiles/r03_pipe_probe.txt: one high-priority stream in four is slow beside a given
+// stream, in no fixed order; config H factorization 97-100 ms with both chains on good streams, 105-110 ms with one
+// on a bad one).  Nothing in the HIP API tells which is which, so the device's chain streams are measured once
+// against the caller's stream: a short chain of dependent one-workgroup launches on each candidate beside
+// back-to-back chip-filling launches on the caller's stream, then the good candidates against each other in pairs
+// (which of them share a pipe); about 10 ms, once per device and caller stream.  The lanes take one stream of each
+// pipe first.
+constexpr int kChainPool = 16;
+constexpr int kCalibLinks = 8;
+constexpr long long kCalibLinkTicks = 500;       // alone: 5-us links (at the 100 MHz of wall_clock64())
+constexpr long long kCalibPairLinkTicks = 2000;  // pairs: 20-us links, so that two streams on ONE queue show as well
+constexpr long long kCalibLoadTicks = 2000;      // 20 us per workgroup of the load
+constexpr int kCalibLoadGrid = 2080, kCalibLoadLaunches = 7;   // per test: 7 x ceil(2080 / 512) x 20 us = 0.56 ms
+
+// a timed spin; workgroups of the load leave at once after the tests are over (*stop != 0)
+__global__ __launch_bounds__(256) void pipe_calibration_kernel(long long ticks, const int32_t *stop) {
+    if (stop != nullptr && __atomic_load_n(stop, __ATOMIC_RELAXED) != 0) return;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+}
+__global__ void pipe_calibration_stop_kernel(int32_t *stop) { __atomic_store_n(stop, 1, __ATOMIC_RELAXED); }
 
 // The lanes of one device and the mutex that serialises schedules on that device (the lanes are the
 // schedule's streams and events; other devices of the process enqueue concurrently).  Created on first
@@ -222,36 +247,189 @@ constexpr int kMaxLanes = 16;
 struct LaneSet {
     CholLane lanes[kMaxLanes];
     std::mutex enqueue;
+    hipStream_t chain_pool[kChainPool] = {};
+    bool pool_made = false, calibrated = false;
+    hipStream_t calibrated_for = nullptr;
+    float chain_us[kChainPool] = {};   // per dependent launch, alone beside the caller's stream (diagnostics)
+    int chain_pipe[kChainPool] = {};   // 0: shares the caller's pipe; 1, 2, ...: groups of streams that share a pipe
+    int chain_order[kChainPool] = {};  // pool indices in the order the lanes use them
+    int32_t *calib_stop = nullptr;     // device flag of the calibration load
 };
 LaneSet g_lane_sets[kMaxDevices];
 std::mutex g_lane_create_mutex;
 
-inline int get_lanes(int count, LaneSet **out) {
+// One measurement: the chain streams a (and b, if >= 0) each run kCalibLinks dependent 5-us launches, at the same
+// time, beside the load on the caller's stream; us = cost per dependent launch, the worse of the two.
+struct ChainTest {
+    int a, b;
+    float us;
+};
+
+// Runs the tests one after the other on the device (enqueued behind a gate and timed with events: the host's launch
+// rate does not enter), then waits for them.
+inline int run_chain_tests(LaneSet &set, hipStream_t st, ChainTest *tests, int n, long long link_ticks) {
+    if (n <= 0) return SSA_OK;
+    constexpr int kMaxTests = 2 * kChainPool;
+    if (n > kMaxTests) return SSA_ERR_INVALID_ARGUMENT;
+    hipEvent_t gate = nullptr, ev[kMaxTests][4] = {};
+    hipStream_t gate_s = nullptr;
+    int rc = SSA_OK;
+    auto ok = [&rc](hipError_t e) {
+        if (e != hipSuccess) rc = SSA_ERR_HIP;
+        return e == hipSuccess;
+    };
+    ok(hipStreamCreateWithFlags(&gate_s, hipStreamNonBlocking)) && ok(hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+    for (int t = 0; t < n && rc == SSA_OK; ++t)
+        for (int e = 0; e < 4 && rc == SSA_OK; ++e) ok(hipEventCreate(&ev[t][e]));
+    if (rc == SSA_OK && set.calib_stop == nullptr) ok(hipMalloc(reinterpret_cast<void **>(&set.calib_stop), sizeof(int32_t)));
+    if (rc == SSA_OK) {
+        ok(hipMemsetAsync(set.calib_stop, 0, sizeof(int32_t), gate_s));
+        hipLaunchKernelGGL(pipe_calibration_kernel, dim3(1), dim3(256), 0, gate_s, 20000LL + 2500LL * n, nullptr);   // the enqueue below
+        ok(hipEventRecord(gate, gate_s));
+        ok(hipStreamWaitEvent(st, gate, 0));
+        for (int i = 0; i < n * kCalibLoadLaunches; ++i)
+            hipLaunchKernelGGL(pipe_calibration_kernel, dim3(kCalibLoadGrid), dim3(256), 64 << 10, st, kCalibLoadTicks,
+                               set.calib_stop);
+        for (int t = 0; t < n && rc == SSA_OK; ++t) {
+            const int who[2] = {tests[t].a, tests[t].b};
+            for (int h = 0; h < 2; ++h) {
+                if (who[h] < 0) continue;
+                hipStream_t c = set.chain_pool[who[h]];
+                if (t == 0) {
+                    ok(hipStreamWaitEvent(c, gate, 0));
+                } else {
+                    ok(hipStreamWaitEvent(c, ev[t - 1][1], 0));
+                    if (tests[t - 1].b >= 0) ok(hipStreamWaitEvent(c, ev[t - 1][3], 0));
+                }
+                ok(hipEventRecord(ev[t][2 * h], c));
+            }
+            for (int l = 0; l < kCalibLinks; ++l)
+                for (int h = 0; h < 2; ++h)
+                    if (who[h] >= 0)
+                        hipLaunchKernelGGL(pipe_calibration_kernel, dim3(1), dim3(256), 0, set.chain_pool[who[h]], link_ticks, nullptr);
+            for (int h = 0; h < 2; ++h)
+                if (who[h] >= 0) ok(hipEventRecord(ev[t][2 * h + 1], set.chain_pool[who[h]]));
+        }
+        if (rc == SSA_OK) {   // the load is not needed any longer once the last test is over
+            hipStream_t last = set.chain_pool[tests[n - 1].a];
+            if (tests[n - 1].b >= 0) ok(hipStreamWaitEvent(last, ev[n - 1][3], 0));
+            hipLaunchKernelGGL(pipe_calibration_stop_kernel, dim3(1), dim3(1), 0, last, set.calib_stop);
+        }
+        if (hipGetLastError() != hipSuccess) rc = SSA_ERR_HIP;
+    }
+    if (rc == SSA_OK) {
+        ok(hipEventSynchronize(ev[n - 1][1]));
+        if (tests[n - 1].b >= 0) ok(hipEventSynchronize(ev[n - 1][3]));
+    }
+    for (int t = 0; t < n && rc == SSA_OK; ++t) {
+        float ms = 0.f, ms2 = 0.f;
+        ok(hipEventElapsedTime(&ms, ev[t][0], ev[t][1]));
+        if (tests[t].b >= 0 && ok(hipEventElapsedTime(&ms2, ev[t][2], ev[t][3]))) ms = std::max(ms, ms2);
+        tests[t].us = ms * 1000.f / kCalibLinks - static_cast<float>(link_ticks) / 100.f;
+    }
+    for (int t = 0; t < n; ++t)
+        for (hipEvent_t e : ev[t])
+            if (e) (void)hipEventDestroy(e);
+    if (gate) (void)hipEventDestroy(gate);
+    if (gate_s) {
+        (void)hipStreamSynchronize(gate_s);
+        (void)hipStreamDestroy(gate_s);
+    }
+    return rc;
+}
+
+// Groups the chain streams of `set` by pipe (see above) and hands them to the lanes: one stream of every pipe that
+// is not the caller's first, then the second of each, ...; the streams on the caller's pipe last.
+inline int calibrate_chain_streams(LaneSet &set, hipStream_t st) {
+    ChainTest tests[kChainPool];
+    for (int j = 0; j < kChainPool; ++j) tests[j] = ChainTest{j, -1, 0.f};
+    int rc = run_chain_tests(set, st, tests, kChainPool, kCalibLinkTicks);
+    if (rc != SSA_OK) return rc;
+    float best = 1e30f;
+    for (int j = 0; j < kChainPool; ++j) {
+        set.chain_us[j] = tests[j].us;
+        best = std::min(best, tests[j].us);
+    }
+    // a stream is "slow" above a limit well clear of both populations (2-4 us and 35-40 us; pairs on distinct
+    // pipes: 6-9 us)
+    const float limit = 2.f * std::max(best, 0.f) + 12.f;
+    int unassigned = 0;
+    for (int j = 0; j < kChainPool; ++j) {
+        set.chain_pipe[j] = (tests[j].us > limit) ? 0 : -1;
+        unassigned += set.chain_pipe[j] < 0;
+    }
+    int pipes = 0;
+    while (unassigned > 0 && pipes < 8) {
+        // the first unassigned stream founds a group; the others join it if the pair is slow together
+        int lead = 0;
+        while (set.chain_pipe[lead] >= 0) ++lead;
+        set.chain_pipe[lead] = ++pipes;
+        --unassigned;
+        int n = 0;
+        for (int j = 0; j < kChainPool; ++j)
+            if (set.chain_pipe[j] < 0) tests[n++] = ChainTest{lead, j, 0.f};
+        rc = run_chain_tests(set, st, tests, n, kCalibPairLinkTicks);
+        if (rc != SSA_OK) return rc;
+        for (int t = 0; t < n; ++t)
+            if (tests[t].us > limit) {
+                set.chain_pipe[tests[t].b] = pipes;
+                --unassigned;
+            }
+    }
+    for (int j = 0; j < kChainPool; ++j)
+        if (set.chain_pipe[j] < 0) set.chain_pipe[j] = pipes;   // (more than 8 groups: not a real device; keep going)
+    int m = 0;
+    bool used[kChainPool] = {};
+    for (int round = 0; round < kChainPool && m < kChainPool; ++round)      // round r: the r-th stream of every pipe
+        for (int g = 1; g <= pipes; ++g) {
+            int seen = 0;
+            for (int j = 0; j < kChainPool; ++j)
+                if (set.chain_pipe[j] == g && !used[j] && seen++ == 0) {
+                    used[j] = true;
+                    set.chain_order[m++] = j;
+                }
+        }
+    for (int j = 0; j < kChainPool; ++j)
+        if (!used[j]) set.chain_order[m++] = j;
+    for (int i = 0; i < kMaxLanes; ++i) set.lanes[i].side = set.chain_pool[set.chain_order[i % kChainPool]];
+    set.calibrated = true;
+    set.calibrated_for = st;
+    return SSA_OK;
+}
+
+inline int get_lanes(int count, hipStream_t st, LaneSet **out) {
     std::lock_guard<std::mutex> lock(g_lane_create_mutex);
     int dev = 0;
     if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
-    CholLane *lanes = g_lane_sets[dev].lanes;  // streams belong to the device they were made on
+    LaneSet &set = g_lane_sets[dev];
+    CholLane *lanes = set.lanes;  // streams belong to the device they were made on
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
+    if (!set.pool_made) {
+        for (int j = 0; j < kChainPool; ++j)
+            if (hipStreamCreateWithPriority(&set.chain_pool[j], hipStreamNonBlocking, hi) != hipSuccess) return SSA_ERR_HIP;
+        set.pool_made = true;
+    }
     for (int i = 0; i < count; ++i) {
-        if (lanes[i].side != nullptr) continue;
-        if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&lanes[i].side2, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_diag, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_top, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_below, hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithPriority(&lanes[i].finish, hipStreamNonBlocking, lo) != hipSuccess ||
+        if (lanes[i].finish != nullptr) continue;
+        if (hipStreamCreateWithPriority(&lanes[i].finish, hipStreamNonBlocking, lo) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_upd, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_strip, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_syrk, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_syrk2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
-    *out = &g_lane_sets[dev];
+    // (the lanes' chain streams are idle here: every schedule joins them into the caller's stream, and schedules
+    // of one device are serialised by set.enqueue, which the caller takes after this)
+    if (!set.calibrated || set.calibrated_for != st) {
+        std::lock_guard<std::mutex> enq(set.enqueue);
+        const int rc = calibrate_chain_streams(set, st);
+        if (rc != SSA_OK) return rc;
+    }
+    *out = &set;
     return SSA_OK;
 }
 
@@ -260,20 +438,27 @@ inline int destroy_lanes() {
     std::lock_guard<std::mutex> lock(g_lane_create_mutex);
     int rc = SSA_OK;
     for (int d = 0; d < kMaxDevices; ++d) {
-        std::lock_guard<std::mutex> enq(g_lane_sets[d].enqueue);
-        for (CholLane &ln : g_lane_sets[d].lanes) {
-            if (ln.side == nullptr) continue;
-            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.side2) != hipSuccess ||
-                hipStreamSynchronize(ln.finish) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess)
-                rc = SSA_ERR_HIP;
-            hipEvent_t evs[10] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk,
-                                  ln.ev_upd,   ln.ev_diag,  ln.ev_top,  ln.ev_below,  ln.ev_syrk2};
+        LaneSet &set = g_lane_sets[d];
+        std::lock_guard<std::mutex> enq(set.enqueue);
+        for (CholLane &ln : set.lanes) {
+            if (ln.finish == nullptr) continue;
+            if (hipStreamSynchronize(ln.finish) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
+            hipEvent_t evs[6] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk, ln.ev_upd};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.side2) != hipSuccess ||
-                hipStreamDestroy(ln.finish) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess)
-                rc = SSA_ERR_HIP;
+            if (hipStreamDestroy(ln.finish) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
             ln = CholLane{};
+        }
+        if (set.pool_made) {
+            for (hipStream_t &c : set.chain_pool) {
+                if (hipStreamSynchronize(c) != hipSuccess || hipStreamDestroy(c) != hipSuccess) rc = SSA_ERR_HIP;
+                c = nullptr;
+            }
+            set.pool_made = set.calibrated = false;
+        }
+        if (set.calib_stop != nullptr) {
+            if (hipFree(set.calib_stop) != hipSuccess) rc = SSA_ERR_HIP;
+            set.calib_stop = nullptr;
         }
     }
     return rc;
@@ -446,18 +631,25 @@ struct FinishPlan {
 // With one matrix this is plain look-ahead (the chain is then the critical path for n ~ 20k);
 // with two or more the chains hide behind the other films' updates.
 //
-// Per matrix and outer step k:   diagonal block C[0:256, 0:256] -= P[0:256] P[0:256]^T, diagonal-block kernel of
-//                                panel k+1, first block row of panel k+1      (side stream: the critical chain)
-//                                strip C[256:, 0:256] -= P[256:] P[0:256]^T, rest of panel k+1
-//                                                                             (second side stream, one step behind)
+// Per matrix and outer step k:   block column C[:, 0:256] -= P P[0:256]^T (diagonal block and the strip below it in
+//                                one product), diagonal-block kernel of panel k+1, panel k+1 = A21 W^T
+//                                                                             (side stream: three dependent launches)
 //                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream; for a large
 //                                        trailing matrix every other step: P = the last two panels, K = 512)
+//
+// The chain is ONE stream per matrix.  Rounds 2 and 3 ran it as two (diagonal block -> diagonal-block kernel ->
+// first block row on one, strip and the rest of the panel one step behind on a second: a look-ahead inside the
+// chain), with up to six hand-offs per round between the three streams of a matrix.  With the diagonal-block kernel
+// of round 3 that no longer pays: a dependent launch on the same stream costs 1-5 us, a hand-off between streams
+// 25-130 us once four or more queues are active (tools/probes/gap_probe.hip, profiles/r03_gap_probe.txt), and the
+// one-stream chain is as fast or faster on every configuration (config H 100.0 vs 101.3 ms, float32 57.8 vs 60.1,
+// four films 360 vs 364, one film 408.9 vs 407.4 ms).
 template <typename T>
 int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
     // the lanes (side streams + events) are shared per device: one schedule per device is enqueued at a time
     LaneSet *lane_set = nullptr;
-    int rc = get_lanes(count, &lane_set);
+    int rc = get_lanes(count, st, &lane_set);
     if (rc != SSA_OK) return rc;
     std::lock_guard<std::mutex> enqueue_lock(lane_set->enqueue);
     CholLane *lanes = lane_set->lanes;
@@ -484,40 +676,20 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (hipEventRecord(ln.ev_strip, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_strip, 0) != hipSuccess)
             return SSA_ERR_HIP;
         if (split_updates && hipStreamWaitEvent(ln.upd, ln.ev_strip, 0) != hipSuccess) return SSA_ERR_HIP;
-        if (hipStreamWaitEvent(ln.side2, ln.ev_strip, 0) != hipSuccess) return SSA_ERR_HIP;
         rc = chol_panel_diag(J, 0, ln.side);
         if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ln.ev_diag, ln.side) != hipSuccess) return SSA_ERR_HIP;
-        rc = chol_panel_rows(J, 0, CNB, std::min<int64_t>(2 * CNB, J.n), ln.side);
+        rc = chol_panel_rows(J, 0, CNB, J.n, ln.side);
         if (rc != SSA_OK) return rc;
-        if (hipEventRecord(ln.ev_top, ln.side) != hipSuccess || hipStreamWaitEvent(ln.side2, ln.ev_diag, 0) != hipSuccess)
-            return SSA_ERR_HIP;
-        rc = chol_panel_rows(J, 0, 2 * CNB, J.n, ln.side2);
-        if (rc != SSA_OK) return rc;
-        if (hipStreamWaitEvent(ln.side2, ln.ev_top, 0) != hipSuccess || hipEventRecord(ln.ev_panel, ln.side2) != hipSuccess)
-            return SSA_ERR_HIP;
+        if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
     }
     bool detached[kMaxLanes] = {};
+    bool updated[kMaxLanes] = {};      // a trailing update of this matrix has been issued (ev_syrk is recorded)
     int64_t pending_from[kMaxLanes] = {};
     // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
-    // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' strips
-    constexpr int kDelayDepth = 2;            // (3 panels, K = 768: 114.5 vs 109.5 ms with the two-stream chains)
-    constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 12288: flat within 1 %, round 2 and again with the skip mode below)
-    // Skip mode (chain-bound tail).  The next panel's block column b_c is made current by the chains, the rest of the
-    // trailing matrix by the update stream; while update k - 1 also wrote b_c, the chains of step k had to wait for
-    // it: in the tail, where nothing hides the chains, every round then was  ... -> panel -> update (80-300 us) ->
-    // diagonal-block update -> diagonal-block kernel.  Below kSkipMaxCols an update leaves out the block column
-    // after the next as well (it starts at column c + 512) and the chains apply the last TWO panels (K = 512) to
-    // their block column: the update the chains wait for is then the one before the last, a full round old.  Each
-    // update is remembered with the first row / column it touched, the panels it had applied and its event; the
-    // chains of b_c start from the last update that covered b_c.
-    constexpr int64_t kSkipMaxCols = 8192;   // (0 / 4096 / 8192 / 12288: 102.1 / 102.6 / 101.6 / 101.2 ms on one box)
-    struct UpdateRecord {
-        int64_t rstart = -1, upto = 0;   // rows / columns >= rstart were updated with the panels [.., upto)
-        hipEvent_t ev = nullptr;
-    };
-    UpdateRecord last_upd[kMaxLanes], prev_upd[kMaxLanes];
+    // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' products
+    constexpr int kDelayDepth = 2;            // (3 / 4 panels: 107 / 108 against 101.5-102.8 ms, round 3)
+    constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 16384: flat within 1 %, rounds 2 and 3)
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
@@ -544,71 +716,40 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 continue;
             }
             const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
-            hipStream_t us = cur_us[i];                                    // where this matrix' trailing updates run
-            hipStream_t c1 = ln.side;                                      // the critical chain
-            hipStream_t c2 = ln.side2;                                     // the second chain, one step behind
+            hipStream_t us = cur_us[i];                       // where this matrix' trailing updates run
+            hipStream_t cs = ln.side;                         // the matrix' panel chain
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
             const int64_t c = k0 + CNB;
-            // panels the chains still have to apply to the block column b_c: everything after the last trailing
-            // update that covered b_c; the update stream itself continues where its last update stopped
-            const UpdateRecord *cover = (last_upd[i].rstart >= 0 && last_upd[i].rstart <= c) ? &last_upd[i]
-                                        : ((prev_upd[i].rstart >= 0 && prev_upd[i].rstart <= c) ? &prev_upd[i] : nullptr);
-            const int64_t pend0 = cover ? cover->upto : 0, kp = c - pend0;
-            const int64_t upd0 = pending_from[i], kpu = c - upd0;   // panels pending for the update stream
-            const T *P = J.A + c * J.lda + pend0;             // the chains' panels below the diagonal block of panel k
+            // panels that the trailing matrix has not seen yet: everything after the last trailing update
+            const int64_t upd0 = pending_from[i], kp = c - upd0;
+            const T *P = J.A + c * J.lda + upd0;              // those panels, from the next diagonal block down
             T *C = J.A + c * J.lda + c;
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
-            // The chain of a matrix is two streams (diagonal look-ahead).  What the NEXT diagonal block needs of
-            // panel k is only its first block row, so per panel the critical recurrence is
-            //     diagonal block update (256 x 256 x kp) -> diagonal-block kernel -> first block row of the panel
-            // on ln.side, while ln.side2 applies the pending panels to the rows below (the strip) and computes the
-            // rest of the panel, one step behind; neither queues behind the other matrices' updates, both wait for
-            // the last trailing update of THIS matrix (which wrote the strip's columns).  (Strip, diagonal kernel and
-            // panel rows were one serial chain before: 0.6 ms per panel in the chain-bound tail, now 0.35-0.55 ms;
-            // config H 114 -> 109.6 ms.)
-            if (right > nw) {   // strip, rows below the diagonal block: behind panel k (all rows) on this stream
-                if (cover && hipStreamWaitEvent(c2, cover->ev, 0) != hipSuccess) return SSA_ERR_HIP;
-                rc = gemm_op_t(0, 1, 0, right - nw, nw, kp, -1.0, P + nw * J.lda, J.lda, P, J.lda, 1.0, C + nw * J.lda,
-                               J.lda, c2);
-                if (rc != SSA_OK) return rc;
-                if (hipEventRecord(ln.ev_below, c2) != hipSuccess) return SSA_ERR_HIP;
-            }
-            if (cover && hipStreamWaitEvent(c1, cover->ev, 0) != hipSuccess) return SSA_ERR_HIP;
-            rc = gemm_op_t(0, 1, 0, nw, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, c1);
+            // the chain: pending panels onto the next block column (behind the last trailing update of THIS matrix,
+            // which wrote that column), diagonal-block kernel, the panel below it
+            if (updated[i] && hipStreamWaitEvent(cs, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
+            rc = gemm_op_t(0, 1, 0, right, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, cs);
             if (rc != SSA_OK) return rc;
-            rc = chol_panel_diag(J, c, c1);
+            rc = chol_panel_diag(J, c, cs);
             if (rc != SSA_OK) return rc;
-            if (hipEventRecord(ln.ev_diag, c1) != hipSuccess) return SSA_ERR_HIP;
             if (right > nw) {
-                if (hipStreamWaitEvent(c1, ln.ev_below, 0) != hipSuccess) return SSA_ERR_HIP;
-                rc = chol_panel_rows(J, c, c + CNB, std::min<int64_t>(c + 2 * CNB, J.n), c1);
+                rc = chol_panel_rows(J, c, c + CNB, J.n, cs);
                 if (rc != SSA_OK) return rc;
             }
-            if (hipEventRecord(ln.ev_top, c1) != hipSuccess || hipStreamWaitEvent(c2, ln.ev_diag, 0) != hipSuccess)
-                return SSA_ERR_HIP;
-            rc = chol_panel_rows(J, c, c + 2 * CNB, J.n, c2);
-            if (rc != SSA_OK) return rc;
-            if (hipStreamWaitEvent(c2, ln.ev_top, 0) != hipSuccess || hipEventRecord(ln.ev_panel, c2) != hipSuccess)
-                return SSA_ERR_HIP;
+            if (hipEventRecord(ln.ev_panel, cs) != hipSuccess) return SSA_ERR_HIP;
             // every other panel of a large trailing matrix keeps its update pending: the next one then
             // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
             // (the phase comes from the matrix' own size, not from its place in the batch: the result
             // of a matrix does not depend on what else is factored with it)
-            const bool delay = kpu < kDelayDepth * CNB && right > kDelayMinCols &&
+            const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
                                ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
             if (right > nw && !delay) {  // rest of the trailing update: lower tiles behind the next panel's block column
-                // (skip mode: behind the block column after it as well)
-                const int64_t lead = (kSkipMaxCols > 0 && right <= kSkipMaxCols && right > 2 * nw) ? 2 * nw : nw;
-                const int64_t rstart = c + lead, M = J.n - rstart;
+                const int64_t rstart = c + nw, M = J.n - rstart;
                 const T *P2 = J.A + rstart * J.lda + upd0;
-                rc = gemm_op_t(0, 1, 1, M, M, kpu, -1.0, P2, J.lda, P2, J.lda, 1.0, J.A + rstart * (J.lda + 1), J.lda, us);
+                rc = gemm_op_t(0, 1, 1, M, M, kp, -1.0, P2, J.lda, P2, J.lda, 1.0, J.A + rstart * (J.lda + 1), J.lda, us);
                 if (rc != SSA_OK) return rc;
-                hipEvent_t ev = (last_upd[i].ev == ln.ev_syrk) ? ln.ev_syrk2 : ln.ev_syrk;
-                if (hipEventRecord(ev, us) != hipSuccess) return SSA_ERR_HIP;
-                prev_upd[i] = last_upd[i];
-                last_upd[i].rstart = rstart;
-                last_upd[i].upto = c;
-                last_upd[i].ev = ev;
+                if (hipEventRecord(ln.ev_syrk, us) != hipSuccess) return SSA_ERR_HIP;
+                updated[i] = true;
             }
             if (!delay) pending_from[i] = k0 + CNB;
             // one early finishing step per outer step once its inputs (panels <= k, which this
@@ -693,6 +834,19 @@ int chol_shutdown() { return destroy_lanes(); }
 extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
     const int64_t np = ceil_div(n, CNB) * CNB;
     return static_cast<size_t>(aux_layout(np).total) * (dtype == SSA_F64 ? 8 : 4);
+}
+
+extern "C" int ssa_chol_chain_stream_costs(double *microseconds, int32_t *pipe_group, int capacity) {
+    std::lock_guard<std::mutex> lock(g_lane_create_mutex);
+    int dev = 0;
+    if (current_device(&dev) != SSA_OK || capacity < 0) return 0;
+    const LaneSet &set = g_lane_sets[dev];
+    if (!set.calibrated) return 0;
+    for (int j = 0; j < kChainPool && j < capacity; ++j) {
+        if (microseconds != nullptr) microseconds[j] = set.chain_us[set.chain_order[j]];
+        if (pipe_group != nullptr) pipe_group[j] = set.chain_pipe[set.chain_order[j]];
+    }
+    return kChainPool;
 }
 
 extern "C" int64_t ssa_chol_padded_n(int64_t n) { return ceil_div(n, CNB) * CNB; }

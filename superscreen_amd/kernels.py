@@ -142,6 +142,18 @@ def chol_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[CholF
     return out
 
 
+def chol_chain_stream_costs() -> Tuple[List[float], List[int]]:
+    """``(microseconds, pipe_group)`` of the panel-chain streams of the current device in the order the
+    factorization schedule uses them (``ssa_chol_chain_stream_costs``): what a dependent launch costs on each beside
+    the caller's stream, and the group of streams it shares a command-processor pipe with (0 = the caller's).
+    Empty before the first factorization."""
+    import ctypes
+
+    us, grp = (ctypes.c_double * 64)(), (ctypes.c_int32 * 64)()
+    k = min(int(load_library().ssa_chol_chain_stream_costs(us, grp, 64)), 64)
+    return [float(us[i]) for i in range(k)], [int(grp[i]) for i in range(k)]
+
+
 def chol_factor(S: torch.Tensor, n: int) -> CholFactors:
     """In-place Cholesky of the symmetric positive definite ``S`` (lower triangle given in the
     leading ``n x n`` part of a ``[chol_padded_n(n), lda >= chol_padded_n(n)]`` buffer)."""

@@ -894,6 +894,38 @@ def test_lu_route_falls_back_to_partial_pivoting(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_chain_streams_are_calibrated():
+    """The panel chains of the Cholesky schedule run on the streams the library measured as cheap to launch on
+    beside the caller's stream (chol.hip calibrate_chain_streams): after a factorization the costs are known, the
+    streams in use come first and are within the limit that separates the two kinds of stream."""
+    import torch
+    from superscreen_amd import kernels
+
+    n = 1500
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((n, n))
+    S_host = M @ M.T + n * np.eye(n)
+    npad = kernels.chol_padded_n(n)
+    S = torch.zeros((npad, npad), dtype=torch.float64, device="cuda")
+    S[:n, :n] = torch.from_numpy(S_host).cuda()
+    f = kernels.chol_factor(S, n)
+    torch.cuda.synchronize()
+    assert int(f.info_device.item()) == 0
+    L = torch.tril(f.L[:n, :n]).cpu().numpy()
+    assert np.abs(L @ L.T - S_host).max() < 1e-9 * np.abs(S_host).max()
+    costs, groups = kernels.chol_chain_stream_costs()
+    assert len(costs) == len(groups) == 16
+    limit = 2.0 * max(min(costs), 0.0) + 12.0
+    for c, g in zip(costs, groups):
+        assert (g == 0) == (c > limit), (costs, groups)     # group 0 = the streams that are slow beside the caller's
+    n_good = sum(g > 0 for g in groups)
+    pipes = max(groups)
+    assert n_good >= 4 and 1 <= pipes <= 8, (costs, groups)
+    assert all(g > 0 for g in groups[:n_good]), (costs, groups)      # the good ones first ...
+    assert sorted(groups[:pipes]) == list(range(1, pipes + 1)), (costs, groups)   # ... one of every pipe to begin with
+
+
+@pytest.mark.gpu
 def test_lu_factor_batch_keeps_cooperative_panels_coresident():
     """The pivoting route's exact sub-panel kernel is cooperative (ceil(n / 256) workgroups of one CU each that
     spin-wait on one another).  Three GENERAL matrices (every sub-panel needs interchanges, so the cooperative

@@ -38,11 +38,11 @@ def analyse(d):
         byq[r["Queue_Id"]].append(r)
     chains = [(q, rs) for q, rs in byq.items() if any("chol_diag256" in r["Kernel_Name"] for r in rs)]
     chains.sort(key=lambda kv: -len(kv[1]))
-    q, rs = chains[0]
-    diag = [i for i, r in enumerate(rs) if "chol_diag256" in r["Kernel_Name"]]
-    print(f"chain queue {q}: {len(diag)} panels; factorization span {(rows[-1]['e'] - t0) / 1e6:.1f} ms")
-    short = {"chol_diag256": "diag", "gemm_op_kernel": "gemm"}
-    for n, i in enumerate(diag[:-1]):
+    short = {"chol_diag256": "diag", "gemm_op_kernel": "gemm", "gemm_nt_small": "small"}
+    for q, rs in chains:
+      diag = [i for i, r in enumerate(rs) if "chol_diag256" in r["Kernel_Name"]]
+      print(f"chain queue {q}: {len(diag)} panels; factorization span {(rows[-1]['e'] - t0) / 1e6:.1f} ms")
+      for n, i in enumerate(diag[:-1]):
         if not (n % 8 == 0 or n >= len(diag) - 6):
             continue
         j = diag[n + 1]
@@ -57,6 +57,24 @@ def analyse(d):
     if syrk:
         busy = sum(r["e"] - r["s"] for r in syrk)
         print(f"SYRK launches {len(syrk)}, busy {busy / 1e6:.1f} ms, first {(syrk[0]['s'] - t0) / 1e6:.1f}, last end {(syrk[-1]['e'] - t0) / 1e6:.1f} ms")
+        uq = syrk[0]["Queue_Id"]
+        span = rows[-1]["e"] - t0
+        win = 5_000_000
+        line = []
+        for w0 in range(0, span, win):
+            b = sum(max(0, min(r["e"] - t0, w0 + win) - max(r["s"] - t0, w0)) for r in byq[uq])
+            line.append(f"{100 * b / min(win, span - w0):.0f}")
+        print(f"update queue {uq} busy % per 5 ms window: " + " ".join(line))
+        other = collections.defaultdict(lambda: [0, 0, 0])
+        for r in byq[uq]:
+            if r in syrk:
+                continue
+            o = other[r["Kernel_Name"][:70]]
+            o[0] += 1
+            o[1] += r["e"] - r["s"]
+            o[2] += (r["e"] - r["s"]) if r["s"] >= syrk[-1]["e"] else 0
+        for k, o in sorted(other.items(), key=lambda kv: -kv[1][1]):
+            print(f"  update queue, not SYRK: {o[0]:4d} x {k:70s} {o[1] / 1e6:6.2f} ms ({o[2] / 1e6:.2f} ms after the last SYRK)")
 
 
 if __name__ == "__main__":
