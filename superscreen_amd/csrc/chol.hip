@@ -378,19 +378,24 @@ inline int calibrate_chain_streams(LaneSet &set, hipStream_t st) {
     }
     for (int j = 0; j < kChainPool; ++j)
         if (set.chain_pipe[j] < 0) set.chain_pipe[j] = pipes;   // (more than 8 groups: not a real device; keep going)
+    // order of use: round r takes the cheapest unused stream of every pipe (cheapest pipe first); the streams on the
+    // caller's pipe come last
+    int by_cost[kChainPool];
+    for (int j = 0; j < kChainPool; ++j) by_cost[j] = j;
+    std::stable_sort(by_cost, by_cost + kChainPool, [&set](int a, int b) { return set.chain_us[a] < set.chain_us[b]; });
     int m = 0;
     bool used[kChainPool] = {};
-    for (int round = 0; round < kChainPool && m < kChainPool; ++round)      // round r: the r-th stream of every pipe
-        for (int g = 1; g <= pipes; ++g) {
-            int seen = 0;
-            for (int j = 0; j < kChainPool; ++j)
-                if (set.chain_pipe[j] == g && !used[j] && seen++ == 0) {
-                    used[j] = true;
-                    set.chain_order[m++] = j;
-                }
+    for (int round = 0; round < kChainPool && m < kChainPool; ++round) {
+        bool pipe_taken[kChainPool + 1] = {};
+        for (int q = 0; q < kChainPool; ++q) {
+            const int j = by_cost[q], g = set.chain_pipe[j];
+            if (used[j] || g == 0 || pipe_taken[g]) continue;
+            used[j] = pipe_taken[g] = true;
+            set.chain_order[m++] = j;
         }
-    for (int j = 0; j < kChainPool; ++j)
-        if (!used[j]) set.chain_order[m++] = j;
+    }
+    for (int q = 0; q < kChainPool; ++q)
+        if (!used[by_cost[q]]) set.chain_order[m++] = by_cost[q];
     for (int i = 0; i < kMaxLanes; ++i) set.lanes[i].side = set.chain_pool[set.chain_order[i % kChainPool]];
     set.calibrated = true;
     set.calibrated_for = st;

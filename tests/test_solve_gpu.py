@@ -922,7 +922,9 @@ def test_chain_streams_are_calibrated():
     pipes = max(groups)
     assert n_good >= 4 and 1 <= pipes <= 8, (costs, groups)
     assert all(g > 0 for g in groups[:n_good]), (costs, groups)      # the good ones first ...
-    assert sorted(groups[:pipes]) == list(range(1, pipes + 1)), (costs, groups)   # ... one of every pipe to begin with
+    assert sorted(groups[:pipes]) == list(range(1, pipes + 1)), (costs, groups)   # ... one of every pipe to begin with,
+    assert costs[:pipes] == sorted(costs[:pipes]), (costs, groups)                # the cheapest pipe first
+    assert costs[0] == min(costs), (costs, groups)
 
 
 @pytest.mark.gpu
