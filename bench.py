@@ -747,7 +747,7 @@ def main():
         fact_flops = sum(u ** 3 / 3.0 for u in unknowns) if used_chol else sum(2.0 * u ** 3 / 3.0 for u in unknowns)
         extras["factorization_ms"] = t_fact * 1e3
         # what a dependent launch costs on the panel-chain streams the schedule uses, as the library measured them on
-        # this device against the caller's stream (chol.hip calibrate_chain_streams); the first entries are the
+        # this device against the caller's stream (chain_streams.hip); the first entries are the
         # ones in use
         chain_us, chain_pipe = kernels.chol_chain_stream_costs()
         extras["chain_stream_dependent_launch_us"] = [round(v, 1) for v in chain_us]

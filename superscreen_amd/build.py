@@ -23,7 +23,7 @@ OBJDIR = os.path.join(PKG, "build")
 LIBNAME = "libsuperscreen_hip.so"
 ARCH = "gfx950"
 SOURCES = ["capi.hip", "assemble.hip", "pairwise.hip", "pairwise_multi.hip", "blas1.hip", "gemm.hip", "gemm_ops.hip",
-           "lu.hip", "chol.hip", "collective.hip"]
+           "lu.hip", "chol.hip", "chain_streams.hip", "collective.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 

@@ -6,6 +6,7 @@
 namespace ssa {
 int chol_shutdown();
 int lu_shutdown();
+int chain_streams_shutdown();
 }
 
 extern "C" int ssa_abi_version(void) { return SSA_ABI_VERSION; }
@@ -40,6 +41,7 @@ extern "C" int ssa_device_info(int *num_cus, size_t *hbm_bytes, char *arch_name,
 extern "C" int ssa_shutdown(void) {
     const int a = ssa::chol_shutdown();
     const int c = ssa::lu_shutdown();
+    const int d = ssa::chain_streams_shutdown();   // after the schedules that use the chain streams
     const int b = ssa::profile_shutdown();
-    return a != SSA_OK ? a : (c != SSA_OK ? c : b);
+    return a != SSA_OK ? a : (c != SSA_OK ? c : (d != SSA_OK ? d : b));
 }

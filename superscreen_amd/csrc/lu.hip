@@ -29,6 +29,7 @@
 #include <mutex>
 #include <utility>
 
+#include "chain_streams.hpp"
 #include "common.hpp"
 #include "lu_diag.hpp"
 
@@ -833,15 +834,16 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 // returns ipiv == arange for them.  Without interchanges the factorization has the structure of the
 // Cholesky route (chol.hip) and takes the same schedule:
 //
-//   per matrix and 256-column panel k (two high-priority chain streams, one update stream):
-//   chain 1   diagonal block  C[0:256, 0:256] -= L21p[0:256] U12p[:, 0:256]     (pending panels p, K = 256 / 512)
+//   per matrix and 256-column panel k (one high-priority chain stream, one update stream):
+//   chain     block column  C[:, 0:256] -= L21p U12p[:, 0:256]  and block row  C[0:256, 256:] -= L21p[0:256] U12p[:, 256:]
+//                           (pending panels p, K = 256 / 512)
 //             diagonal block: L11 \ U11 in place, WL = inv(L11), WU = inv(U11)  (lu_diag256_kernel, lu_diag.hpp:
 //                             one workgroup, 64-column Gaussian eliminations in registers + MFMA block products)
-//             first block row of L21 = A21 WU, first block column of U12 = WL A12   (all the next diagonal block needs)
-//   chain 2   column strip  C[256:, 0:256] -= L21p[256:] U12p[:, 0:256],  row strip  C[0:256, 256:] -= ...
-//             rest of L21 = A21 WU and of U12 = WL A12   (two in-place MFMA GEMMs each; one step behind chain 1)
+//             L21 = A21 WU and U12 = WL A12   (two in-place MFMA GEMMs each)
 //   update    rest  C[256:, 256:] -= L21p U12p   (every other panel with K = 512 for large trailing matrices)
 //
+// The chain is ONE stream per matrix, one of the device's measured chain streams (chain_streams.hpp), as in the
+// Cholesky schedule (chol.hip potrf_batch); rounds 2 and 3 ran it as two streams with hand-offs.
 // i.e. panel k + 1 is factored while the rest of update k runs (look-ahead), the matrices of a batch hide
 // each other's chains, and the trailing update is one NN GEMM.  What makes the result LAPACK's: partial
 // pivoting keeps the diagonal at column J iff no multiplier below it exceeds 1 in magnitude (|a_rJ| <=
@@ -850,9 +852,8 @@ int trtri_lower_blocks(const T *A, int64_t lda, int64_t n, T *inv, hipStream_t s
 // as info = -2 and the caller factors the matrix again with ssa_lu_factor (full partial pivoting).
 constexpr int kMaxLuLanes = 16;
 struct LuLane {
-    hipStream_t side = nullptr, side2 = nullptr, upd = nullptr, fin = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr, ev_fin = nullptr,
-               ev_diag = nullptr, ev_top = nullptr, ev_below = nullptr;
+    hipStream_t side = nullptr, upd = nullptr, fin = nullptr;   // side: a chain stream of the device (not owned)
+    hipEvent_t ev_fork = nullptr, ev_panel = nullptr, ev_rest = nullptr, ev_upd = nullptr, ev_fin = nullptr;
 };
 struct LuLaneSet {
     LuLane lanes[kMaxLuLanes];
@@ -869,13 +870,8 @@ inline int get_lu_lanes(int count, LuLaneSet **out) {
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return SSA_ERR_HIP;
     LuLane *lanes = g_lu_lane_sets[dev].lanes;
     for (int i = 0; i < count; ++i) {
-        if (lanes[i].side != nullptr) continue;
-        if (hipStreamCreateWithPriority(&lanes[i].side, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&lanes[i].side2, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_diag, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_top, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&lanes[i].ev_below, hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
+        if (lanes[i].upd != nullptr) continue;
+        if (hipStreamCreateWithPriority(&lanes[i].upd, hipStreamNonBlocking, 0) != hipSuccess ||
             hipStreamCreateWithPriority(&lanes[i].fin, hipStreamNonBlocking, lo) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fin, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -884,6 +880,15 @@ inline int get_lu_lanes(int count, LuLaneSet **out) {
             hipEventCreateWithFlags(&lanes[i].ev_upd, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
+    // the chains run on the device's chain streams, in the order measured against the stream of the trailing updates
+    // (the first lane's update stream: two matrices share it, more have one each)
+    hipStream_t chains[kMaxLuLanes];
+    {
+        std::lock_guard<std::mutex> enq(g_lu_lane_sets[dev].enqueue);
+        const int rc = chain_streams_get(lanes[0].upd, kMaxLuLanes, chains);
+        if (rc != SSA_OK) return rc;
+    }
+    for (int i = 0; i < kMaxLuLanes; ++i) lanes[i].side = chains[i];
     *out = &g_lu_lane_sets[dev];
     return SSA_OK;
 }
@@ -894,16 +899,12 @@ int lu_shutdown() {
     for (int d = 0; d < kMaxDevices; ++d) {
         std::lock_guard<std::mutex> enq(g_lu_lane_sets[d].enqueue);
         for (LuLane &ln : g_lu_lane_sets[d].lanes) {
-            if (ln.side == nullptr) continue;
-            if (hipStreamSynchronize(ln.side) != hipSuccess || hipStreamSynchronize(ln.side2) != hipSuccess ||
-                hipStreamSynchronize(ln.upd) != hipSuccess || hipStreamSynchronize(ln.fin) != hipSuccess)
-                rc = SSA_ERR_HIP;
-            hipEvent_t evs[8] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd, ln.ev_fin, ln.ev_diag, ln.ev_top, ln.ev_below};
+            if (ln.upd == nullptr) continue;
+            if (hipStreamSynchronize(ln.upd) != hipSuccess || hipStreamSynchronize(ln.fin) != hipSuccess) rc = SSA_ERR_HIP;
+            hipEvent_t evs[5] = {ln.ev_fork, ln.ev_panel, ln.ev_rest, ln.ev_upd, ln.ev_fin};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-            if (hipStreamDestroy(ln.side) != hipSuccess || hipStreamDestroy(ln.side2) != hipSuccess ||
-                hipStreamDestroy(ln.upd) != hipSuccess || hipStreamDestroy(ln.fin) != hipSuccess)
-                rc = SSA_ERR_HIP;
+            if (hipStreamDestroy(ln.upd) != hipSuccess || hipStreamDestroy(ln.fin) != hipSuccess) rc = SSA_ERR_HIP;
             ln = LuLane{};
         }
     }
@@ -1029,27 +1030,17 @@ int np_cols(const NpJob<T> &J, int64_t k0, int64_t c0, int64_t c1, hipStream_t s
     if (rc != SSA_OK) return rc;
     return gemm_t<T>(128, M, 128, 1.0, WL, LSB, A12, lda, 0.0, A12, lda, s);
 }
-// panel k0 on the two chain streams of a lane: diagonal kernel and the first block row / column on ln.side (what the
-// next diagonal block needs), the rest of the panel on ln.side2; ev_panel = all of it
+// panel k0 on the chain stream of a lane: diagonal-block kernel, then L21 and U12; ev_panel = all of it
 template <typename T>
-int np_panel_two_streams(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, LuLane &ln, bool wait_below) {
-    const int64_t kend = k0 + NB, top = std::min<int64_t>(kend + NB, J.np);
+int np_panel(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, LuLane &ln) {
+    const int64_t kend = k0 + NB;
     int rc = np_diag(J, S, k0, ln.side);
     if (rc != SSA_OK) return rc;
-    if (hipEventRecord(ln.ev_diag, ln.side) != hipSuccess) return SSA_ERR_HIP;
-    if (wait_below && hipStreamWaitEvent(ln.side, ln.ev_below, 0) != hipSuccess) return SSA_ERR_HIP;
-    rc = np_rows(J, k0, kend, top, ln.side);
+    rc = np_rows(J, k0, kend, J.np, ln.side);
     if (rc != SSA_OK) return rc;
-    rc = np_cols(J, k0, kend, top, ln.side);
+    rc = np_cols(J, k0, kend, J.np, ln.side);
     if (rc != SSA_OK) return rc;
-    if (hipEventRecord(ln.ev_top, ln.side) != hipSuccess || hipStreamWaitEvent(ln.side2, ln.ev_diag, 0) != hipSuccess)
-        return SSA_ERR_HIP;
-    rc = np_rows(J, k0, top, J.np, ln.side2);
-    if (rc != SSA_OK) return rc;
-    rc = np_cols(J, k0, top, J.np, ln.side2);
-    if (rc != SSA_OK) return rc;
-    if (hipStreamWaitEvent(ln.side2, ln.ev_top, 0) != hipSuccess || hipEventRecord(ln.ev_panel, ln.side2) != hipSuccess)
-        return SSA_ERR_HIP;
+    if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
     return SSA_OK;
 }
 
@@ -1089,10 +1080,9 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             hipMemsetAsync(J.aux, 0, static_cast<size_t>(lu_aux_layout(J.n).tmp) * sizeof(T), st) != hipSuccess)
             return SSA_ERR_HIP;
         if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.side, ln.ev_fork, 0) != hipSuccess ||
-            hipStreamWaitEvent(ln.side2, ln.ev_fork, 0) != hipSuccess ||
             hipStreamWaitEvent(us, ln.ev_fork, 0) != hipSuccess)
             return SSA_ERR_HIP;
-        rc = np_panel_two_streams(J, scratch[i], 0, ln, false);
+        rc = np_panel(J, scratch[i], 0, ln);
         if (rc != SSA_OK) return rc;
     }
     constexpr int kDelayDepth = 2;            // as in the Cholesky schedule: two panels per trailing update
@@ -1114,25 +1104,17 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
             const T *PU = J.A + pend0 * J.lda + (k0 + NB);   // pending U panels, columns of the trailing matrix
             T *C = J.A + (k0 + NB) * (J.lda + 1);
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;   // panel k done
-            // The chain of a matrix is two streams (diagonal look-ahead, as in chol.hip): the next diagonal block
-            // needs only the first block row and column of a panel, so
-            //     diagonal block update (256 x 256 x kp) -> diagonal-block kernel -> first block row / column
-            // is the critical recurrence on ln.side, while ln.side2 applies the pending panels to the rest of the
-            // two strips and computes the rest of the panel one step behind.  Both wait for this matrix' last rest
-            // update (it wrote the strips' entries).
-            if (right > nw) {
-                if (rest_recorded[i] && hipStreamWaitEvent(ln.side2, ln.ev_rest, 0) != hipSuccess) return SSA_ERR_HIP;
-                rc = gemm_t<T>(right - nw, nw, kp, -1.0, PL + nw * J.lda, J.lda, PU, J.lda, 1.0, C + nw * J.lda, J.lda,
-                               ln.side2);
-                if (rc != SSA_OK) return rc;
-                rc = gemm_t<T>(nw, right - nw, kp, -1.0, PL, J.lda, PU + nw, J.lda, 1.0, C + nw, J.lda, ln.side2);
-                if (rc != SSA_OK) return rc;
-                if (hipEventRecord(ln.ev_below, ln.side2) != hipSuccess) return SSA_ERR_HIP;
-            }
+            // the chain: pending panels onto the next block column (diagonal block included) and onto the block row
+            // right of the diagonal block, behind this matrix' last rest update (it wrote those entries); then the
+            // panel
             if (rest_recorded[i] && hipStreamWaitEvent(ln.side, ln.ev_rest, 0) != hipSuccess) return SSA_ERR_HIP;
-            rc = gemm_t<T>(nw, nw, kp, -1.0, PL, J.lda, PU, J.lda, 1.0, C, J.lda, ln.side);
+            rc = gemm_t<T>(right, nw, kp, -1.0, PL, J.lda, PU, J.lda, 1.0, C, J.lda, ln.side);
             if (rc != SSA_OK) return rc;
-            rc = np_panel_two_streams(J, scratch[i], k0 + NB, ln, right > nw);
+            if (right > nw) {
+                rc = gemm_t<T>(nw, right - nw, kp, -1.0, PL, J.lda, PU + nw, J.lda, 1.0, C + nw, J.lda, ln.side);
+                if (rc != SSA_OK) return rc;
+            }
+            rc = np_panel(J, scratch[i], k0 + NB, ln);
             if (rc != SSA_OK) return rc;
             const bool delay = kp < kDelayDepth * NB && right > kDelayMinCols &&
                                ((k0 + J.np) / NB) % kDelayDepth != kDelayDepth - 1;

@@ -895,8 +895,8 @@ def test_lu_route_falls_back_to_partial_pivoting(monkeypatch):
 
 @pytest.mark.gpu
 def test_chain_streams_are_calibrated():
-    """The panel chains of the Cholesky schedule run on the streams the library measured as cheap to launch on
-    beside the caller's stream (chol.hip calibrate_chain_streams): after a factorization the costs are known, the
+    """The panel chains of the factorization schedules run on the streams the library measured as cheap to launch on
+    beside the stream of the trailing updates (chain_streams.hip): after a factorization the costs are known, the
     streams in use come first and are within the limit that separates the two kinds of stream."""
     import torch
     from superscreen_amd import kernels
@@ -920,7 +920,7 @@ def test_chain_streams_are_calibrated():
         assert (g == 0) == (c > limit), (costs, groups)     # group 0 = the streams that are slow beside the caller's
     n_good = sum(g > 0 for g in groups)
     pipes = max(groups)
-    assert n_good >= 4 and 1 <= pipes <= 8, (costs, groups)
+    assert n_good >= 2 and 1 <= pipes <= 8, (costs, groups)   # (12 of 16 with 4 hardware queues per priority, 3 with 8)
     assert all(g > 0 for g in groups[:n_good]), (costs, groups)      # the good ones first ...
     assert sorted(groups[:pipes]) == list(range(1, pipes + 1)), (costs, groups)   # ... one of every pipe to begin with,
     assert costs[:pipes] == sorted(costs[:pipes]), (costs, groups)                # the cheapest pipe first
