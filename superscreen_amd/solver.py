@@ -121,6 +121,15 @@ def _sites_in_polygon(mesh, polygon) -> np.ndarray:
     return cache[key]
 
 
+def _index_setdiff(a, b, n: int) -> np.ndarray:
+    """``np.setdiff1d(a, b)`` for index arrays into ``range(n)`` (sorted, unique) without its sorts: a cold step
+    calls this a few times per film before its first kernel can be launched."""
+    keep = np.zeros(n, dtype=bool)
+    keep[np.asarray(a, dtype=np.int64)] = True
+    keep[np.asarray(b, dtype=np.int64)] = False
+    return np.flatnonzero(keep)
+
+
 def make_film_info(*, device: Device, vortices: Sequence[Vortex],
                    circulating_currents: Dict[str, float],
                    terminal_currents: Dict[str, Dict[str, float]]) -> Dict[str, FilmInfo]:
@@ -156,14 +165,17 @@ def make_film_info(*, device: Device, vortices: Sequence[Vortex],
             boundary = device.boundary_vertices(name)  # ordered, solver/utils.py:298-299
         else:
             boundary = mesh.boundary_indices
-        interior = np.setdiff1d(_sites_in_polygon(mesh, film), boundary)
+        interior = _index_setdiff(_sites_in_polygon(mesh, film), boundary, len(mesh.sites))
         film_info[name] = FilmInfo(
             name=name, layer=layer.name, lambda_info=lambda_info,
             vortices=tuple(vortices_by_film[name]), interior_indices=interior,
             boundary_indices=boundary, hole_indices=hole_indices, in_hole=in_hole,
             circulating_currents=circ, terminal_currents=terminal_currents.get(name),
             weights=mesh.operators.weights.astype(dtype, copy=False),
-            laplacian=mesh.operators.laplacian.astype(dtype), z0=float(layer.z0),
+            # (the mesh's own matrix when the dtype already matches: read-only here, as in the reference)
+            laplacian=(mesh.operators.laplacian if mesh.operators.laplacian.dtype == dtype
+                       else mesh.operators.laplacian.astype(dtype)),
+            z0=float(layer.z0),
         )
     return film_info
 
@@ -411,9 +423,9 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
         for role, interior in targets:
             if role == "film":
                 if info.hole_indices:  # solve_film.py:269-272
-                    interior = np.setdiff1d(interior, np.concatenate(list(info.hole_indices.values())))
+                    interior = _index_setdiff(interior, np.concatenate(list(info.hole_indices.values())), fd.n)
                 if name in device.terminals:
-                    interior = np.setdiff1d(interior, info.boundary_indices)  # :273-274
+                    interior = _index_setdiff(interior, info.boundary_indices, fd.n)  # :273-274
             ix_d = _h2d(interior.astype(np.int64), dev)
             ni = len(interior)
 
@@ -1114,19 +1126,22 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                 logger.debug(f"iteration {it + 1}: relative change {change:.3e}")
                 if change < tolerance:
                     break
+        # (the multi-vector launches go out before the host unpacks the last iterate: they run meanwhile)
+        patch = _enqueue_exterior_self_fields(model, deferred) if batch_exterior else None
         if keep:
             package(pending)
-        if batch_exterior:
-            _patch_exterior_self_fields(model, deferred, solutions, conv)
+        if patch is not None:
+            _patch_exterior_self_fields(model, patch, solutions, conv)
     finally:
         close_file()
     return solutions if return_solutions else None
 
 
-def _patch_exterior_self_fields(model: FactorizedModel, deferred, solutions: List[Solution], conv: float) -> None:
+def _enqueue_exterior_self_fields(model: FactorizedModel, deferred):
     """The all-pairs part of the self field (``Q @ (w * g)`` on the rows that are not unknowns,
-    ``solver/solve_film.py:565``) of every iterate in ``deferred`` in one multi-vector launch per film, written
-    into ``solutions[k].film_solutions[name].self_field`` (pass k = ``deferred[k]`` = ``solutions[k]``)."""
+    ``solver/solve_film.py:565``) of every iterate in ``deferred`` in one multi-vector launch per film, with the
+    device-to-host copies of the results behind them (pass k = ``deferred[k]``).  Returns what
+    ``_patch_exterior_self_fields`` needs."""
     import torch
 
     from . import kernels
@@ -1143,16 +1158,24 @@ def _patch_exterior_self_fields(model: FactorizedModel, deferred, solutions: Lis
         vals = out.index_select(0, rows)                                                  # [rows, passes]
         host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
         host.copy_(vals, non_blocking=True)
-        staged.append((name, passes, rows, host))
+        staged.append((name, passes, rows.numel(), host))
     done = torch.cuda.Event()
     done.record()
+    return staged, done
+
+
+def _patch_exterior_self_fields(model: FactorizedModel, patch, solutions: List[Solution], conv: float) -> None:
+    """Writes the rows computed by ``_enqueue_exterior_self_fields`` into
+    ``solutions[k].film_solutions[name].self_field`` (pass k = ``solutions[k]``)."""
+    staged, done = patch
     rows_h = {}
-    for name, _, rows, _ in staged:   # the same rows on the host (mesh-only data: kept with the system)
+    for name, _, nrows, _ in staged:   # the same rows on the host (mesh-only data: kept with the system)
         system = model.film_systems[name]
         ext = system.__dict__.get("_exterior_host")
-        if ext is None or len(ext) != rows.numel():
-            ext = system.__dict__["_exterior_host"] = np.setdiff1d(
-                np.arange(model.film_data[name].n, dtype=np.int64), system.indices)
+        if ext is None or len(ext) != nrows:
+            mask = np.ones(model.film_data[name].n, dtype=bool)
+            mask[system.indices] = False
+            ext = system.__dict__["_exterior_host"] = np.flatnonzero(mask)
         rows_h[name] = ext
     done.synchronize()
     for name, passes, _, host in staged:
