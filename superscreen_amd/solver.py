@@ -238,6 +238,13 @@ class FilmDeviceData:
         self.lap, self.grad = geo["lap"], geo["grad"]
         self.Lambda = put(info.lambda_info.Lambda[:, 0].astype(np.float64))
         self._geo = geo
+        # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
+        # unless the dense Q is wanted for the self-field GEMV.  (Launched before the host work below: the row sums
+        # are the first kernel of a cold step.)
+        if geometry_only:  # a film owned by another rank: only a coupling source / target geometry
+            self.Q = self.qdiag = None
+        else:
+            self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, geo["C"], dtype, want_Q=store_Q)
         # Index range of the vertices that can carry a sheet current: g lives on the interior and hole
         # vertices (plus the boundary of a film with terminals), J = curl(g z) on those and their mesh
         # neighbours.  Vertices outside the range are exact zeros in every coupling sum and are skipped
@@ -254,12 +261,6 @@ class FilmDeviceData:
         carries = support | ((pattern @ support.astype(np.float64)) > 0)
         self.src_range = (int(np.argmax(carries)), int(self.n - np.argmax(carries[::-1]))) if carries.any() \
             else (0, self.n)
-        if geometry_only:  # a film owned by another rank: only a coupling source / target geometry
-            self.Q = self.qdiag = None
-            return
-        # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
-        # unless the dense Q is wanted for the self-field GEMV.
-        self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, geo["C"], dtype, want_Q=store_Q)
 
     def triangle_data(self, mesh):
         """Per-triangle operators of films with terminals (centroids, areas, triangle gradient CSR
@@ -972,6 +973,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
 
     if log_level is not None:
         logging.basicConfig(level=log_level)
+
     if model is None:
         if device is None:
             raise ValueError("Either a model or a device must be provided.")
