@@ -1035,6 +1035,7 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     # spread over ranks (the owners' vectors travel after every pass).
     batch_exterior = return_solutions and save_path is None and placement is None and len(films) >= 2 and iterations >= 1
     deferred: List[Dict[str, _DeviceFilmResult]] = []   # one entry per pass: the results with missing rows
+    coupling_sources: List[Dict[str, object]] = []      # one entry per iteration: the sheet currents it started from
 
     def run_pass(other_d):
         results = {}
@@ -1107,6 +1108,30 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                                          device=model.film_data[name].device) for name in films}
             if coupling is not None:
                 coupling.accumulate(model, results, other_d)
+            elif batch_exterior:
+                # The iteration reads the coupling field only on the rows that are unknowns (h = Hz[indices] - ...,
+                # solve_film.py:526-529); the other rows only go into the returned Solutions.  Per pass the
+                # all-pairs sums run over the unknowns' rows (a compact copy of their coordinates); the remaining
+                # rows of ALL passes are evaluated in one multi-vector launch per film pair after the last pass.
+                coupling_sources.append({name: results[name].J for name in films})
+                for tgt in films:
+                    t = model.film_data[tgt]
+                    rows = model.film_systems[tgt].indices_device
+                    if rows is None or rows.numel() == 0:
+                        continue
+                    cache = model.film_systems[tgt].__dict__
+                    xy_rows = cache.get("_xy_rows")
+                    if xy_rows is None:
+                        xy_rows = cache["_xy_rows"] = t.xy.index_select(0, rows).contiguous()
+                    compact = torch.zeros(rows.numel(), dtype=t.tdtype, device=t.device)
+                    for src in films:
+                        if src == tgt:
+                            continue
+                        s = model.film_data[src]
+                        kernels.biot_savart(s.xy, s.w_t, results[src].J, xy_rows,
+                                            film_info[tgt].z0 - film_info[src].z0, compact,
+                                            accumulate=True, src_begin=s.src_range[0], src_end=s.src_range[1])
+                    other_d[tgt].index_copy_(0, rows, compact)
             else:
                 for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
                     if src == tgt or tgt not in mine:  # owner-computes: only this rank's target films
@@ -1130,10 +1155,13 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                     break
         # (the multi-vector launches go out before the host unpacks the last iterate: they run meanwhile)
         patch = _enqueue_exterior_self_fields(model, deferred) if batch_exterior else None
+        patch_c = _enqueue_exterior_coupling(model, coupling_sources) if (batch_exterior and coupling_sources) else None
         if keep:
             package(pending)
         if patch is not None:
             _patch_exterior_self_fields(model, patch, solutions, conv)
+        if patch_c is not None:
+            _patch_exterior_coupling(model, patch_c, solutions, conv)
     finally:
         close_file()
     return solutions if return_solutions else None
@@ -1166,19 +1194,72 @@ def _enqueue_exterior_self_fields(model: FactorizedModel, deferred):
     return staged, done
 
 
+def _exterior_rows_host(model: FactorizedModel, name: str) -> np.ndarray:
+    """The mesh rows of film ``name`` that are not unknowns of its system (mesh-only data: kept with the system)."""
+    system = model.film_systems[name]
+    ext = system.__dict__.get("_exterior_host")
+    if ext is None:
+        mask = np.ones(model.film_data[name].n, dtype=bool)
+        mask[system.indices] = False
+        ext = system.__dict__["_exterior_host"] = np.flatnonzero(mask)
+    return ext
+
+
+def _enqueue_exterior_coupling(model: FactorizedModel, coupling_sources):
+    """The field from the other films (``solver/solve.py:499-515``) on the rows that are NOT unknowns, for every
+    iteration in ``coupling_sources`` (iteration k started from the sheet currents ``coupling_sources[k]``) in one
+    multi-vector launch per ordered film pair, with the device-to-host copies behind them."""
+    import torch
+
+    from . import kernels
+
+    films = list(coupling_sources[0])
+    nvec = len(coupling_sources)
+    staged = []
+    for tgt in films:
+        t = model.film_data[tgt]
+        ext = _exterior_rows_host(model, tgt)
+        if len(ext) == 0:
+            continue
+        system = model.film_systems[tgt]
+        rows = system.exterior_device
+        if rows is None:
+            rows = system.exterior_device = torch.from_numpy(ext).to(t.device)
+        out = torch.zeros((t.n, nvec), dtype=t.tdtype, device=t.device)
+        for src in films:
+            if src == tgt:
+                continue
+            s = model.film_data[src]
+            b, e = s.src_range
+            J = torch.stack([coupling_sources[k][src][b:e] for k in range(nvec)], dim=1).contiguous()   # [ns, nvec, 2]
+            kernels.biot_savart_multi(s.xy[b:e], s.w_t[b:e], J, t.xy, model.film_info[tgt].z0 - model.film_info[src].z0,
+                                      out, accumulate=True, rows=rows)
+        vals = out.index_select(0, rows)
+        host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+        host.copy_(vals, non_blocking=True)
+        staged.append((tgt, ext, host))
+    done = torch.cuda.Event()
+    done.record()
+    return staged, done
+
+
+def _patch_exterior_coupling(model: FactorizedModel, patch, solutions: List[Solution], conv: float) -> None:
+    """Writes the rows computed by ``_enqueue_exterior_coupling`` into
+    ``solutions[k + 1].film_solutions[name].field_from_other_films`` (iteration k produced Solution k + 1)."""
+    staged, done = patch
+    done.synchronize()
+    for name, ext, host in staged:
+        vals = host.numpy() / conv
+        for k in range(vals.shape[1]):
+            if k + 1 < len(solutions):
+                solutions[k + 1].film_solutions[name].field_from_other_films[ext] = vals[:, k]
+
+
 def _patch_exterior_self_fields(model: FactorizedModel, patch, solutions: List[Solution], conv: float) -> None:
     """Writes the rows computed by ``_enqueue_exterior_self_fields`` into
     ``solutions[k].film_solutions[name].self_field`` (pass k = ``solutions[k]``)."""
     staged, done = patch
-    rows_h = {}
-    for name, _, nrows, _ in staged:   # the same rows on the host (mesh-only data: kept with the system)
-        system = model.film_systems[name]
-        ext = system.__dict__.get("_exterior_host")
-        if ext is None or len(ext) != nrows:
-            mask = np.ones(model.film_data[name].n, dtype=bool)
-            mask[system.indices] = False
-            ext = system.__dict__["_exterior_host"] = np.flatnonzero(mask)
-        rows_h[name] = ext
+    rows_h = {name: _exterior_rows_host(model, name) for name, _, _, _ in staged}
     done.synchronize()
     for name, passes, _, host in staged:
         vals = host.numpy() / conv
