@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 3
+#define SSA_ABI_VERSION 4
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);
@@ -173,6 +173,15 @@ int ssa_chol_factor_batch(int count, void *const *S, const int64_t *n, const int
 size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
 int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
                    int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* ssa_chol_solve_batch: `count` single-right-hand-side solves L_i L_i^T x_i = b_i (the films of a device in one
+ * pass of the Jacobi loop, solver/solve.py:517-536 - they are independent of each other) in lockstep: every block
+ * step of all solves is one launch, so that the short launches of the triangular GEMV chain (a 4096-row inverse
+ * block, a film's last block column) run side by side in one grid.  L, n, lda, aux, B, workspace, workspace_bytes:
+ * HOST arrays of `count` entries with the arguments of ssa_chol_solve for nrhs = 1, ldb = 1 (workspace_bytes[i] >=
+ * ssa_chol_solve_workspace_bytes(n[i], 1, dtype)).  Results bit-identical to `count` ssa_chol_solve calls. */
+int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
+                         const void *const *aux, void *const *B, int dtype, void *const *workspace,
+                         const size_t *workspace_bytes, void *stream);
 /*
  * Diagnostics of the factorization schedule (no reference counterpart).  The panel chains run on internal
  * high-priority streams; which hardware queue / command-processor pipe the runtime gives a stream decides what a

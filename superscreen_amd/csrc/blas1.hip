@@ -32,19 +32,20 @@ struct Vec16<float> {
     static constexpr int N = 4;
 };
 
+// (explicit fused multiply-adds: left to the compiler's contraction, the float32 sums of two instantiations of the
+// same loop differed in the last bit - packed multiplies and adds in one, fused in the other)
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // TRI = 1 / 2: M is lower / upper triangular (zero on the other side); a wave then only streams
 // the columns up to / from the diagonal of its rows (whole vectors: the extra elements are zeros).
-template <typename T, int ROWS, bool VECTOR, int TRI = 0>
-__global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int64_t nr,
-                                                   int64_t nc, int64_t ldm,
-                                                   const T *__restrict__ x,
-                                                   const T *__restrict__ xscale,
-                                                   const int64_t *__restrict__ xidx,
-                                                   T *__restrict__ y, T alpha, T beta) {
+// The rows [row0, row0 + ROWS) of one wave:
+template <typename T, int ROWS, bool VECTOR, int TRI>
+__device__ __forceinline__ void gemv_wave_rows(const T *__restrict__ M, int64_t nr, int64_t nc, int64_t ldm,
+                                               const T *__restrict__ x, const T *__restrict__ xscale,
+                                               const int64_t *__restrict__ xidx, T *__restrict__ y, T alpha, T beta,
+                                               int64_t row0, int lane) {
     constexpr int VN = VECTOR ? Vec16<T>::N : 1;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * ROWS;
     if (row0 >= nr) return;
     T acc[ROWS];
 #pragma unroll
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int6
                 const V mv = *reinterpret_cast<const V *>(rowp[r] + c);
                 const T *mp = reinterpret_cast<const T *>(&mv);
 #pragma unroll
-                for (int k = 0; k < VN; ++k) acc[r] += mp[k] * xv[k];
+                for (int k = 0; k < VN; ++k) acc[r] = fma_t(mp[k], xv[k], acc[r]);
             }
         }
     }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int6
         T v = x[xidx ? xidx[c] : c];
         if (xscale) v *= xscale[c];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] += rowp[r][c] * v;
+        for (int r = 0; r < ROWS; ++r) acc[r] = fma_t(rowp[r][c], v, acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -95,6 +96,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int6
             y[row0 + r] = out;
         }
     }
+}
+
+template <typename T, int ROWS, bool VECTOR, int TRI = 0>
+__global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int64_t nr,
+                                                   int64_t nc, int64_t ldm,
+                                                   const T *__restrict__ x,
+                                                   const T *__restrict__ xscale,
+                                                   const int64_t *__restrict__ xidx,
+                                                   T *__restrict__ y, T alpha, T beta) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * ROWS;
+    gemv_wave_rows<T, ROWS, VECTOR, TRI>(M, nr, nc, ldm, x, xscale, xidx, y, alpha, beta, row0, lane);
 }
 
 template <typename T, int ROWS>
@@ -160,6 +174,86 @@ int trmv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double 
 int trmv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
              double beta, int tri, hipStream_t st) {
     return launch_trmv<float>(M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Several independent GEMV / triangular MV of the same kind in ONE launch (the same step of the triangular
+// solves of several films, chol.hip potrs_batch): a 4096-row inverse block or the last block column of a film
+// is too short a launch to reach the HBM rate alone (3.9 / 2.9 TB/s); two or more of them side by side in one
+// grid come closer.  The rows of a wave are gemv_wave_rows, as in the single launches: bit-identical results.
+// ---------------------------------------------------------------------------------------
+constexpr int kGemvBatchMax = 8;
+template <typename T>
+struct GemvBatch {
+    const T *M[kGemvBatchMax];
+    const T *x[kGemvBatchMax];
+    T *y[kGemvBatchMax];
+    int64_t nr[kGemvBatchMax], nc[kGemvBatchMax], ldm[kGemvBatchMax];
+    int rows[kGemvBatchMax];          // rows per wave: 4, 2 or 1 (as launch_gemv picks them)
+    unsigned first_block[kGemvBatchMax + 1];
+    int count;
+};
+template <typename T, int TRI>
+__global__ __launch_bounds__(256) void gemv_batch_kernel(GemvBatch<T> b, T alpha, T beta) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < kGemvBatchMax; ++i)
+        if (i < b.count && blockIdx.x >= b.first_block[i]) p = i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t local = blockIdx.x - b.first_block[p];
+    const int rows = b.rows[p];
+    const int64_t row0 = (local * 4 + wave) * rows;
+    if (rows == 4)
+        gemv_wave_rows<T, 4, true, TRI>(b.M[p], b.nr[p], b.nc[p], b.ldm[p], b.x[p], nullptr, nullptr, b.y[p], alpha, beta, row0, lane);
+    else if (rows == 2)
+        gemv_wave_rows<T, 2, true, TRI>(b.M[p], b.nr[p], b.nc[p], b.ldm[p], b.x[p], nullptr, nullptr, b.y[p], alpha, beta, row0, lane);
+    else
+        gemv_wave_rows<T, 1, true, TRI>(b.M[p], b.nr[p], b.nc[p], b.ldm[p], b.x[p], nullptr, nullptr, b.y[p], alpha, beta, row0, lane);
+}
+
+// y_i = alpha M_i x_i + beta y_i for i < count; tri = 0: rectangular (rows per wave by the row count, as launch_gemv),
+// 1 / 2: lower / upper triangular inverse blocks (rows per wave as launch_trmv).  All operands 16-byte aligned with
+// 16-byte aligned leading dimensions (the factor buffers are); count <= kGemvBatchMax.
+template <typename T>
+int launch_gemv_batch(int count, const T *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                      const T *const *x, T *const *y, double alpha, double beta, int tri, hipStream_t st) {
+    if (count <= 0) return SSA_OK;
+    if (count > kGemvBatchMax || tri < 0 || tri > 2) return SSA_ERR_INVALID_ARGUMENT;
+    GemvBatch<T> b;
+    b.count = 0;
+    unsigned blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (nr[i] <= 0) continue;
+        if (reinterpret_cast<uintptr_t>(M[i]) % 16 != 0 || (ldm[i] * sizeof(T)) % 16 != 0) return SSA_ERR_INVALID_ARGUMENT;
+        const int k = b.count++;
+        b.M[k] = M[i];
+        b.x[k] = x[i];
+        b.y[k] = y[i];
+        b.nr[k] = nr[i];
+        b.nc[k] = nc[i];
+        b.ldm[k] = ldm[i];
+        b.rows[k] = tri != 0 ? SSA_TRMV_ROWS : ((nr[i] >= SSA_GEMV_T4) ? 4 : ((nr[i] >= SSA_GEMV_T2) ? 2 : 1));
+        b.first_block[k] = blocks;
+        blocks += static_cast<unsigned>(ceil_div(nr[i], 4 * b.rows[k]));
+    }
+    if (b.count == 0) return SSA_OK;
+    for (int k = b.count; k <= kGemvBatchMax; ++k) b.first_block[k] = blocks;
+    if (tri == 0)
+        hipLaunchKernelGGL((gemv_batch_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, b, static_cast<T>(alpha), static_cast<T>(beta));
+    else if (tri == 1)
+        hipLaunchKernelGGL((gemv_batch_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, b, static_cast<T>(alpha), static_cast<T>(beta));
+    else
+        hipLaunchKernelGGL((gemv_batch_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, b, static_cast<T>(alpha), static_cast<T>(beta));
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+int gemv_batch_f64(int count, const double *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                   const double *const *x, double *const *y, double alpha, double beta, int tri, hipStream_t st) {
+    return launch_gemv_batch<double>(count, M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+int gemv_batch_f32(int count, const float *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                   const float *const *x, float *const *y, double alpha, double beta, int tri, hipStream_t st) {
+    return launch_gemv_batch<float>(count, M, nr, nc, ldm, x, y, alpha, beta, tri, st);
 }
 
 // Used by lu.hip (single right-hand-side triangular solves).

@@ -62,6 +62,10 @@ int trmv_f64(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double 
              double beta, int tri, hipStream_t st);
 int trmv_f32(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y, double alpha,
              double beta, int tri, hipStream_t st);
+int gemv_batch_f64(int count, const double *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                   const double *const *x, double *const *y, double alpha, double beta, int tri, hipStream_t st);
+int gemv_batch_f32(int count, const float *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                   const float *const *x, float *const *y, double alpha, double beta, int tri, hipStream_t st);
 int gemm_batched_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int batch1,
                      int batch2, const int64_t *strides, int tri, hipStream_t st);
@@ -111,6 +115,14 @@ inline int gemv_n_t(const double *M, int64_t nr, int64_t nc, int64_t ldm, const 
 inline int gemv_n_t(const float *M, int64_t nr, int64_t nc, int64_t ldm, const float *x, float *y,
                     double alpha, double beta, hipStream_t st) {
     return gemv_f32(M, nr, nc, ldm, x, y, alpha, beta, st);
+}
+inline int gemv_batch_t(int count, const double *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                        const double *const *x, double *const *y, double alpha, double beta, int tri, hipStream_t st) {
+    return gemv_batch_f64(count, M, nr, nc, ldm, x, y, alpha, beta, tri, st);
+}
+inline int gemv_batch_t(int count, const float *const *M, const int64_t *nr, const int64_t *nc, const int64_t *ldm,
+                        const float *const *x, float *const *y, double alpha, double beta, int tri, hipStream_t st) {
+    return gemv_batch_f32(count, M, nr, nc, ldm, x, y, alpha, beta, tri, st);
 }
 inline int trmv_t(const double *M, int64_t nr, int64_t nc, int64_t ldm, const double *x, double *y,
                   double alpha, double beta, int tri, hipStream_t st) {
@@ -703,8 +715,136 @@ int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t
         return SSA_ERR_HIP;
     return SSA_OK;
 }
+// Single right-hand-side solves of several factors (the films of a device in one Jacobi pass) in lockstep: step s of
+// every solve in ONE launch per kind (blas1.hip gemv_batch_kernel) - the same launches as `count` potrs calls, side
+// by side in one grid; a film with fewer blocks sits out the last steps.  Results bit-identical to separate solves.
+constexpr int kSolveBatchMax = 8;
+template <typename T>
+int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_t *lda, const T *const *aux, T *const *B,
+                    T *const *X, hipStream_t st) {
+    int64_t nblk[kSolveBatchMax], maxblk = 0;
+    for (int i = 0; i < count; ++i) {
+        nblk[i] = aux_layout(n[i]).nblk;
+        if (nblk[i] > maxblk) maxblk = nblk[i];
+    }
+    const T *M[kSolveBatchMax];
+    const T *x[kSolveBatchMax];
+    T *y[kSolveBatchMax];
+    int64_t nr[kSolveBatchMax], nc[kSolveBatchMax], ld[kSolveBatchMax];
+    int rc;
+    for (int64_t s = 0; s < maxblk; ++s) {   // forward: L y = b
+        int m = 0;
+        for (int i = 0; i < count; ++i) {
+            if (s >= nblk[i]) continue;
+            const AuxLayout al = aux_layout(n[i]);
+            const int64_t r0 = s * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB;
+            M[m] = aux[i] + al.inv + s * SNB * SNB;
+            nr[m] = nc[m] = kb;
+            ld[m] = SNB;
+            x[m] = B[i] + r0;
+            y[m] = X[i] + r0;
+            ++m;
+        }
+        rc = gemv_batch_t(m, M, nr, nc, ld, x, y, 1.0, 0.0, 1, st);
+        if (rc != SSA_OK) return rc;
+        m = 0;
+        for (int i = 0; i < count; ++i) {
+            if (s >= nblk[i]) continue;
+            const int64_t r0 = s * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB, below = n[i] - r0 - kb;
+            if (below <= 0) continue;
+            M[m] = L[i] + (r0 + kb) * lda[i] + r0;
+            nr[m] = below;
+            nc[m] = kb;
+            ld[m] = lda[i];
+            x[m] = X[i] + r0;
+            y[m] = B[i] + r0 + kb;
+            ++m;
+        }
+        rc = gemv_batch_t(m, M, nr, nc, ld, x, y, -1.0, 1.0, 0, st);
+        if (rc != SSA_OK) return rc;
+    }
+    for (int64_t s = 0; s < maxblk; ++s) {   // backward: L^T x = y   (y lives in X, x goes to B)
+        int m = 0;
+        for (int i = 0; i < count; ++i) {
+            const int64_t k = nblk[i] - 1 - s;
+            if (k < 0) continue;
+            const AuxLayout al = aux_layout(n[i]);
+            const int64_t r0 = k * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB;
+            M[m] = aux[i] + al.invT + k * SNB * SNB;
+            nr[m] = nc[m] = kb;
+            ld[m] = SNB;
+            x[m] = X[i] + r0;
+            y[m] = B[i] + r0;
+            ++m;
+        }
+        rc = gemv_batch_t(m, M, nr, nc, ld, x, y, 1.0, 0.0, 2, st);
+        if (rc != SSA_OK) return rc;
+        m = 0;
+        for (int i = 0; i < count; ++i) {
+            const int64_t k = nblk[i] - 1 - s;
+            if (k <= 0) continue;
+            const int64_t r0 = k * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB;
+            M[m] = L[i] + r0;   // rows 0 .. r0-1 of L^T, columns of this block
+            nr[m] = r0;
+            nc[m] = kb;
+            ld[m] = lda[i];
+            x[m] = B[i] + r0;
+            y[m] = X[i];
+            ++m;
+        }
+        rc = gemv_batch_t(m, M, nr, nc, ld, x, y, -1.0, 1.0, 0, st);
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
+
+template <typename T>
+int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda, const void *const *aux,
+                           void *const *B, void *const *workspace, hipStream_t st) {
+    const T *Lp[kSolveBatchMax];
+    const T *auxp[kSolveBatchMax];
+    T *Bp[kSolveBatchMax], *Xp[kSolveBatchMax];
+    int64_t np[kSolveBatchMax];
+    for (int i = 0; i < count; ++i) {
+        np[i] = ssa_chol_padded_n(n[i]);
+        Lp[i] = static_cast<const T *>(L[i]);
+        auxp[i] = static_cast<const T *>(aux[i]);
+        Xp[i] = static_cast<T *>(workspace[i]);
+        Bp[i] = Xp[i] + np[i];
+        if (hipMemcpyAsync(Bp[i], B[i], n[i] * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return SSA_ERR_HIP;
+        if (np[i] > n[i] && hipMemsetAsync(Bp[i] + n[i], 0, (np[i] - n[i]) * sizeof(T), st) != hipSuccess)
+            return SSA_ERR_HIP;
+    }
+    const int rc = potrs_vec_batch<T>(count, Lp, np, lda, auxp, Bp, Xp, st);
+    if (rc != SSA_OK) return rc;
+    for (int i = 0; i < count; ++i)
+        if (hipMemcpyAsync(B[i], Bp[i], n[i] * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return SSA_ERR_HIP;
+    return SSA_OK;
+}
 }  // namespace
 }  // namespace ssa
+
+extern "C" int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
+                                    const void *const *aux, void *const *B, int dtype, void *const *workspace,
+                                    const size_t *workspace_bytes, void *stream) {
+    if (count <= 0 || !L || !n || !lda || !aux || !B || !workspace || !workspace_bytes) return SSA_ERR_INVALID_ARGUMENT;
+    if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < count; ++i) {
+        if (!L[i] || !aux[i] || !B[i] || n[i] <= 0 || lda[i] < n[i]) return SSA_ERR_INVALID_ARGUMENT;
+        if (!workspace[i] || workspace_bytes[i] < ssa_chol_solve_workspace_bytes(n[i], 1, dtype))
+            return SSA_ERR_WORKSPACE_TOO_SMALL;
+    }
+    for (int first = 0; first < count; first += kSolveBatchMax) {   // more solves than a launch holds: groups
+        const int c = (count - first < kSolveBatchMax) ? count - first : kSolveBatchMax;
+        const int rc = (dtype == SSA_F64)
+                           ? potrs_padded_vec_batch<double>(c, L + first, n + first, lda + first, aux + first, B + first,
+                                                            workspace + first, as_stream(stream))
+                           : potrs_padded_vec_batch<float>(c, L + first, n + first, lda + first, aux + first, B + first,
+                                                           workspace + first, as_stream(stream));
+        if (rc != SSA_OK) return rc;
+    }
+    return SSA_OK;
+}
 
 extern "C" int ssa_chol_factor_batch(int count, void *const *A, const int64_t *n, const int64_t *lda,
                                      int32_t *const *info, void *const *aux, int dtype, void *stream) {

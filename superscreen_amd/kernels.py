@@ -172,6 +172,31 @@ def chol_solve(f: CholFactors, B: torch.Tensor) -> torch.Tensor:
     return B
 
 
+def chol_solve_batch(factors: Sequence[CholFactors], rhs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """``L_i L_i^T x_i = b_i`` in place for several factors with ONE right-hand side each (``b_i [n_i]``), the block
+    steps of all solves side by side in one launch each (``ssa_chol_solve_batch``); same dtype for all."""
+    import ctypes
+
+    lib = load_library()
+    count = len(factors)
+    if count == 0:
+        return []
+    if count == 1:
+        return [chol_solve(factors[0], rhs[0])]
+    dt = dtype_code(factors[0].dtype)
+    if any(dtype_code(f.dtype) != dt for f in factors) or any(b.dim() != 1 or not b.is_contiguous() for b in rhs):
+        raise ValueError("chol_solve_batch: one contiguous vector per factor, all of the same dtype.")
+    nbytes = [lib.ssa_chol_solve_workspace_bytes(f.n, 1, dt) for f in factors]
+    ws = [_ws(nb, rhs[0].device) for nb in nbytes]
+    PtrArr, I64Arr, SizeArr = ctypes.c_void_p * count, ctypes.c_int64 * count, ctypes.c_size_t * count
+    check(lib.ssa_chol_solve_batch(
+        count, PtrArr(*[f.L.data_ptr() for f in factors]), I64Arr(*[f.n for f in factors]),
+        I64Arr(*[f.lda for f in factors]), PtrArr(*[f.aux.data_ptr() for f in factors]),
+        PtrArr(*[b.data_ptr() for b in rhs]), dt, PtrArr(*[w.data_ptr() for w in ws]), SizeArr(*nbytes),
+        current_stream()), "ssa_chol_solve_batch")
+    return list(rhs)
+
+
 def gemm_ex(opA: int, opB: int, lower_only: bool, A, B, C, M: int, N: int, K: int,
             alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
     lib = load_library()

@@ -813,7 +813,55 @@ def _terminal_transport(model: "FactorizedModel", name: str):
 def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
                        check_inversion: bool, vortex_flux_value: float = 0.0,
                        defer_exterior: bool = False) -> _DeviceFilmResult:
-    """Device part of ``solve_film`` (``solver/solve_film.py:486-565``).  ``defer_exterior``: where the self field
+    """Device part of ``solve_film`` (``solver/solve_film.py:486-565``) for one film: ``_solve_film_steps`` with its
+    Cholesky solve done on the spot."""
+    from . import kernels
+
+    steps = _solve_film_steps(model, name, applied_d, other_d, check_inversion, vortex_flux_value, defer_exterior)
+    try:
+        factor, rhs = next(steps)
+        steps.send(kernels.chol_solve(factor, rhs))
+    except StopIteration as stop:
+        return stop.value
+    raise RuntimeError("_solve_film_steps asked for more than one solve.")
+
+
+def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d, other_d, check_inversion: bool,
+                        vortex_flux_value: float = 0.0, defer_exterior: bool = False) -> Dict[str, _DeviceFilmResult]:
+    """``_solve_film_device`` for several films of one pass (independent of each other, ``solver/solve.py:517-536``):
+    the Cholesky solves of all of them go out together (``kernels.chol_solve_batch``: the block steps of the
+    triangular solves side by side in one launch each)."""
+    from . import kernels
+
+    results, waiting = {}, []
+    for name in names:
+        steps = _solve_film_steps(model, name, applied_d[name], None if other_d is None else other_d[name],
+                                  check_inversion, vortex_flux_value, defer_exterior)
+        try:
+            waiting.append((name, steps) + tuple(next(steps)))
+        except StopIteration as stop:
+            results[name] = stop.value
+    by_dtype: Dict[object, list] = {}
+    for item in waiting:
+        by_dtype.setdefault(item[2].dtype, []).append(item)
+    for group in by_dtype.values():
+        solved = kernels.chol_solve_batch([item[2] for item in group], [item[3] for item in group])
+        for (name, steps, _, _), gf in zip(group, solved):
+            try:
+                steps.send(gf)
+            except StopIteration as stop:
+                results[name] = stop.value
+            else:
+                raise RuntimeError("_solve_film_steps asked for more than one solve.")
+    return {name: results[name] for name in names}
+
+
+def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
+                      check_inversion: bool, vortex_flux_value: float = 0.0,
+                      defer_exterior: bool = False):
+    """Device part of ``solve_film`` (``solver/solve_film.py:486-565``) as a generator: it yields
+    ``(CholFactors, right-hand side)`` where the film's system goes through its Cholesky factor, is sent the solution
+    and returns the ``_DeviceFilmResult`` (films on the LU route never yield).  ``defer_exterior``: where the self field
     of the film interior comes from the London equation, leave its all-pairs part (the rows that are not unknowns)
     to the caller, which evaluates it for all iterates at once (``_DeviceFilmResult.deferred_rows``)."""
     import torch
@@ -841,7 +889,7 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
         gf = None
     elif system.chol is not None:
         h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
-        gf = kernels.chol_solve(system.chol, kernels.row_scale(h_nat, system.neg_w_device))
+        gf = yield system.chol, kernels.row_scale(h_nat, system.neg_w_device)
     else:
         h = kernels.film_rhs(applied_d, other_d, ha_eff, system.rhs_indices_device)
         if check_inversion:
@@ -1038,11 +1086,8 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     coupling_sources: List[Dict[str, object]] = []      # one entry per iteration: the sheet currents it started from
 
     def run_pass(other_d):
-        results = {}
-        for name in mine:
-            results[name] = _solve_film_device(model, name, applied_d[name],
-                                               None if other_d is None else other_d[name],
-                                               check_inversion, vflux, defer_exterior=batch_exterior)
+        results = _solve_films_device(model, mine, applied_d, other_d, check_inversion, vflux,
+                                      defer_exterior=batch_exterior)
         if batch_exterior:
             deferred.append({name: res for name, res in results.items() if res.deferred_rows is not None})
         if placement is not None:

@@ -328,6 +328,31 @@ def test_cholesky_block_solves(K, n):
         assert relerr(x, la.cho_solve((Lref, True), b)) < 1e-11
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cholesky_solve_batch_equals_single(K, dtype):
+    """ssa_chol_solve_batch (the block steps of several single-right-hand-side solves side by side in one launch each)
+    is bit-identical to separate ssa_chol_solve calls, for factors with different numbers of 4096-blocks."""
+    rng = np.random.default_rng(11)
+    tdt = getattr(torch, dtype)
+    factors, rhs = [], []
+    for n in (9000, 1500, 13111, 4096, 300):
+        U = rng.standard_normal((n, 16))
+        S = U @ U.T / 16 + np.diag(2.0 + rng.random(n))
+        npad = K.chol_padded_n(n)
+        Sd = torch.zeros((npad, K.padded_ld(npad, dtype)), dtype=tdt, device="cuda")
+        Sd[:n, :n] = dev(np.tril(S).astype(dtype))
+        f = K.chol_factor(Sd, n)
+        assert f.info == 0
+        factors.append(f)
+        rhs.append(dev(rng.standard_normal(n).astype(dtype)))
+    single = [K.chol_solve(f, b.clone()) for f, b in zip(factors, rhs)]
+    batch = K.chol_solve_batch(factors, [b.clone() for b in rhs])
+    for a, b in zip(single, batch):
+        assert torch.equal(a, b)
+    again = K.chol_solve_batch(factors[:2], [b.clone() for b in rhs[:2]])
+    assert torch.equal(again[0], single[0]) and torch.equal(again[1], single[1])
+
+
 def test_cholesky_batch_equals_single(K):
     """ssa_chol_factor_batch (films interleaved on one schedule) is bit-identical to separate calls."""
     rng = np.random.default_rng(5)
