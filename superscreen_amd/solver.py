@@ -827,7 +827,8 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
 
 
 def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d, other_d, check_inversion: bool,
-                        vortex_flux_value: float = 0.0, defer_exterior: bool = False) -> Dict[str, _DeviceFilmResult]:
+                        vortex_flux_value: float = 0.0, defer_exterior: bool = False,
+                        pass_cache: Optional[dict] = None) -> Dict[str, _DeviceFilmResult]:
     """``_solve_film_device`` for several films of one pass (independent of each other, ``solver/solve.py:517-536``):
     the Cholesky solves of all of them go out together (``kernels.chol_solve_batch``: the block steps of the
     triangular solves side by side in one launch each)."""
@@ -836,7 +837,7 @@ def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d,
     results, waiting = {}, []
     for name in names:
         steps = _solve_film_steps(model, name, applied_d[name], None if other_d is None else other_d[name],
-                                  check_inversion, vortex_flux_value, defer_exterior)
+                                  check_inversion, vortex_flux_value, defer_exterior, pass_cache)
         try:
             waiting.append((name, steps) + tuple(next(steps)))
         except StopIteration as stop:
@@ -858,7 +859,7 @@ def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d,
 
 def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
                       check_inversion: bool, vortex_flux_value: float = 0.0,
-                      defer_exterior: bool = False):
+                      defer_exterior: bool = False, pass_cache: Optional[dict] = None):
     """Device part of ``solve_film`` (``solver/solve_film.py:486-565``) as a generator: it yields
     ``(CholFactors, right-hand side)`` where the film's system goes through its Cholesky factor, is sent the solution
     and returns the ``_DeviceFilmResult`` (films on the LU route never yield).  ``defer_exterior``: where the self field
@@ -871,20 +872,29 @@ def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
     fd = model.film_data[name]
     info = model.film_info[name]
     system = model.film_systems[name]
-    g = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
-    ha_eff = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
-    for hole_name, hs in model.hole_systems[name].items():
-        current = info.circulating_currents.get(hole_name, 0)
-        if len(hs.indices) == 0:
-            continue
-        kernels.index_add_scalar(g, hs.indices_device, current)        # g[hole] += I_circ
-        kernels.gemv(hs.A_device, fd.n, len(hs.indices), g, xidx=hs.indices_device,
-                     y=ha_eff, alpha=-1.0, beta=1.0)                      # Ha_eff += -(A @ g[ix])
     has_terminals = name in model.device.terminals
-    if has_terminals:  # solve_film.py:505-524
-        g_transport, ha_transport = _terminal_transport(model, name)
-        g += g_transport
-        ha_eff += ha_transport
+    fixed = None if pass_cache is None else pass_cache.get(name)
+    if fixed is None:
+        g = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+        ha_eff = torch.zeros(fd.n, dtype=fd.tdtype, device=fd.device)
+        for hole_name, hs in model.hole_systems[name].items():
+            current = info.circulating_currents.get(hole_name, 0)
+            if len(hs.indices) == 0:
+                continue
+            kernels.index_add_scalar(g, hs.indices_device, current)        # g[hole] += I_circ
+            kernels.gemv(hs.A_device, fd.n, len(hs.indices), g, xidx=hs.indices_device,
+                         y=ha_eff, alpha=-1.0, beta=1.0)                      # Ha_eff += -(A @ g[ix])
+        if has_terminals:  # solve_film.py:505-524
+            g_transport, ha_transport = _terminal_transport(model, name)
+            g += g_transport
+            ha_eff += ha_transport
+        if pass_cache is not None:
+            # the holes' and terminals' part of g and of the effective field depends neither on the applied field
+            # nor on the iteration (solve_film.py:498-524 recomputes it in every call: an [n, n_hole] product per hole):
+            # evaluated in the first pass of a solve, copied in the others
+            pass_cache[name] = (g.clone(), ha_eff)
+    else:
+        g, ha_eff = fixed[0].clone(), fixed[1]     # (ha_eff is only read below)
     if len(system.indices) == 0:
         gf = None
     elif system.chol is not None:
@@ -1083,11 +1093,12 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     # spread over ranks (the owners' vectors travel after every pass).
     batch_exterior = return_solutions and save_path is None and placement is None and len(films) >= 2 and iterations >= 1
     deferred: List[Dict[str, _DeviceFilmResult]] = []   # one entry per pass: the results with missing rows
+    pass_cache: Dict[str, object] = {}                  # per film: what is the same in every pass of this solve
     coupling_sources: List[Dict[str, object]] = []      # one entry per iteration: the sheet currents it started from
 
     def run_pass(other_d):
         results = _solve_films_device(model, mine, applied_d, other_d, check_inversion, vflux,
-                                      defer_exterior=batch_exterior)
+                                      defer_exterior=batch_exterior, pass_cache=pass_cache)
         if batch_exterior:
             deferred.append({name: res for name, res in results.items() if res.deferred_rows is not None})
         if placement is not None:
