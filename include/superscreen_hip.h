@@ -178,9 +178,11 @@ int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void 
  * step of all solves is one launch, so that the short launches of the triangular GEMV chain (a 4096-row inverse
  * block, a film's last block column) run side by side in one grid.  L, n, lda, aux, B, workspace, workspace_bytes:
  * HOST arrays of `count` entries with the arguments of ssa_chol_solve for nrhs = 1, ldb = 1 (workspace_bytes[i] >=
- * ssa_chol_solve_workspace_bytes(n[i], 1, dtype)).  Results bit-identical to `count` ssa_chol_solve calls. */
+ * ssa_chol_solve_workspace_bytes(n[i], 1, dtype)).  b_is_padded != 0: every B[i] holds ssa_chol_padded_n(n[i])
+ * elements, zero from n[i] on, and is solved where it is (no staging copies; the padding stays zero) - what a caller
+ * that runs many passes with the same buffers wants.  Results bit-identical to `count` ssa_chol_solve calls. */
 int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
-                         const void *const *aux, void *const *B, int dtype, void *const *workspace,
+                         const void *const *aux, void *const *B, int b_is_padded, int dtype, void *const *workspace,
                          const size_t *workspace_bytes, void *stream);
 /*
  * Diagnostics of the factorization schedule (no reference counterpart).  The panel chains run on internal

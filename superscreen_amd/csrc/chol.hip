@@ -800,7 +800,7 @@ int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_
 
 template <typename T>
 int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda, const void *const *aux,
-                           void *const *B, void *const *workspace, hipStream_t st) {
+                           void *const *B, void *const *workspace, bool padded, hipStream_t st) {
     const T *Lp[kSolveBatchMax];
     const T *auxp[kSolveBatchMax];
     T *Bp[kSolveBatchMax], *Xp[kSolveBatchMax];
@@ -810,13 +810,17 @@ int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, co
         Lp[i] = static_cast<const T *>(L[i]);
         auxp[i] = static_cast<const T *>(aux[i]);
         Xp[i] = static_cast<T *>(workspace[i]);
+        if (padded) {   // the caller's vector already is the padded right-hand side: solved where it is
+            Bp[i] = static_cast<T *>(B[i]);
+            continue;
+        }
         Bp[i] = Xp[i] + np[i];
         if (hipMemcpyAsync(Bp[i], B[i], n[i] * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return SSA_ERR_HIP;
         if (np[i] > n[i] && hipMemsetAsync(Bp[i] + n[i], 0, (np[i] - n[i]) * sizeof(T), st) != hipSuccess)
             return SSA_ERR_HIP;
     }
     const int rc = potrs_vec_batch<T>(count, Lp, np, lda, auxp, Bp, Xp, st);
-    if (rc != SSA_OK) return rc;
+    if (rc != SSA_OK || padded) return rc;
     for (int i = 0; i < count; ++i)
         if (hipMemcpyAsync(B[i], Bp[i], n[i] * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return SSA_ERR_HIP;
     return SSA_OK;
@@ -825,8 +829,8 @@ int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, co
 }  // namespace ssa
 
 extern "C" int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
-                                    const void *const *aux, void *const *B, int dtype, void *const *workspace,
-                                    const size_t *workspace_bytes, void *stream) {
+                                    const void *const *aux, void *const *B, int b_is_padded, int dtype,
+                                    void *const *workspace, const size_t *workspace_bytes, void *stream) {
     if (count <= 0 || !L || !n || !lda || !aux || !B || !workspace || !workspace_bytes) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < count; ++i) {
@@ -838,9 +842,9 @@ extern "C" int ssa_chol_solve_batch(int count, const void *const *L, const int64
         const int c = (count - first < kSolveBatchMax) ? count - first : kSolveBatchMax;
         const int rc = (dtype == SSA_F64)
                            ? potrs_padded_vec_batch<double>(c, L + first, n + first, lda + first, aux + first, B + first,
-                                                            workspace + first, as_stream(stream))
+                                                            workspace + first, b_is_padded != 0, as_stream(stream))
                            : potrs_padded_vec_batch<float>(c, L + first, n + first, lda + first, aux + first, B + first,
-                                                           workspace + first, as_stream(stream));
+                                                           workspace + first, b_is_padded != 0, as_stream(stream));
         if (rc != SSA_OK) return rc;
     }
     return SSA_OK;

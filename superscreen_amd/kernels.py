@@ -172,29 +172,32 @@ def chol_solve(f: CholFactors, B: torch.Tensor) -> torch.Tensor:
     return B
 
 
-def chol_solve_batch(factors: Sequence[CholFactors], rhs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+def chol_solve_batch(factors: Sequence[CholFactors], rhs: Sequence[torch.Tensor], padded: bool = False) -> List[torch.Tensor]:
     """``L_i L_i^T x_i = b_i`` in place for several factors with ONE right-hand side each (``b_i [n_i]``), the block
-    steps of all solves side by side in one launch each (``ssa_chol_solve_batch``); same dtype for all."""
+    steps of all solves side by side in one launch each (``ssa_chol_solve_batch``); same dtype for all.
+    ``padded``: every ``b_i`` has ``chol_padded_n(n_i)`` elements, zero from ``n_i`` on, and is solved where it is
+    (no staging copies); the returned vectors are views of the first ``n_i`` elements."""
     import ctypes
 
     lib = load_library()
     count = len(factors)
     if count == 0:
         return []
-    if count == 1:
-        return [chol_solve(factors[0], rhs[0])]
     dt = dtype_code(factors[0].dtype)
     if any(dtype_code(f.dtype) != dt for f in factors) or any(b.dim() != 1 or not b.is_contiguous() for b in rhs):
         raise ValueError("chol_solve_batch: one contiguous vector per factor, all of the same dtype.")
+    for f, b in zip(factors, rhs):
+        if b.numel() != (chol_padded_n(f.n) if padded else f.n):
+            raise ValueError("chol_solve_batch: a right-hand side has the wrong length.")
     nbytes = [lib.ssa_chol_solve_workspace_bytes(f.n, 1, dt) for f in factors]
     ws = [_ws(nb, rhs[0].device) for nb in nbytes]
     PtrArr, I64Arr, SizeArr = ctypes.c_void_p * count, ctypes.c_int64 * count, ctypes.c_size_t * count
     check(lib.ssa_chol_solve_batch(
         count, PtrArr(*[f.L.data_ptr() for f in factors]), I64Arr(*[f.n for f in factors]),
         I64Arr(*[f.lda for f in factors]), PtrArr(*[f.aux.data_ptr() for f in factors]),
-        PtrArr(*[b.data_ptr() for b in rhs]), dt, PtrArr(*[w.data_ptr() for w in ws]), SizeArr(*nbytes),
-        current_stream()), "ssa_chol_solve_batch")
-    return list(rhs)
+        PtrArr(*[b.data_ptr() for b in rhs]), int(bool(padded)), dt, PtrArr(*[w.data_ptr() for w in ws]),
+        SizeArr(*nbytes), current_stream()), "ssa_chol_solve_batch")
+    return [b[:f.n] for f, b in zip(factors, rhs)] if padded else list(rhs)
 
 
 def gemm_ex(opA: int, opB: int, lower_only: bool, A, B, C, M: int, N: int, K: int,
@@ -405,9 +408,10 @@ def gemv(M: torch.Tensor, nr: int, nc: int, x: torch.Tensor, *, xscale=None, xid
     return y
 
 
-def row_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+def row_scale(x: torch.Tensor, s: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y = s[:, None] * x`` (``out``: where to write it, same shape as ``x``)."""
     lib = load_library()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     nvec = 1 if x.dim() == 1 else x.shape[1]
     check(lib.ssa_row_scale(ptr(x), ptr(s), ptr(y), x.shape[0], nvec, dtype_code(x.dtype),
                             current_stream()), "ssa_row_scale")

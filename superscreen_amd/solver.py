@@ -820,7 +820,7 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
     steps = _solve_film_steps(model, name, applied_d, other_d, check_inversion, vortex_flux_value, defer_exterior)
     try:
         factor, rhs = next(steps)
-        steps.send(kernels.chol_solve(factor, rhs))
+        steps.send(kernels.chol_solve_batch([factor], [rhs], padded=True)[0])
     except StopIteration as stop:
         return stop.value
     raise RuntimeError("_solve_film_steps asked for more than one solve.")
@@ -846,7 +846,7 @@ def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d,
     for item in waiting:
         by_dtype.setdefault(item[2].dtype, []).append(item)
     for group in by_dtype.values():
-        solved = kernels.chol_solve_batch([item[2] for item in group], [item[3] for item in group])
+        solved = kernels.chol_solve_batch([item[2] for item in group], [item[3] for item in group], padded=True)
         for (name, steps, _, _), gf in zip(group, solved):
             try:
                 steps.send(gf)
@@ -861,7 +861,7 @@ def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
                       check_inversion: bool, vortex_flux_value: float = 0.0,
                       defer_exterior: bool = False, pass_cache: Optional[dict] = None):
     """Device part of ``solve_film`` (``solver/solve_film.py:486-565``) as a generator: it yields
-    ``(CholFactors, right-hand side)`` where the film's system goes through its Cholesky factor, is sent the solution
+    ``(CholFactors, right-hand side padded to chol_padded_n)`` where the film's system goes through its Cholesky factor, is sent the solution
     and returns the ``_DeviceFilmResult`` (films on the LU route never yield).  ``defer_exterior``: where the self field
     of the film interior comes from the London equation, leave its all-pairs part (the rows that are not unknowns)
     to the caller, which evaluates it for all iterates at once (``_DeviceFilmResult.deferred_rows``)."""
@@ -899,7 +899,15 @@ def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
         gf = None
     elif system.chol is not None:
         h_nat = kernels.film_rhs(applied_d, other_d, ha_eff, system.indices_device)
-        gf = yield system.chol, kernels.row_scale(h_nat, system.neg_w_device)
+        # the right-hand side in a buffer padded as the factorization is (zero tail), kept for all passes of a solve:
+        # the triangular solves then run where it is, without staging copies
+        rhs = None if pass_cache is None else pass_cache.get(("rhs", name))
+        if rhs is None:
+            rhs = torch.zeros(kernels.chol_padded_n(system.chol.n), dtype=fd.tdtype, device=fd.device)
+            if pass_cache is not None:
+                pass_cache[("rhs", name)] = rhs
+        kernels.row_scale(h_nat, system.neg_w_device, out=rhs[:system.chol.n])
+        gf = yield system.chol, rhs
     else:
         h = kernels.film_rhs(applied_d, other_d, ha_eff, system.rhs_indices_device)
         if check_inversion:

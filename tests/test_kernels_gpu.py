@@ -351,6 +351,16 @@ def test_cholesky_solve_batch_equals_single(K, dtype):
         assert torch.equal(a, b)
     again = K.chol_solve_batch(factors[:2], [b.clone() for b in rhs[:2]])
     assert torch.equal(again[0], single[0]) and torch.equal(again[1], single[1])
+    # right-hand sides that already sit in padded buffers (zero tail) are solved where they are
+    padded = []
+    for f, b in zip(factors, rhs):
+        buf = torch.zeros(K.chol_padded_n(f.n), dtype=tdt, device="cuda")
+        buf[:f.n] = b
+        padded.append(buf)
+    inplace = K.chol_solve_batch(factors, padded, padded=True)
+    for a, b, buf, f in zip(single, inplace, padded, factors):
+        assert torch.equal(a, b) and b.data_ptr() == buf.data_ptr()
+        assert not buf[f.n:].any()                                   # the padding stays zero: the buffer can be reused
 
 
 def test_cholesky_batch_equals_single(K):
