@@ -200,23 +200,21 @@ def _h2d(a: np.ndarray, dev):
 class FilmDeviceData:
     """Everything of one film that lives in HBM (torch tensors are plumbing only)."""
 
-    def __init__(self, info: FilmInfo, mesh, dtype: np.dtype, store_Q: bool, geometry_only: bool = False):
+    @staticmethod
+    def device_geometry(mesh, dtype: np.dtype):
+        """Mesh geometry and sparse operators on the current GPU: uploaded once per (mesh, GPU, dtype), they stay
+        resident in HBM across factorize_model calls."""
         import torch
-
-        from . import kernels
 
         tdt = torch.float64 if dtype == np.float64 else torch.float32
         dev = torch.device("cuda", torch.cuda.current_device())
         ops = mesh.operators
-
-        def put(a):
-            return _h2d(a, dev)
-
-        # Mesh geometry and sparse operators are uploaded once per (mesh, GPU, dtype) and stay
-        # resident in HBM across factorize_model calls.
         key = (dev.index, str(dtype))
         geo = ops._device_cache.get(key)
         if geo is None:
+            def put(a):
+                return _h2d(a, dev)
+
             lap = ops.laplacian.tocsr()
             lap.sort_indices()
             ptr_, idx_, vx, vy = fem.shared_pattern(ops.gradient_x, ops.gradient_y)
@@ -232,6 +230,30 @@ class FilmDeviceData:
             done.record()
             done.synchronize()
             ops._device_cache[key] = geo
+        return geo
+
+    @staticmethod
+    def start_row_sums(mesh, dtype: np.dtype, store_Q: bool) -> None:
+        """Launches the kernel-matrix row sums of a film (the first kernel of a cold step, 0.5 ms at 25 000
+        vertices) ahead of the host work that prepares its index sets; the constructor picks the result up."""
+        from . import kernels
+
+        geo = FilmDeviceData.device_geometry(mesh, dtype)
+        geo["_row_sums"] = (bool(store_Q),) + tuple(kernels.q_assemble(geo["xy"], geo["w"], geo["C"], dtype, want_Q=store_Q))
+
+    def __init__(self, info: FilmInfo, mesh, dtype: np.dtype, store_Q: bool, geometry_only: bool = False):
+        import torch
+
+        from . import kernels
+
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ops = mesh.operators
+
+        def put(a):
+            return _h2d(a, dev)
+
+        geo = FilmDeviceData.device_geometry(mesh, dtype)
         self.n = len(mesh.sites)
         self.dtype, self.tdtype, self.device = dtype, tdt, dev
         self.xy, self.w, self.w_t = geo["xy"], geo["w"], geo["w_t"]  # w: f64 geometry; w_t: solve dtype
@@ -241,8 +263,11 @@ class FilmDeviceData:
         # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
         # unless the dense Q is wanted for the self-field GEMV.  (Launched before the host work below: the row sums
         # are the first kernel of a cold step.)
+        started = geo.pop("_row_sums", None)   # (FilmDeviceData.start_row_sums)
         if geometry_only:  # a film owned by another rank: only a coupling source / target geometry
             self.Q = self.qdiag = None
+        elif started is not None and started[0] == bool(store_Q):
+            self.Q, self.qdiag = started[1], started[2]
         else:
             self.Q, self.qdiag = kernels.q_assemble(self.xy, self.w, geo["C"], dtype, want_Q=store_Q)
         # Index range of the vertices that can carry a sheet current: g lives on the interior and hole
@@ -667,6 +692,15 @@ def factorize_model(*, device: Device, current_units: str,
     vortices = list(vortices or [])
     if not device.meshes:
         raise ValueError("The device does not have a mesh. Call device.make_mesh() to generate it.")
+    # the films' kernel-matrix row sums go out first: they only need the mesh, and run on the GPU while the host
+    # works out the index sets (make_film_info: polygon tests, set arithmetic)
+    if device.meshes:
+        from . import _hip
+
+        _hip.require_gpu()   # (no CPU fallback: HipLibraryError without the library or a GPU)
+        mine_first = list(device.films) if placement is None else placement.mine(list(device.films))
+        for name in mine_first:
+            FilmDeviceData.start_row_sums(device.meshes[name], device.solve_dtype, self_field == "dense")
     film_info = make_film_info(device=device, vortices=vortices,
                                circulating_currents=circulating_currents,
                                terminal_currents=terminal_currents)
