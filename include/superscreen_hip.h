@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 5
+#define SSA_ABI_VERSION 4
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);
@@ -173,14 +173,6 @@ int ssa_chol_factor_batch(int count, void *const *S, const int64_t *n, const int
 size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dtype);
 int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
                    int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, void *stream);
-/* ssa_chol_wait_infos: the pivot reports (`info`) of the `count` matrices of the LAST ssa_chol_factor_batch (or
- * ssa_chol_factor: count = 1) call on the current device, as soon as they are final - when a matrix' last diagonal
- * block has been factored, one to two milliseconds before the schedule's finishing passes are through.  Blocks the
- * host until then and no longer: a caller that must decide on them (fall back to ssa_lu_factor or not,
- * solver/solve_film.py:279 has no such decision) can enqueue its next work while the GPU still finishes.  Returns
- * SSA_ERR_INVALID_ARGUMENT if `count` is not the size of that call (or it had more than 16 matrices: read `info`
- * from the device then). */
-int ssa_chol_wait_infos(int count, int32_t *info_host);
 /* ssa_chol_solve_batch: `count` single-right-hand-side solves L_i L_i^T x_i = b_i (the films of a device in one
  * pass of the Jacobi loop, solver/solve.py:517-536 - they are independent of each other) in lockstep: every block
  * step of all solves is one launch, so that the short launches of the triangular GEMV chain (a 4096-row inverse

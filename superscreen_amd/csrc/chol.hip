@@ -234,11 +234,6 @@ constexpr int kMaxLanes = 16;
 struct LaneSet {
     CholLane lanes[kMaxLanes];
     std::mutex enqueue;
-    // Pivot reports of the last schedule, on their way to the host from the moment a matrix' LAST diagonal block is
-    // factored (ssa_chol_wait_infos): a pinned int32 per lane, the event behind its copy, and how many are valid.
-    int32_t *info_host = nullptr;
-    hipEvent_t ev_info[kMaxLanes] = {};
-    int info_count = 0;
 };
 LaneSet g_lane_sets[kMaxDevices];
 std::mutex g_lane_create_mutex;
@@ -264,12 +259,6 @@ inline int get_lanes(int count, hipStream_t st, LaneSet **out) {
             hipEventCreateWithFlags(&lanes[i].ev_syrk, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
-    }
-    if (set.info_host == nullptr) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&set.info_host), kMaxLanes * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
-            return SSA_ERR_HIP;
-        for (int i = 0; i < kMaxLanes; ++i)
-            if (hipEventCreateWithFlags(&set.ev_info[i], hipEventDisableTiming) != hipSuccess) return SSA_ERR_HIP;
     }
     // (the chain streams are idle here: every schedule joins them into its caller's stream, and the schedules of
     // one device are serialised by set.enqueue, taken here for a measurement and by the caller after this)
@@ -299,15 +288,6 @@ inline int destroy_lanes() {
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
             if (hipStreamDestroy(ln.finish) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
             ln = CholLane{};
-        }
-        if (set.info_host != nullptr) {
-            for (hipEvent_t &e : set.ev_info) {
-                if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
-                e = nullptr;
-            }
-            if (hipHostFree(set.info_host) != hipSuccess) rc = SSA_ERR_HIP;
-            set.info_host = nullptr;
-            set.info_count = 0;
         }
     }
     return rc;
@@ -510,18 +490,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     const bool split_updates = count >= 3;
     // outer steps (per matrix) that are chain bound: the early finishing steps are slipped into the last 16 of them
     constexpr int64_t kTailCols = 4096;
-    // The pivot report of a matrix is final when its last diagonal block is factored, one to two milliseconds before
-    // the schedule's finishing passes are through: it starts its way to the host right there, on the chain stream
-    // (ssa_chol_wait_infos), so that a caller that has to look at it before it goes on (fall back to the LU route
-    // or not) can prepare and enqueue its next work while the GPU still finishes.
-    lane_set->info_count = count;
-    auto report_info = [&](int i) -> int {
-        if (hipMemcpyAsync(lane_set->info_host + i, jobs[i].info, sizeof(int32_t), hipMemcpyDeviceToHost, lanes[i].side) !=
-                hipSuccess ||
-            hipEventRecord(lane_set->ev_info[i], lanes[i].side) != hipSuccess)
-            return SSA_ERR_HIP;
-        return SSA_OK;
-    };
     FinishPlan<T> plans[kMaxLanes];
     int64_t nmax = 0;
     for (int i = 0; i < count; ++i) {
@@ -539,7 +507,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (split_updates && hipStreamWaitEvent(ln.upd, ln.ev_strip, 0) != hipSuccess) return SSA_ERR_HIP;
         rc = chol_panel_diag(J, 0, ln.side);
         if (rc != SSA_OK) return rc;
-        if (J.n <= CNB && (rc = report_info(i)) != SSA_OK) return rc;
         rc = chol_panel_rows(J, 0, CNB, J.n, ln.side);
         if (rc != SSA_OK) return rc;
         if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
@@ -594,7 +561,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             if (rc != SSA_OK) return rc;
             rc = chol_panel_diag(J, c, cs);
             if (rc != SSA_OK) return rc;
-            if (right <= nw && (rc = report_info(i)) != SSA_OK) return rc;   // that was the last diagonal block
             if (right > nw) {
                 rc = chol_panel_rows(J, c, c + CNB, J.n, cs);
                 if (rc != SSA_OK) return rc;
@@ -701,20 +667,6 @@ extern "C" size_t ssa_chol_aux_bytes(int64_t n, int dtype) {
 
 extern "C" int ssa_chol_chain_stream_costs(double *microseconds, int32_t *pipe_group, int capacity) {
     return chain_streams_costs(microseconds, pipe_group, capacity);
-}
-
-extern "C" int ssa_chol_wait_infos(int count, int32_t *info_host) {
-    if (count <= 0 || !info_host) return SSA_ERR_INVALID_ARGUMENT;
-    int dev = 0;
-    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
-    LaneSet &set = g_lane_sets[dev];
-    std::lock_guard<std::mutex> enq(set.enqueue);
-    if (set.info_host == nullptr || count != set.info_count || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
-    for (int i = 0; i < count; ++i) {
-        if (hipEventSynchronize(set.ev_info[i]) != hipSuccess) return SSA_ERR_HIP;
-        info_host[i] = set.info_host[i];
-    }
-    return SSA_OK;
 }
 
 extern "C" int64_t ssa_chol_padded_n(int64_t n) { return ceil_div(n, CNB) * CNB; }

@@ -90,7 +90,6 @@ class CholFactors:
         self.L, self.n, self.aux, self.info_device = L, n, aux, info_device
         self.dtype = L.dtype
         self._info: Optional[int] = None
-        self._batch: Optional[list] = None   # the list chol_factor_batch returned this object in (fetch_chol_infos)
 
     @property
     def info(self) -> int:
@@ -103,28 +102,12 @@ class CholFactors:
         return self.L.shape[1]
 
 
-_last_chol_batch: Optional[list] = None   # what the last chol_factor_batch call returned
-
-
 def fetch_chol_infos(factors: Sequence[CholFactors]) -> None:
-    """The ``info`` of several factorizations in one go.  For the matrices of the last ``chol_factor_batch`` call
-    (``factors`` = what it returned) the library hands them over as soon as they are final - before its finishing
-    passes have run (``ssa_chol_wait_infos``); otherwise one device-to-host round trip for all of them."""
-    import ctypes
-
+    """One device-to-host round trip for the ``info`` of several factorizations (instead of one per access)."""
     todo = [f for f in factors if f._info is None]
-    if not todo:
-        return
-    batch = factors[0]._batch
-    if (batch is not None and batch is _last_chol_batch and len(batch) == len(factors) <= 16
-            and all(a is b for a, b in zip(factors, batch))):
-        out = (ctypes.c_int32 * len(factors))()
-        if load_library().ssa_chol_wait_infos(len(factors), out) == 0:
-            for f, v in zip(factors, out):
-                f._info = int(v)
-            return
-    for f, v in zip(todo, torch.cat([f.info_device for f in todo]).cpu().tolist()):
-        f._info = int(v)
+    if todo:
+        for f, v in zip(todo, torch.cat([f.info_device for f in todo]).cpu().tolist()):
+            f._info = int(v)
 
 
 def chol_padded_n(n: int) -> int:
@@ -156,10 +139,6 @@ def chol_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[CholF
         count, PtrArr(*[f.L.data_ptr() for f in out]), I64Arr(*[f.n for f in out]),
         I64Arr(*[f.lda for f in out]), PtrArr(*[f.info_device.data_ptr() for f in out]),
         PtrArr(*[f.aux.data_ptr() for f in out]), dt, current_stream()), "ssa_chol_factor_batch")
-    global _last_chol_batch
-    _last_chol_batch = out
-    for f in out:
-        f._batch = out
     return out
 
 

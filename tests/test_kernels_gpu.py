@@ -363,37 +363,6 @@ def test_cholesky_solve_batch_equals_single(K, dtype):
         assert not buf[f.n:].any()                                   # the padding stays zero: the buffer can be reused
 
 
-def test_cholesky_infos_arrive_early(K):
-    """ssa_chol_wait_infos: the pivot reports of the last batch, handed over when each matrix' last diagonal block
-    is factored (kernels.fetch_chol_infos takes this route for the list chol_factor_batch returned): the same values
-    as the device-side info, for positive definite and indefinite matrices, one-panel matrices included."""
-    rng = np.random.default_rng(3)
-    mats = []
-    for n, bad in ((1500, None), (200, None), (3000, 2100), (256, 100), (5000, None)):
-        U = rng.standard_normal((n, 16))
-        S = U @ U.T / 16 + np.diag(1.5 + rng.random(n))
-        if bad is not None:
-            S[bad, bad] = -3.0
-        mats.append(np.tril(S))
-
-    def buf(S):
-        n = len(S)
-        npad = K.chol_padded_n(n)
-        t = torch.zeros((npad, K.padded_ld(npad, "float64")), dtype=torch.float64, device="cuda")
-        t[:n, :n] = dev(S)
-        return t
-
-    batch = K.chol_factor_batch([(buf(S), len(S)) for S in mats])
-    K.fetch_chol_infos(batch)
-    early = [f._info for f in batch]
-    torch.cuda.synchronize()
-    late = [int(f.info_device.item()) for f in batch]
-    assert early == late
-    assert [v == 0 for v in late] == [True, True, False, False, True]
-    single = K.chol_factor(buf(mats[3]), len(mats[3]))   # count = 1 goes the same way
-    assert single.info == late[3] > 0
-
-
 def test_cholesky_batch_equals_single(K):
     """ssa_chol_factor_batch (films interleaved on one schedule) is bit-identical to separate calls."""
     rng = np.random.default_rng(5)
