@@ -894,6 +894,37 @@ def test_lu_route_falls_back_to_partial_pivoting(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("films", [("washer", "disk"), ("disk", "washer", "disk")])
+def test_output_only_rows_batched_equal_per_pass_route(tmp_path, films):
+    """What only goes into the returned Solutions - the self field and the coupling field on the rows that are not
+    unknowns - is evaluated for all iterates at once after the last pass (``solver._enqueue_exterior_*``); with
+    ``save_path`` the iterates are written as they come and every pass evaluates all rows itself.  Both routes give
+    the same Solutions (the stream functions bit for bit: the iteration itself does not change)."""
+    import superscreen_amd as sc
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(24, films, z_spacing=0.6)
+    currents = {f"hole{films.index('washer')}": "1.5 uA"}
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents=currents)
+    batched = sc.solve(model=model, applied_field=sc.ConstantField(0.7), field_units="mT", iterations=4)
+    per_pass = sc.solve(model=model, applied_field=sc.ConstantField(0.7), field_units="mT", iterations=4,
+                        save_path=tmp_path / "iterates.npz")
+    assert len(batched) == len(per_pass) == 5
+    for k, (a, b) in enumerate(zip(batched, per_pass)):
+        for name in device.films:
+            fa, fb = a.film_solutions[name], b.film_solutions[name]
+            assert np.array_equal(fa.stream, fb.stream) and np.array_equal(fa.current_density, fb.current_density)
+            scale = np.abs(fb.self_field).max()
+            assert np.abs(fa.self_field - fb.self_field).max() < 1e-12 * scale
+            if k == 0:
+                assert fa.field_from_other_films is None and fb.field_from_other_films is None
+            else:
+                scale = np.abs(fb.field_from_other_films).max()
+                assert np.abs(fa.field_from_other_films - fb.field_from_other_films).max() < 1e-12 * scale
+                assert np.count_nonzero(fa.field_from_other_films) == len(fa.field_from_other_films)   # every row filled in
+
+
+@pytest.mark.gpu
 def test_chain_streams_are_calibrated():
     """The panel chains of the factorization schedules run on the streams the library measured as cheap to launch on
     beside the stream of the trailing updates (chain_streams.hip): after a factorization the costs are known, the
