@@ -17,7 +17,10 @@ def run(dtype):
     import superscreen_amd as sc
     from superscreen_amd import synthetic
 
-    device = synthetic.make_stack_device(91, ("washer", "disk"), solve_dtype=dtype)
+    if dtype == "stack4":   # the 4-film stack of config 5 (float64)
+        device = synthetic.make_stack_device(100, ("disk",) * 4, solve_dtype="float64")
+    else:
+        device = synthetic.make_stack_device(91, ("washer", "disk"), solve_dtype=dtype)
     for _ in range(2):
         model = sc.factorize_model(device=device, current_units="uA")
         torch.cuda.synchronize()
@@ -31,7 +34,8 @@ def analyse(d):
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     rows.sort(key=lambda r: r["s"])
     asm = [i for i, r in enumerate(rows) if "system_assemble" in r["Kernel_Name"]]
-    rows = rows[asm[-2]:]          # the last factorization (two films: two assemblies)
+    nf = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    rows = rows[asm[-nf]:]         # the last factorization (one assembly per film)
     t0 = rows[0]["s"]
     byq = collections.defaultdict(list)
     for r in rows:
@@ -57,14 +61,22 @@ def analyse(d):
     if syrk:
         busy = sum(r["e"] - r["s"] for r in syrk)
         print(f"SYRK launches {len(syrk)}, busy {busy / 1e6:.1f} ms, first {(syrk[0]['s'] - t0) / 1e6:.1f}, last end {(syrk[-1]['e'] - t0) / 1e6:.1f} ms")
-        uq = syrk[0]["Queue_Id"]
         span = rows[-1]["e"] - t0
-        win = 5_000_000
-        line = []
-        for w0 in range(0, span, win):
-            b = sum(max(0, min(r["e"] - t0, w0 + win) - max(r["s"] - t0, w0)) for r in byq[uq])
-            line.append(f"{100 * b / min(win, span - w0):.0f}")
-        print(f"update queue {uq} busy % per 5 ms window: " + " ".join(line))
+        win = 5_000_000 if span < 150_000_000 else 20_000_000
+        for uq in sorted({r["Queue_Id"] for r in syrk}):
+            line = []
+            for w0 in range(0, span, win):
+                b = sum(max(0, min(r["e"] - t0, w0 + win) - max(r["s"] - t0, w0)) for r in byq[uq])
+                line.append(f"{100 * b / min(win, span - w0):.0f}")
+            print(f"update queue {uq} busy % per {win // 1_000_000} ms window: " + " ".join(line))
+        # all SYRK launches together: how much of the time is at least one / how many run at once
+        ev = sorted([(r["s"], 1) for r in syrk] + [(r["e"], -1) for r in syrk])
+        depth, last, hist = 0, ev[0][0], collections.Counter()
+        for t, d in ev:
+            hist[depth] += t - last
+            depth, last = depth + d, t
+        print("SYRK launches in flight (ms): " + ", ".join(f"{k}: {v / 1e6:.1f}" for k, v in sorted(hist.items())))
+        uq = syrk[0]["Queue_Id"]
         other = collections.defaultdict(lambda: [0, 0, 0])
         for r in byq[uq]:
             if r in syrk:
