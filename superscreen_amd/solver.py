@@ -1221,14 +1221,16 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                     xy_rows = cache.get("_xy_rows")
                     if xy_rows is None:
                         xy_rows = cache["_xy_rows"] = t.xy.index_select(0, rows).contiguous()
-                    compact = torch.zeros(rows.numel(), dtype=t.tdtype, device=t.device)
+                    compact = torch.empty(rows.numel(), dtype=t.tdtype, device=t.device)
+                    first = True
                     for src in films:
                         if src == tgt:
                             continue
                         s = model.film_data[src]
                         kernels.biot_savart(s.xy, s.w_t, results[src].J, xy_rows,
                                             film_info[tgt].z0 - film_info[src].z0, compact,
-                                            accumulate=True, src_begin=s.src_range[0], src_end=s.src_range[1])
+                                            accumulate=not first, src_begin=s.src_range[0], src_end=s.src_range[1])
+                        first = False
                     other_d[tgt].index_copy_(0, rows, compact)
             else:
                 for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
