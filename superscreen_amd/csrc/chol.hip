@@ -12,11 +12,14 @@
 // A non-positive pivot is reported through `info` (LAPACK ?potrf convention) and the host
 // falls back to the LU path (lu.hip).
 //
-// Factorization: 256-column outer panels.  Panel = one diagonal-block kernel (chol_diag.hpp: L11
+// Factorization: 256-column outer panels.  Panel = one diagonal-block kernel (chol_diag2.hpp: L11
 // and W = L11^-1) + L21 = A21 W^T as in-place MFMA GEMMs; trailing update = one MFMA SYRK with
-// K = 256 or 512; the panels run on two high-priority side streams per matrix beside the updates
-// (look-ahead: the diagonal recurrence on one, the strip and the rest of the panel on the other),
-// and the films of a device are factored in one interleaved schedule (potrf_batch).
+// K = 256 or 512.  The films of a device are factored in one interleaved schedule (potrf_batch) with two parts:
+// while the trailing matrices are large, the panels run on one high-priority side stream per matrix beside the
+// updates (look-ahead); once every trailing matrix is at most 10 240 columns -- where the panel chains set the
+// pace -- the rest runs as ROUNDS on the caller's stream alone: per round three batched launches for all films
+// (diagonal-block kernels as the first workgroups of a launch whose other workgroups are update tiles; panels;
+// next block columns: chol_tail.hpp), the finishing passes in slices beside them.
 //
 // Solve: the factor buffer ends up holding L below and L^T above the diagonal, and `aux` the
 // inverses (and their transposes) of the SNB x SNB diagonal blocks of L, so that both triangular
@@ -31,6 +34,7 @@
 #include "chain_streams.hpp"
 #include "chol_diag.hpp"
 #include "chol_diag2.hpp"
+#include "chol_tail.hpp"
 #include "common.hpp"
 
 namespace ssa {
@@ -73,10 +77,16 @@ int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float 
                      const float *B, int64_t ldb, double beta, float *C, int64_t ldc, int batch1,
                      int batch2, const int64_t *strides, int tri, hipStream_t st);
 
+int gemm_batched_sliced_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                            int64_t ldb, double beta, double *C, int64_t ldc, int batch1, int batch2, const int64_t *strides,
+                            int tri, int64_t kchunk, int64_t max_wgs, hipStream_t st);
+int gemm_batched_sliced_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
+                            int64_t ldb, double beta, float *C, int64_t ldc, int batch1, int batch2, const int64_t *strides,
+                            int tri, int64_t kchunk, int64_t max_wgs, hipStream_t st);
+
 namespace {
 
 constexpr int CNB = 256;  // outer panel
-constexpr int CPW = 64;   // sub-panel
 
 inline int gemm_op_t(int oa, int ob, int lower, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
                      int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
@@ -142,6 +152,33 @@ inline int gemm_batched_t(int64_t M, int64_t N, int64_t K, double alpha, const f
                           const int64_t *strides, int tri, hipStream_t st) {
     return gemm_batched_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, st);
 }
+// the same product in slices (gemm.hip): small grids, K in chunks -- beside latency-critical launches of another stream
+// (grids of 128 / 64 workgroups: 99 / 105.5 ms against 95.7 ms for config H -- the passes then outlast the rounds;
+// 512: no better; chunks of 256: + 0.5 ms)
+constexpr int64_t kSliceK = 512, kSliceWgs = 256;
+inline int gemm_sliced_t(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                         int64_t ldb, double beta, double *C, int64_t ldc, int b1, int b2, const int64_t *strides, int tri,
+                         hipStream_t st) {
+    return gemm_batched_sliced_f64(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, kSliceK, kSliceWgs, st);
+}
+inline int gemm_sliced_t(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
+                         int64_t ldb, double beta, float *C, int64_t ldc, int b1, int b2, const int64_t *strides, int tri,
+                         hipStream_t st) {
+    return gemm_batched_sliced_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, kSliceK, kSliceWgs, st);
+}
+
+inline int small_batch_t(const double *, int n, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch_f64(n, jobs, st);
+}
+inline int small_batch_t(const float *, int n, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch_f32(n, jobs, st);
+}
+inline int tail_round_t(const double *, int n, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
+    return chol_tail_round_f64(n, jobs, exclusive, st);
+}
+inline int tail_round_t(const float *, int n, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
+    return chol_tail_round_f32(n, jobs, exclusive, st);
+}
 
 #ifndef SSA_SNB
 #define SSA_SNB 4096
@@ -160,9 +197,9 @@ inline AuxLayout aux_layout(int64_t n) {
     a.invT = a.nblk * SNB * SNB;
     a.tmp = 2 * a.nblk * SNB * SNB;
     a.scratch = a.tmp + a.nblk * (SNB * SNB / 4);
-    // scratch of the diagonal-block kernels: 4 x 64 x 64 (first form) / one register image per lower 16 x 16 tile of
-    // the 256 x 256 block (second form, chol_diag2.hpp: 34 816 elements)
-    a.total = a.scratch + (4 * CPW * CPW > cholk2::kScratchElems ? 4 * CPW * CPW : cholk2::kScratchElems);
+    // scratch of the diagonal-block kernel: one register image per lower 16 x 16 tile of the 256 x 256 block
+    // (chol_diag2.hpp: 34 816 elements)
+    a.total = a.scratch + cholk2::kScratchElems;
     return a;
 }
 
@@ -315,22 +352,11 @@ int chol_panel_diag(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     const int64_t n = J.n, lda = J.lda;
     T *scratch = J.aux + aux_layout(n).scratch;
     if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
-    {   // the tile-layout form (chol_diag2.hpp), both precisions
-        static DeviceFlags lds_flags2;
-        if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel<T>),
-                                            sizeof(cholk2::Smem<T>)}}) != SSA_OK)
-            return SSA_ERR_HIP;
-        hipLaunchKernelGGL((cholk2::chol_diag256_v2_kernel<T>), dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem<T>), s,
-                           J.A + k0 * (lda + 1), static_cast<int>(lda), chol_leaf(J, k0), static_cast<int>(SNB), scratch,
-                           J.info, static_cast<int>(k0 + 1));
-        SSA_RETURN_IF_LAUNCH_FAILED();
-        return SSA_OK;
-    }
-    static DeviceFlags lds_flags;
-    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&cholk::chol_diag256_kernel<T>),
-                                       sizeof(cholk::Ge64Smem<T>)}}) != SSA_OK)
+    static DeviceFlags lds_flags2;   // the tile-layout form (chol_diag2.hpp), both precisions
+    if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel<T>),
+                                        sizeof(cholk2::Smem<T>)}}) != SSA_OK)
         return SSA_ERR_HIP;
-    hipLaunchKernelGGL((cholk::chol_diag256_kernel<T>), dim3(1), dim3(256), sizeof(cholk::Ge64Smem<T>), s,
+    hipLaunchKernelGGL((cholk2::chol_diag256_v2_kernel<T>), dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem<T>), s,
                        J.A + k0 * (lda + 1), static_cast<int>(lda), chol_leaf(J, k0), static_cast<int>(SNB), scratch,
                        J.info, static_cast<int>(k0 + 1));
     SSA_RETURN_IF_LAUNCH_FAILED();
@@ -368,7 +394,7 @@ int mirror_columns(const CholJob<T> &J, int64_t c0, int64_t c1, hipStream_t st) 
 }
 
 template <typename T>
-int inverse_level(const CholJob<T> &J, int64_t h, bool second, int64_t j0, int64_t j1, hipStream_t st) {
+int inverse_level(const CholJob<T> &J, int64_t h, bool second, int64_t j0, int64_t j1, hipStream_t st, bool sliced = false) {
     if (j1 <= j0) return SSA_OK;
     const int64_t lda = J.lda;
     const AuxLayout al = aux_layout(J.n);
@@ -381,9 +407,12 @@ int inverse_level(const CholJob<T> &J, int64_t h, bool second, int64_t j0, int64
     const int nb = static_cast<int>(j1 - j0);
     if (!second) {
         const int64_t s1[6] = {pair_l, blk_l, pair_i, blk_i, pair_t, blk_t};
+        if (sliced) return gemm_sliced_t(h, h, h, 1.0, L + h * lda, lda, inv, SNB, 0.0, tmp, h, ppb, nb, s1, 1, st);
         return gemm_batched_t(h, h, h, 1.0, L + h * lda, lda, inv, SNB, 0.0, tmp, h, ppb, nb, s1, 1, st);
     }
     const int64_t s2[6] = {pair_i, blk_i, pair_t, blk_t, pair_i, blk_i};
+    if (sliced)
+        return gemm_sliced_t(h, h, h, -1.0, inv + h * (SNB + 1), SNB, tmp, h, 0.0, inv + h * SNB, SNB, ppb, nb, s2, 2, st);
     return gemm_batched_t(h, h, h, -1.0, inv + h * (SNB + 1), SNB, tmp, h, 0.0, inv + h * SNB, SNB, ppb, nb, s2, 2,
                           st);
 }
@@ -401,53 +430,61 @@ int inverse_transposes(const CholJob<T> &J, int64_t j0, int64_t j1, hipStream_t 
     return SSA_OK;
 }
 
-// The finishing passes of one matrix as a list of small steps (see above).  Steps [0, n_early) only
-// need the first `early_blocks` SNB blocks of L and are issued one per outer step during the
-// tail; the rest runs after the last panel.
+// The finishing passes of one matrix.  Full SNB blocks are finished in order as their columns become final
+// (run_blocks: inverse levels, inverse transposes, mirror of their columns -- beside the rounds of the schedule from
+// the matrix' low-priority stream, sliced); run_rest does what is left after the last panel.
 template <typename T>
 struct FinishPlan {
     const CholJob<T> *job = nullptr;
-    int64_t early_blocks = 0;  // full SNB blocks finished ahead of time
-    int next = 0, n_early = 0, n_total = 0;
+    int64_t done = 0;   // full SNB blocks whose solve-phase data have been issued
 
-    void init(const CholJob<T> *j, int64_t tail_cols) {
+    void init(const CholJob<T> *j) {
         job = j;
-        const AuxLayout al = aux_layout(j->n);
-        early_blocks = (j->n > tail_cols) ? (j->n - tail_cols) / SNB : 0;
-        if (early_blocks > al.nfull) early_blocks = al.nfull;
-        int levels = 0;
-        for (int64_t h = 256; h < SNB; h *= 2) ++levels;
-        n_early = (early_blocks > 0) ? 2 * levels + 1 + 4 : 0;
-        n_total = n_early + 2 * levels + 1 + 1 + 1;
-        next = 0;
+        done = 0;
     }
-    // columns of L that are final once the first early_blocks blocks are factored
-    int64_t early_cols() const { return early_blocks * SNB; }
+    int64_t nfull() const { return job->n / SNB; }
+    bool finished() const { return done < 0; }
 
-    int run_step(int step, hipStream_t st) const {
+    int run_blocks(int64_t upto, bool sliced, hipStream_t st) {
+        const CholJob<T> &J = *job;
+        if (upto > nfull()) upto = nfull();
+        if (upto <= done) return SSA_OK;
+        int rc;
+        for (int64_t h = 256; h < SNB; h *= 2) {
+            rc = inverse_level(J, h, false, done, upto, st, sliced);
+            if (rc != SSA_OK) return rc;
+            rc = inverse_level(J, h, true, done, upto, st, sliced);
+            if (rc != SSA_OK) return rc;
+        }
+        rc = inverse_transposes(J, done, upto, st);
+        if (rc != SSA_OK) return rc;
+        rc = mirror_columns(J, done * SNB, upto * SNB, st);
+        if (rc != SSA_OK) return rc;
+        done = upto;
+        return SSA_OK;
+    }
+    int run_rest(bool sliced, hipStream_t st) {
         const CholJob<T> &J = *job;
         const AuxLayout al = aux_layout(J.n);
-        int levels = 0;
-        for (int64_t h = 256; h < SNB; h *= 2) ++levels;
-        auto level_h = [](int l) { return int64_t(256) << l; };
-        if (step < n_early) {
-            if (step < 2 * levels) return inverse_level(J, level_h(step / 2), step % 2 == 1, 0, early_blocks, st);
-            if (step == 2 * levels) return inverse_transposes(J, 0, early_blocks, st);
-            const int q = step - 2 * levels - 1;  // the early columns of L in four pieces
-            const int64_t per = ceil_div(early_cols() / 64, 4) * 64;
-            const int64_t c0 = q * per, c1 = (c0 + per < early_cols()) ? c0 + per : early_cols();
-            return mirror_columns(J, c0, c1, st);
+        const int64_t first = done;
+        int rc = SSA_OK;
+        for (int64_t h = 256; h < SNB; h *= 2) {
+            rc = inverse_level(J, h, false, first, al.nfull, st, sliced);
+            if (rc != SSA_OK) return rc;
+            rc = inverse_level(J, h, true, first, al.nfull, st, sliced);
+            if (rc != SSA_OK) return rc;
         }
-        const int t = step - n_early;
-        if (t < 2 * levels) return inverse_level(J, level_h(t / 2), t % 2 == 1, early_blocks, al.nfull, st);
-        if (t == 2 * levels) {  // the last, partial block
-            if (J.n % SNB == 0) return SSA_OK;
+        if (J.n % SNB != 0) {  // the last, partial block
             const int64_t r0 = al.nfull * SNB;
-            return build_block_inverse(J.A, J.lda, r0, J.n - r0, J.aux + al.inv + al.nfull * SNB * SNB, SNB,
-                                       J.aux + al.tmp + al.nfull * (SNB * SNB / 4), st);
+            rc = build_block_inverse(J.A, J.lda, r0, J.n - r0, J.aux + al.inv + al.nfull * SNB * SNB, SNB,
+                                     J.aux + al.tmp + al.nfull * (SNB * SNB / 4), st);
+            if (rc != SSA_OK) return rc;
         }
-        if (t == 2 * levels + 1) return inverse_transposes(J, early_blocks, al.nblk, st);
-        return mirror_columns(J, early_cols(), J.n, st);
+        rc = inverse_transposes(J, first, al.nblk, st);
+        if (rc != SSA_OK) return rc;
+        rc = mirror_columns(J, first * SNB, J.n, st);
+        done = -1;
+        return rc;
     }
 };
 
@@ -466,13 +503,24 @@ struct FinishPlan {
 //                                rest    C[256:, 256:] -= P2 P2^T  (lower)    (caller's stream; for a large
 //                                        trailing matrix every other step: P = the last two panels, K = 512)
 //
-// The chain is ONE stream per matrix.  Rounds 2 and 3 ran it as two (diagonal block -> diagonal-block kernel ->
-// first block row on one, strip and the rest of the panel one step behind on a second: a look-ahead inside the
-// chain), with up to six hand-offs per round between the three streams of a matrix.  With the diagonal-block kernel
-// of round 3 that no longer pays: a dependent launch on the same stream costs 1-5 us, a hand-off between streams
-// 25-130 us once four or more queues are active (tools/probes/gap_probe.hip, profiles/r03_gap_probe.txt), and the
-// one-stream chain is as fast or faster on every configuration (config H 100.0 vs 101.3 ms, float32 57.8 vs 60.1,
-// four films 360 vs 364, one film 408.9 vs 407.4 ms).
+// The chain is ONE stream per matrix (rounds 2 and 3 ran it as two, with up to six hand-offs per round; a dependent
+// launch on the same stream costs 1-5 us, a hand-off between streams 25-130 us once four or more queues are active:
+// tools/probes/gap_probe.hip, profiles/r03_gap_probe.txt).
+//
+// ROUNDS (round 4).  In the last third of a factorization an update takes less time than a round of a chain
+// (0.3-0.5 ms beside running updates: the diagonal-block kernel shares its CU's vector ALUs with an update
+// workgroup, its products wait for workgroup slots), the update stream idles and the schedule depends on which
+// hardware queue the chains got.  From there on every film advances one panel per round and a round is three
+// launches on the caller's stream, no events, no side streams:
+//     round launch   workgroups 0 .. films-1: diagonal-block kernel of block c of each film; the others: the pending
+//                    panel(s) onto the lower tiles BEHIND block column c -- the update the diagonal block does not
+//                    need runs under it.  With few tiles the launch asks for a CU per workgroup: the diagonal-block
+//                    kernel then takes the 175 us it takes alone;
+//     panel launch   L21 = A21 W^T of all films, one workgroup per 32 rows;
+//     strip launch   block column c + 256 of all films -= the new panel (it has the older ones from the round launch).
+// A chain-bound round is 235 us (175 + 25 + 29 + launch gaps) against 300-570 us for a round of a chain of the stream
+// schedule.  The finishing passes of the blocks that are final ride beside the chain-bound rounds on the films'
+// low-priority streams, in slices (gemm_batched_sliced) so that the rounds' launches always find free slots.
 template <typename T>
 int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
@@ -488,15 +536,29 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // others (4 x 30 301-vertex stack: 350 -> 317 ms; two matrices: no gain, 156.6 vs 158.7 ms, so they keep the
     // single stream).
     const bool split_updates = count >= 3;
-    // outer steps (per matrix) that are chain bound: the early finishing steps are slipped into the last 16 of them
-    constexpr int64_t kTailCols = 4096;
+    // Once the trailing matrix of EVERY film is at most this order the schedule is bound by the panel chains (a
+    // round of a chain takes 0.3-0.5 ms beside running updates, an update of that size less): the rest of the
+    // factorization runs as single-stream rounds of batched launches (see the loop below).
+    // (round 4, same-box runs: config H float64 99.5 / 97.0 / 96.8 / 95.9 / 96.9 / 99.2 / 101.3 ms for 0 / 6144 / 8192 /
+    // 10240 / 12288 / 16384 / all columns, float32 57.7 -> 52.6, K = 81 60.8 -> 54.8, one film K = 64 18.0 -> 15.1,
+    // K = 129 407 -> 405, four films 361 -> 350 ms.  Larger: the rounds' panel and strip launches are not hidden
+    // behind an update the way the chains' are)
+    constexpr int64_t tail_round_cols = 10240;
+    // a round launch with at most this many update tiles asks for a CU per workgroup (chain-bound rounds: the
+    // diagonal-block workgroups then run alone on their CUs, 175 us instead of 220-300; 0 / 2500: + 0.5 ms)
+    constexpr int64_t tail_excl_tiles = 1024;
+    // the finishing passes of the blocks that are final go out beside the rounds once a round has at most this many
+    // update tiles (before that the rounds are update bound and the passes would only lengthen them; 800 / 3000 /
+    // always: the same within 0.5 ms, never: + 3 ms)
+    constexpr int64_t fill_tiles = 1500;
     FinishPlan<T> plans[kMaxLanes];
     int64_t nmax = 0;
     for (int i = 0; i < count; ++i) {
         const CholJob<T> &J = jobs[i];
         CholLane &ln = lanes[i];
-        plans[i].init(&jobs[i], kTailCols);
+        plans[i].init(&jobs[i]);
         if (J.n % CNB != 0) return SSA_ERR_INVALID_ARGUMENT;  // callers pad (potrf_padded_batch)
+        if (J.lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside a diagonal block
         if (J.n > nmax) nmax = J.n;
         if (hipMemsetAsync(J.info, 0, sizeof(int32_t), st) != hipSuccess ||
             hipMemsetAsync(J.aux, 0, static_cast<size_t>(aux_layout(J.n).tmp) * sizeof(T), st) != hipSuccess)
@@ -513,6 +575,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     }
     bool detached[kMaxLanes] = {};
     bool updated[kMaxLanes] = {};      // a trailing update of this matrix has been issued (ev_syrk is recorded)
+    bool on_finish[kMaxLanes] = {};    // finishing steps of this matrix have gone to its low-priority stream
     int64_t pending_from[kMaxLanes] = {};
     // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
@@ -521,38 +584,130 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 16384: flat within 1 %, rounds 2 and 3)
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
+    bool in_rounds = false;
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
+        const int64_t c = k0 + CNB;   // first column of the next panel
+        // ---- films that have run out of panels while others still have some: their remaining finishing steps go to
+        // their own low-priority stream, behind their last panel and behind what their update stream holds for them
         for (int i = 0; i < count; ++i) {
             const CholJob<T> &J = jobs[i];
             CholLane &ln = lanes[i];
-            if (k0 + CNB >= J.n) {
-                // this (smaller) matrix has no panels left while others are still in their chain-bound
-                // tail: its remaining finishing steps go to its own low-priority stream, behind its last
-                // panel and behind what the caller's stream holds for it so far
-                if (!detached[i]) {
-                    detached[i] = true;
-                    if (hipEventRecord(ln.ev_fork, cur_us[i]) != hipSuccess ||
-                        hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess ||
-                        hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess)
-                        return SSA_ERR_HIP;
-                    FinishPlan<T> &fp = plans[i];
-                    while (fp.next < fp.n_total) {
-                        rc = fp.run_step(fp.next++, ln.finish);
-                        if (rc != SSA_OK) return rc;
-                    }
-                    if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
-                }
-                continue;
+            if (c < J.n || detached[i]) continue;
+            detached[i] = true;
+            if (hipEventRecord(ln.ev_fork, cur_us[i]) != hipSuccess || hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess ||
+                hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess)
+                return SSA_ERR_HIP;
+            rc = plans[i].run_rest(in_rounds, ln.finish);   // (beside rounds: in slices)
+            if (rc != SSA_OK) return rc;
+            if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
+            on_finish[i] = true;
+        }
+        // ---- switch to single-stream rounds: the chains and update streams join the caller's stream, and the next
+        // block column of every film takes its pending panels (what the chain's first product of a step does)
+        if (!in_rounds && tail_round_cols > 0 && nmax - c <= tail_round_cols) {
+            SmallNtJob strips[kMaxLanes];
+            int ns = 0;
+            for (int i = 0; i < count; ++i) {
+                const CholJob<T> &J = jobs[i];
+                CholLane &ln = lanes[i];
+                if (c >= J.n) continue;
+                if (hipStreamWaitEvent(st, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+                if (cur_us[i] != st && (hipEventRecord(ln.ev_upd, cur_us[i]) != hipSuccess ||
+                                        hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess))
+                    return SSA_ERR_HIP;
+                cur_us[i] = st;
+                const int64_t upd0 = pending_from[i], right = J.n - c;
+                const T *P = J.A + c * J.lda + upd0;
+                strips[ns++] = SmallNtJob{P, P, nullptr, J.A + c * J.lda + c, J.lda, J.lda, J.lda, right, CNB, c - upd0,
+                                          -1.0, 1.0, 0};
             }
-            const int64_t right = J.n - k0 - CNB;             // order of the trailing matrix
+            rc = small_batch_t(static_cast<const T *>(nullptr), ns, strips, st);
+            if (rc != SSA_OK) return rc;
+            in_rounds = true;
+        }
+        if (in_rounds) {
+            // ---- one round of every film on the caller's stream.  State of a film at this point: block column c has
+            // every earlier panel applied, the trailing matrix behind it every panel before pending_from.
+            //   round launch: diagonal-block kernel of block c (first workgroups of the launch)  |  the pending panels
+            //                 onto the lower tiles of A[c + 256:, c + 256:] (the other workgroups)
+            //   panel launch: L21 = A21 W^T, one workgroup per 32 rows
+            //   strip launch: block column c + 256 -= L21 L21[0:256]^T
+            TailRoundJob rj[kMaxLanes];
+            SmallNtJob pj[kMaxLanes], sj[kMaxLanes];
+            int nr = 0, np = 0;
+            int64_t tiles = 0;
+            for (int i = 0; i < count; ++i) {
+                const CholJob<T> &J = jobs[i];
+                if (c >= J.n) continue;
+                const int64_t below = J.n - c - CNB;   // rows under the diagonal block = order of what is behind it
+                const int64_t upd0 = pending_from[i];
+                T *A21 = J.A + (c + CNB) * J.lda + c;
+                TailRoundJob &r = rj[nr++];
+                r.D = J.A + c * (J.lda + 1);
+                r.W = chol_leaf(J, c);
+                r.scratch = J.aux + aux_layout(J.n).scratch;
+                r.info = J.info;
+                r.lda = static_cast<int>(J.lda);
+                r.ldw = static_cast<int>(SNB);
+                r.col1 = static_cast<int>(c + 1);
+                r.has_diag = 1;
+                r.C = J.A + (c + CNB) * (J.lda + 1);
+                r.P = J.A + (c + CNB) * J.lda + upd0;
+                r.ldc = J.lda;
+                r.M = below;
+                r.K = c - upd0;
+                tiles += (below / 128) * (below / 128 + 1) / 2;
+                pending_from[i] = c;
+                if (below <= 0) continue;
+                const T *W = chol_leaf(J, c);
+                pj[np] = SmallNtJob{A21, W, W + 128 * SNB, A21, J.lda, SNB, J.lda, below, CNB, CNB, 1.0, 0.0, 1};
+                sj[np] = SmallNtJob{A21, A21, nullptr, A21 + CNB, J.lda, J.lda, J.lda, below, CNB, CNB, -1.0, 1.0, 0};
+                ++np;
+            }
+            rc = tail_round_t(static_cast<const T *>(nullptr), nr, rj, tiles <= tail_excl_tiles ? 1 : 0, st);
+            if (rc != SSA_OK) return rc;
+            rc = small_batch_t(static_cast<const T *>(nullptr), np, pj, st);
+            if (rc != SSA_OK) return rc;
+            rc = small_batch_t(static_cast<const T *>(nullptr), np, sj, st);
+            if (rc != SSA_OK) return rc;
+            // the finishing passes of a film's blocks that are final (all their columns lie left of c) fill the chip
+            // beside the chain-bound rounds from the film's low-priority stream: in slices, so that no launch of theirs
+            // holds more than a quarter of the chip's workgroup slots or a slot for longer than a round takes
+            if (tiles <= fill_tiles) {
+                for (int i = 0; i < count; ++i) {
+                    FinishPlan<T> &fp = plans[i];
+                    CholLane &ln = lanes[i];
+                    const int64_t ready = c / SNB;
+                    if (detached[i] || fp.finished() || ready <= fp.done || fp.done >= fp.nfull()) continue;
+                    if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess)
+                        return SSA_ERR_HIP;
+                    rc = fp.run_blocks(ready, true, ln.finish);
+                    if (rc != SSA_OK) return rc;
+                    if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
+                    on_finish[i] = true;
+                }
+            }
+            continue;
+        }
+        // ---- body: panel chains on side streams beside the updates
+        for (int i = 0; i < count; ++i) {
+            const CholJob<T> &J = jobs[i];
+            CholLane &ln = lanes[i];
+            if (c >= J.n) continue;
+            const int64_t right = J.n - c;                    // order of the trailing matrix
             hipStream_t us = cur_us[i];                       // where this matrix' trailing updates run
             hipStream_t cs = ln.side;                         // the matrix' panel chain
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
-            const int64_t c = k0 + CNB;
             // panels that the trailing matrix has not seen yet: everything after the last trailing update
             const int64_t upd0 = pending_from[i], kp = c - upd0;
             const T *P = J.A + c * J.lda + upd0;              // those panels, from the next diagonal block down
             T *C = J.A + c * J.lda + c;
+            // every other panel of a large trailing matrix keeps its update pending: the next one then
+            // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
+            // (the phase comes from the matrix' own size, not from its place in the batch: the result
+            // of a matrix does not depend on what else is factored with it)
+            const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
+                               ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
             // the chain: pending panels onto the next block column (behind the last trailing update of THIS matrix,
             // which wrote that column), diagonal-block kernel, the panel below it
@@ -566,12 +721,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 if (rc != SSA_OK) return rc;
             }
             if (hipEventRecord(ln.ev_panel, cs) != hipSuccess) return SSA_ERR_HIP;
-            // every other panel of a large trailing matrix keeps its update pending: the next one then
-            // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
-            // (the phase comes from the matrix' own size, not from its place in the batch: the result
-            // of a matrix does not depend on what else is factored with it)
-            const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
-                               ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
             if (right > nw && !delay) {  // rest of the trailing update: lower tiles behind the next panel's block column
                 const int64_t rstart = c + nw, M = J.n - rstart;
                 const T *P2 = J.A + rstart * J.lda + upd0;
@@ -580,29 +729,20 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 if (hipEventRecord(ln.ev_syrk, us) != hipSuccess) return SSA_ERR_HIP;
                 updated[i] = true;
             }
-            if (!delay) pending_from[i] = k0 + CNB;
-            // one early finishing step per outer step once its inputs (panels <= k, which this
-            // stream has waited for) are final: fills the slots where the stream waits for the chain
-            FinishPlan<T> &fp = plans[i];
-            if (fp.next < fp.n_early && k0 + CNB >= fp.early_cols()) {
-                rc = fp.run_step(fp.next++, us);
-                if (rc != SSA_OK) return rc;
-            }
+            if (!delay) pending_from[i] = c;
         }
     }
     for (int i = 0; i < count; ++i) {  // join, then the inverses of the diagonal blocks
-        if (hipStreamWaitEvent(st, detached[i] ? lanes[i].ev_finish : lanes[i].ev_panel, 0) != hipSuccess)
-            return SSA_ERR_HIP;
+        if (!in_rounds && hipStreamWaitEvent(st, lanes[i].ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+        if (on_finish[i] && hipStreamWaitEvent(st, lanes[i].ev_finish, 0) != hipSuccess) return SSA_ERR_HIP;
         if (cur_us[i] != st && (hipEventRecord(lanes[i].ev_upd, cur_us[i]) != hipSuccess ||
                                 hipStreamWaitEvent(st, lanes[i].ev_upd, 0) != hipSuccess))
             return SSA_ERR_HIP;
     }
     for (int i = 0; i < count; ++i) {
-        FinishPlan<T> &fp = plans[i];
-        while (fp.next < fp.n_total) {
-            rc = fp.run_step(fp.next++, st);
-            if (rc != SSA_OK) return rc;
-        }
+        if (plans[i].finished()) continue;
+        rc = plans[i].run_rest(false, st);
+        if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
 }

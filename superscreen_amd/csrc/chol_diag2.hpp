@@ -205,6 +205,13 @@ constexpr TriTable kTri{};
 // layout makes every wave-instruction touch 16 rows x 32 bytes: the panel loads, the updates right of a panel and
 // the inversion ran at 3-6 times their MFMA time on exactly those accesses.)
 __device__ __forceinline__ int img_of(int I, int K) { return (I * (I + 1) / 2 + K) * 256; }
+// image of the L tile of product k of block column c of the inversion (row c + u, column c + v).  The prefetch ring
+// runs ahead of the products that exist for a column (rows past the last tile row): those requests are clamped to
+// a tile INSIDE the scratch (row and column; the values are never used).
+__device__ __forceinline__ int tri_img(int c, int k) {
+    const int I = min(c + kTriU[k], NT - 1);
+    return img_of(I, min(c + kTriV[k], I));
+}
 
 // Workgroup barrier for data handed over through LDS: the LDS stores of this wave have completed, loads and stores to
 // global memory stay in flight (__syncthreads() would also wait for the acknowledgement of every global store:
@@ -290,10 +297,12 @@ __device__ __forceinline__ void chol16inv(Tile<T> &d, Tile<T> &w, bool &bad, int
 #define CHOLK2_STAMP(i) do { } while (0)
 #define CHOLK2_TIMING_ARG
 #endif
+// The body is a device function: the stand-alone kernel below runs it as a launch of its own (panel chains of the
+// stream schedule), the tail rounds of the factorization run it as the first workgroups of a launch whose other
+// workgroups are trailing-update tiles (gemm_ops.hip, chol_tail_round_kernel).
 template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int lda, T *W, int ldw, T *scratch,
-                                                                     int32_t *info, int col1 CHOLK2_TIMING_ARG) {
-    extern __shared__ __attribute__((aligned(16))) char cholk2_smem_raw[];
+__device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ldw, T *scratch, int32_t *info, int col1,
+                                                     char *cholk2_smem_raw CHOLK2_TIMING_ARG) {
     Smem<T> &sm = *reinterpret_cast<Smem<T> *>(cholk2_smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __builtin_amdgcn_s_setprio(3);
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int 
         constexpr int kRing = 8;
         Tile<T> Q[kRing];
 #pragma unroll
-        for (int k = 0; k < kRing; ++k) Q[k] = image_load<T>(scratch + img_of(min(c + kTriU[k], NT - 1), c + kTriV[k]), lane);
+        for (int k = 0; k < kRing; ++k) Q[k] = image_load<T>(scratch + tri_img(c, k), lane);
 #pragma unroll
         for (int u = 1; u < NT; ++u) {
             if (c + u < NT) {
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int 
                     const int k = u * (u - 1) / 2 + v;
                     const Tile<T> l = Q[k % kRing];
                     if (k + kRing < kTriCount)
-                        Q[k % kRing] = image_load<T>(scratch + img_of(min(c + kTriU[k + kRing], NT - 1), c + kTriV[k + kRing]), lane);
+                        Q[k % kRing] = image_load<T>(scratch + tri_img(c, k + kRing), lane);
                     if (v & 1) acc1 = mma_xyT<T>(acc1, U[v], l);
                     else acc0 = mma_xyT<T>(acc0, U[v], l);
                 }
@@ -483,6 +492,18 @@ __global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int 
     }
     __syncthreads();
     CHOLK2_STAMP(15);
+}
+
+#ifdef CHOLK2_TIMING
+#define CHOLK2_TIMING_PASS , tstamp
+#else
+#define CHOLK2_TIMING_PASS
+#endif
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int lda, T *W, int ldw, T *scratch,
+                                                                     int32_t *info, int col1 CHOLK2_TIMING_ARG) {
+    extern __shared__ __attribute__((aligned(16))) char cholk2_smem_raw[];
+    chol_diag256_v2_body<T>(D, lda, W, ldw, scratch, info, col1, cholk2_smem_raw CHOLK2_TIMING_PASS);
 }
 
 }  // namespace cholk2

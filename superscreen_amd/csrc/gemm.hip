@@ -519,6 +519,86 @@ int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float 
 }
 
 
+// ---- a batched product in SLICES: the same tiles as gemm_kernel's two-level batch, launched as many small grids
+// (at most `max_wgs` workgroups each) and with the K range cut into chunks of `kchunk` (a later chunk accumulates
+// onto the earlier ones: the launches of one stream are ordered, and the sum over k runs in the same order as in
+// the unsliced product, so the result is bit-identical).  For work that fills the chip beside latency-critical
+// launches of another stream (the finishing passes of the Cholesky schedule beside its single-stream rounds,
+// chol.hip): no launch holds more than max_wgs workgroup slots, and no workgroup lives longer than kchunk / 16
+// LDS stages.  Aligned full tiles only (M, N multiples of 128, K ranges multiples of 32).
+struct SliceArgs {
+    int64_t lin0;       // first linear id (tile + tiles_per_matrix * (y + batch1 * z)) of this launch
+    int64_t kc0, kc1;   // k chunk
+    int batch1;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_slice_kernel(
+    int64_t K, T alpha, const T *__restrict__ A, int64_t lda, const T *__restrict__ B, int64_t ldb, T beta,
+    T *__restrict__ C, int64_t ldc, int64_t ntm, int64_t ntn, BatchStrides bs, SliceArgs sl) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int64_t lin = sl.lin0 + blockIdx.x, per = ntm * ntn;
+    const int64_t yz = lin / per, y = yz % sl.batch1, z = yz / sl.batch1;
+    A += y * bs.a1 + z * bs.a2;
+    B += y * bs.b1 + z * bs.b2;
+    C += y * bs.c1 + z * bs.c2;
+    int64_t tm, tn;
+    remap_tile(lin % per, ntm, ntn, tm, tn);
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    int64_t kb = 0, ke = K;   // the tile's own K range (BatchStrides)
+    if (bs.tri == 1) kb = (n0 < K) ? n0 : K;
+    else if (bs.tri == 2) ke = (m0 + BM < K) ? m0 + BM : K;
+    else if (bs.tri == 3) ke = (n0 + BN < K) ? n0 + BN : K;
+    else if (bs.tri == 4) kb = (m0 < K) ? m0 : K;
+    const int64_t cb = kb > sl.kc0 ? kb : sl.kc0, ce = ke < sl.kc1 ? ke : sl.kc1;
+    if (ce <= cb) return;
+    const T beta_eff = (cb == kb) ? beta : T(1);
+    if constexpr (sizeof(T) == 8)
+        gemm_tile_full_f64(ce - cb, alpha, A + cb, lda, B + cb * ldb, ldb, beta_eff, C, ldc, m0, n0, smem_raw);
+    else
+        gemm_tile_full_f32(ce - cb, alpha, A + cb, lda, B + cb * ldb, ldb, beta_eff, C, ldc, m0, n0, smem_raw);
+}
+
+template <typename T>
+int gemm_batched_sliced(int64_t M, int64_t N, int64_t K, double alpha, const T *A, int64_t lda, const T *B, int64_t ldb,
+                        double beta, T *C, int64_t ldc, int batch1, int batch2, const int64_t *strides, int tri,
+                        int64_t kchunk, int64_t max_wgs, hipStream_t st) {
+    if (M <= 0 || N <= 0 || batch1 <= 0 || batch2 <= 0) return SSA_OK;
+    const BatchStrides bs{strides[0], strides[1], strides[2], strides[3], strides[4], strides[5], tri};
+    const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0) &&
+                         ((lda * sizeof(T)) % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0) &&
+                         ((bs.a1 * sizeof(T)) % 16 == 0) && ((bs.a2 * sizeof(T)) % 16 == 0) &&
+                         ((bs.b1 * sizeof(T)) % 16 == 0) && ((bs.b2 * sizeof(T)) % 16 == 0);
+    if (!aligned || M % BM != 0 || N % BN != 0 || K % BN != 0 || kchunk <= 0 || kchunk % BN != 0 || max_wgs <= 0 || alpha == 0.0)
+        return launch_gemm<T>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, batch1, batch2, bs);
+    const size_t smem = (sizeof(T) == 4 && sizeof(FullSmemF32) > sizeof(GemmSmem<T>)) ? sizeof(FullSmemF32) : sizeof(GemmSmem<T>);
+    static DeviceFlags lds_flags;
+    if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&gemm_slice_kernel<T>), smem}}) != SSA_OK) return SSA_ERR_HIP;
+    const int64_t ntm = M / BM, ntn = N / BN, total = ntm * ntn * batch1 * batch2;
+    for (int64_t kc0 = 0; kc0 < K; kc0 += kchunk) {
+        for (int64_t lin0 = 0; lin0 < total; lin0 += max_wgs) {
+            const int64_t nwg = (total - lin0 < max_wgs) ? total - lin0 : max_wgs;
+            hipLaunchKernelGGL((gemm_slice_kernel<T>), dim3(static_cast<unsigned>(nwg)), dim3(kGemmThreads), smem, st, K,
+                               static_cast<T>(alpha), A, lda, B, ldb, static_cast<T>(beta), C, ldc, ntm, ntn, bs,
+                               SliceArgs{lin0, kc0, kc0 + kchunk, batch1});
+            SSA_RETURN_IF_LAUNCH_FAILED();
+        }
+    }
+    return SSA_OK;
+}
+int gemm_batched_sliced_f64(int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda, const double *B,
+                            int64_t ldb, double beta, double *C, int64_t ldc, int batch1, int batch2, const int64_t *strides,
+                            int tri, int64_t kchunk, int64_t max_wgs, hipStream_t st) {
+    return gemm_batched_sliced<double>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, batch1, batch2, strides, tri, kchunk,
+                                       max_wgs, st);
+}
+int gemm_batched_sliced_f32(int64_t M, int64_t N, int64_t K, double alpha, const float *A, int64_t lda, const float *B,
+                            int64_t ldb, double beta, float *C, int64_t ldc, int batch1, int batch2, const int64_t *strides,
+                            int tri, int64_t kchunk, int64_t max_wgs, hipStream_t st) {
+    return gemm_batched_sliced<float>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, batch1, batch2, strides, tri, kchunk,
+                                      max_wgs, st);
+}
+
 // ---- split-K for skinny products (multi-right-hand-side triangular solves: M x 128 outputs give only
 // M / 128 tiles, far fewer than 256 CUs).  The K range is cut into `splits` pieces computed as one
 // batched launch into `partial` (splits x M x N, ld = N), then reduced: C = alpha * sum + beta * C.

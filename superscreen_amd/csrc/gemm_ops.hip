@@ -10,6 +10,8 @@
 //   K-MINOR  (m|n contiguous: A for op T, B for op N) [16][128 + 16]
 // so NT (SYRK: both operands are row panels of the same matrix) uses two K-MAJOR images and TN
 // (backward substitution with L^T on many right-hand sides) two K-MINOR images.
+#include "chol_diag2.hpp"
+#include "chol_tail.hpp"
 #include "gemm_profile.hpp"
 #include "mfma_traits.hpp"
 
@@ -453,6 +455,34 @@ __device__ __forceinline__ void tile_edge(int64_t M, int64_t N, int64_t K, T alp
     }
 }
 
+// Lower-triangular tile enumeration in bands of 8 tile rows, column by column inside a band: 64 consecutive
+// ids (= what one XCD runs at a time) touch 8 row blocks + 8 column blocks of the panel (4 MB at K = 256, the
+// size of the XCD's L2) instead of 1 + 64.  Measured with FETCH_SIZE: row-by-row order re-read the panel ~60x
+// through the fabric.  id in [0, ntm (ntm + 1) / 2) -> tile (tm, tn), tn <= tm < ntm.
+__device__ __forceinline__ void lower_band_tile(int64_t id, int64_t ntm, int64_t &tm, int64_t &tn) {
+    constexpr int64_t G = 8;
+    // band b starts at id 8b (8b + 1) / 2
+    int64_t b = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5) / G;
+    while (G * b * (G * b + 1) / 2 > id) --b;
+    while (G * (b + 1) * (G * (b + 1) + 1) / 2 <= id) ++b;
+    const int64_t r0 = G * b;
+    const int64_t R = (ntm - r0 < G) ? ntm - r0 : G;  // tile rows in this band
+    int64_t l = id - r0 * (r0 + 1) / 2;
+    if (l < r0 * R) {  // full columns left of the band's diagonal blocks
+        tn = l / R;
+        tm = r0 + l % R;
+    } else {
+        l -= r0 * R;
+        int64_t j = 0;
+        while (l >= R - j) {  // column r0 + j holds rows r0 + j .. r0 + R - 1
+            l -= R - j;
+            ++j;
+        }
+        tn = r0 + j;
+        tm = r0 + j + l;
+    }
+}
+
 // LOWER is a template parameter so that the SYRK-shaped launches carry their own symbol in
 // rocprofv3's kernel statistics (profiles/), apart from the skinny in-panel updates.
 template <typename T, int TA, int TB, bool LOWER>
@@ -464,32 +494,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_op_kernel(
     int64_t tm, tn;
     if constexpr (!LOWER) __builtin_amdgcn_s_setprio(2);   // strips and panel products of the chains (see gemm_nt_small_kernel)
     if constexpr (LOWER) {
-        // Lower-triangular tile enumeration in bands of 8 tile rows, column by column inside a
-        // band: 64 consecutive ids (= what one XCD runs at a time) touch 8 row blocks + 8 column
-        // blocks of the panel (4 MB at K = 256, the size of the XCD's L2) instead of 1 + 64.
-        // Measured with FETCH_SIZE: row-by-row order re-read the panel ~60x through the fabric.
-        const int64_t id = xcd_contiguous(blockIdx.x, gridDim.x);
-        constexpr int64_t G = 8;
-        // band b starts at id 8b (8b + 1) / 2
-        int64_t b = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(id) + 1.0) - 1.0) * 0.5) / G;
-        while (G * b * (G * b + 1) / 2 > id) --b;
-        while (G * (b + 1) * (G * (b + 1) + 1) / 2 <= id) ++b;
-        const int64_t r0 = G * b;
-        const int64_t R = (ntm - r0 < G) ? ntm - r0 : G;  // tile rows in this band
-        int64_t l = id - r0 * (r0 + 1) / 2;
-        if (l < r0 * R) {  // full columns left of the band's diagonal blocks
-            tn = l / R;
-            tm = r0 + l % R;
-        } else {
-            l -= r0 * R;
-            int64_t j = 0;
-            while (l >= R - j) {  // column r0 + j holds rows r0 + j .. r0 + R - 1
-                l -= R - j;
-                ++j;
-            }
-            tn = r0 + j;
-            tm = r0 + j + l;
-        }
+        lower_band_tile(xcd_contiguous(blockIdx.x, gridDim.x), ntm, tm, tn);
     } else {
         const int64_t wg = xcd_contiguous(blockIdx.x, ntm * ntn);
         constexpr int64_t G = 8;
@@ -576,6 +581,163 @@ int gemm_op(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double
     if (opA == OP_N && opB == OP_N)
         return launch_op<T, OP_N, OP_N>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, st);
     return launch_op<T, OP_T, OP_T>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, st);
+}
+
+
+// ---- batched launches of the single-stream rounds of the Cholesky schedule (chol_tail.hpp) --------------------
+struct SmallBatchArgs {
+    int njobs;
+    int64_t wg_begin[kTailMaxFilms + 1];   // first workgroup of each job
+    struct Job {
+        const double *A, *B, *B2;          // 8-byte views
+        void *C;
+        int64_t lda8, ldb8, ldc, K8, ntm;
+        double alpha, beta;
+        int pair;
+    } j[kTailMaxFilms];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kGemmThreads) void gemm_nt_small_batch_kernel(SmallBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __builtin_amdgcn_s_setprio(3);   // beside the finishing passes' tiles on their low-priority stream (see gemm_nt_small_kernel)
+    const int64_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    int f = 0;
+    while (f + 1 < a.njobs && wg >= a.wg_begin[f + 1]) ++f;
+    const SmallBatchArgs::Job &J = a.j[f];
+    const int64_t l = wg - a.wg_begin[f];
+    T *C = static_cast<T *>(J.C);
+    if (J.pair) {   // one workgroup per 32 rows of a panel: columns 128 .. 255 from all 256, then 0 .. 127 from the first 128
+        tile_small_nt<T>(J.K8, static_cast<T>(J.alpha), J.A, J.lda8, J.B2, J.ldb8, T(0), C + BN, J.ldc, l * SBM, 0, smem_raw);
+        tile_small_nt<T>(J.K8 / 2, static_cast<T>(J.alpha), J.A, J.lda8, J.B, J.ldb8, T(0), C, J.ldc, l * SBM, 0, smem_raw);
+    } else {
+        const int64_t tm = l % J.ntm, tn = l / J.ntm;   // consecutive ids share the B panel
+        tile_small_nt<T>(J.K8, static_cast<T>(J.alpha), J.A, J.lda8, J.B, J.ldb8, static_cast<T>(J.beta), C, J.ldc, tm * SBM,
+                         tn * BN, smem_raw);
+    }
+}
+
+template <typename T>
+int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st) {
+    if (njobs < 0 || njobs > kTailMaxFilms) return SSA_ERR_INVALID_ARGUMENT;
+    constexpr int64_t per8 = 8 / sizeof(T);
+    constexpr int64_t kStage = (sizeof(T) == 8) ? KC : 2 * KC;
+    SmallBatchArgs a{};
+    int64_t total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SmallNtJob &s = jobs[i];
+        if (s.M <= 0 || s.N <= 0) continue;
+        const bool aligned = reinterpret_cast<uintptr_t>(s.A) % 16 == 0 && reinterpret_cast<uintptr_t>(s.B) % 16 == 0 &&
+                             (s.lda * sizeof(T)) % 16 == 0 && (s.ldb * sizeof(T)) % 16 == 0 &&
+                             (!s.pair || reinterpret_cast<uintptr_t>(s.B2) % 16 == 0);
+        if (!aligned || s.M % SBM != 0 || s.N % BN != 0 || s.K % kStage != 0 || s.K <= 0 || s.alpha == 0.0 ||
+            (s.pair && (s.N != 2 * BN || s.K != 2 * BN)))
+            return SSA_ERR_INVALID_ARGUMENT;
+        SmallBatchArgs::Job &J = a.j[a.njobs];
+        J.A = static_cast<const double *>(s.A);
+        J.B = static_cast<const double *>(s.B);
+        J.B2 = static_cast<const double *>(s.B2);
+        J.C = s.C;
+        J.lda8 = s.lda / per8;
+        J.ldb8 = s.ldb / per8;
+        J.ldc = s.ldc;
+        J.K8 = s.K / per8;
+        J.ntm = s.M / SBM;
+        J.alpha = s.alpha;
+        J.beta = s.beta;
+        J.pair = s.pair;
+        a.wg_begin[a.njobs] = total;
+        total += s.pair ? J.ntm : J.ntm * (s.N / BN);
+        ++a.njobs;
+    }
+    if (total == 0) return SSA_OK;
+    a.wg_begin[a.njobs] = total;
+    static DeviceFlags flags;
+    if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&gemm_nt_small_batch_kernel<T>), sizeof(SmallSmem)}}) !=
+        SSA_OK)
+        return SSA_ERR_HIP;
+    hipLaunchKernelGGL((gemm_nt_small_batch_kernel<T>), dim3(static_cast<unsigned>(total)), dim3(kGemmThreads),
+                       sizeof(SmallSmem), st, a);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+int gemm_nt_small_batch_f64(int njobs, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch<double>(njobs, jobs, st);
+}
+int gemm_nt_small_batch_f32(int njobs, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch<float>(njobs, jobs, st);
+}
+
+// The round launch: workgroups [0, ndiag) run the diagonal-block kernel of one film each (the lowest block ids of a
+// grid are dispatched first, round-robin over the XCDs: each of them starts on a CU of its own), the others one
+// 128 x 128 tile of a film's pending trailing update, C -= P P^T on the lower tiles, in the band order of the
+// stand-alone update.
+struct TailRoundArgs {
+    int nfilms, ndiag;
+    int diag_film[kTailMaxFilms];
+    int64_t tile_begin[kTailMaxFilms + 1];
+    TailRoundJob f[kTailMaxFilms];
+};
+// LDS request that leaves no room for a second 72 KiB tile workgroup on a 160 KiB CU
+constexpr size_t kExclusiveLds = 89 * 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kGemmThreads, 2) void chol_tail_round_kernel(TailRoundArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (static_cast<int>(blockIdx.x) < a.ndiag) {
+        const TailRoundJob &F = a.f[a.diag_film[blockIdx.x]];
+        cholk2::chol_diag256_v2_body<T>(static_cast<T *>(F.D), F.lda, static_cast<T *>(F.W), F.ldw,
+                                        static_cast<T *>(F.scratch), F.info, F.col1, smem_raw);
+        return;
+    }
+    // (equal blockIdx.x % 8 = equal XCD holds for the shifted ids as well)
+    const int64_t id = xcd_contiguous(static_cast<int64_t>(blockIdx.x) - a.ndiag, static_cast<int64_t>(gridDim.x) - a.ndiag);
+    int f = 0;
+    while (f + 1 < a.nfilms && id >= a.tile_begin[f + 1]) ++f;
+    const TailRoundJob &F = a.f[f];
+    int64_t tm, tn;
+    lower_band_tile(id - a.tile_begin[f], F.M / BM, tm, tn);
+    const T *P = static_cast<const T *>(F.P);
+    if constexpr (sizeof(T) == 8)
+        tile_full_f64<OP_N, OP_T>(F.K, -1.0, P, F.ldc, P, F.ldc, 1.0, static_cast<T *>(F.C), F.ldc, tm * BM, tn * BN, smem_raw);
+    else
+        tile_full_f32_nt(F.K, -1.0f, P, F.ldc, P, F.ldc, 1.0f, static_cast<T *>(F.C), F.ldc, tm * BM, tn * BN, smem_raw);
+}
+
+template <typename T>
+int chol_tail_round(int nfilms, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
+    if (nfilms <= 0 || nfilms > kTailMaxFilms) return SSA_ERR_INVALID_ARGUMENT;
+    constexpr int64_t kStage = (sizeof(T) == 8) ? KC : 2 * KC;
+    TailRoundArgs a{};
+    a.nfilms = nfilms;
+    int64_t tiles = 0;
+    for (int i = 0; i < nfilms; ++i) {
+        TailRoundJob J = jobs[i];
+        if (J.M < 0 || J.M % BM != 0 || (J.M > 0 && (J.K <= 0 || J.K % kStage != 0))) return SSA_ERR_INVALID_ARGUMENT;
+        if (J.M > 0 && (reinterpret_cast<uintptr_t>(J.P) % 16 != 0 || (J.ldc * sizeof(T)) % 16 != 0))
+            return SSA_ERR_INVALID_ARGUMENT;
+        if (J.has_diag) a.diag_film[a.ndiag++] = i;
+        a.f[i] = J;
+        a.tile_begin[i] = tiles;
+        const int64_t ntm = J.M / BM;
+        tiles += ntm * (ntm + 1) / 2;
+    }
+    a.tile_begin[nfilms] = tiles;
+    if (a.ndiag + tiles == 0) return SSA_OK;
+    const size_t base = sizeof(OpSmemF64) > sizeof(cholk2::Smem<T>) ? sizeof(OpSmemF64) : sizeof(cholk2::Smem<T>);
+    static DeviceFlags flags;
+    if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&chol_tail_round_kernel<T>), kExclusiveLds}}) != SSA_OK)
+        return SSA_ERR_HIP;
+    hipLaunchKernelGGL((chol_tail_round_kernel<T>), dim3(static_cast<unsigned>(a.ndiag + tiles)), dim3(kGemmThreads),
+                       exclusive ? kExclusiveLds : base, st, a);
+    SSA_RETURN_IF_LAUNCH_FAILED();
+    return SSA_OK;
+}
+int chol_tail_round_f64(int nfilms, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
+    return chol_tail_round<double>(nfilms, jobs, exclusive, st);
+}
+int chol_tail_round_f32(int nfilms, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
+    return chol_tail_round<float>(nfilms, jobs, exclusive, st);
 }
 
 // used by chol.hip

@@ -82,6 +82,48 @@ def test_biot_savart(golden):
         assert relerr(H, d[f"H_{tag}"]) < 1e-12
 
 
+def _cpu_kernels():
+    """The OpenMP C port of the reference's two numba kernels (oracle/csrc/oracle_kernels.c), built on demand."""
+    import shutil
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available: the C port of the oracle kernels cannot be built")
+    import build_oracle
+    import cpu_kernels
+
+    build_oracle.build(verbose=False)
+    return cpu_kernels
+
+
+def test_c_port_q_matrix_pinned_to_reference(golden):
+    """cpu_kernels.q_matrix (distance.py:87-115; what the headline-size oracle and bench.py's cpu_baseline use) against
+    the reference's own Q of the 331-vertex disk: Q_ij = -q_ij off the diagonal (device/mesh.py:435-458), q_ii = 0."""
+    ck = _cpu_kernels()
+    d = golden("disk_K10.npz")
+    q = ck.q_matrix(d["sites"])
+    off = ~np.eye(len(q), dtype=bool)
+    assert not np.diag(q).any()
+    assert relerr(-q[off], d["Q"][off]) < 1e-13
+    # and the numpy restatement of the same function
+    assert relerr(q, orc.q_matrix(d["sites"])) < 1e-13
+    # the diagonal the reference derives from it: Q_ii = (C_i + sum_l q_il w_l) / w_i
+    w = d["weights"]
+    assert relerr((d["C"] + q @ w) / w, d["Q_diag"]) < 1e-13
+
+
+def test_c_port_biot_savart_pinned_to_reference(golden):
+    """cpu_kernels.biot_savart_film_to_film (solver/solve.py:28-73) against the reference's outputs: stacked films,
+    disjoint films in one plane (dz = 0) and a source above its target."""
+    ck = _cpu_kernels()
+    d = golden("biot_savart.npz")
+    for tag in ("dz05", "dz0_disjoint", "dzneg"):
+        za, zb, shift = d[f"args_{tag}"]
+        H = ck.biot_savart_film_to_film(
+            film1_sites=d["sites1"], film1_z0=za, film1_areas=d["areas"], film1_J=d["J"],
+            film2_sites=d["sites2"] + np.array([shift, 0.0]), film2_z0=zb)
+        assert relerr(H, d[f"H_{tag}"]) < 1e-13
+
+
 def _stack(d):
     import importlib.util, os
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,172 @@
+// Q-assembly probe (development aid): where does the time of q_assemble_kernel go -- its store stream, its FP64
+// work, or their overlap?  The production strip kernel's loop with the arithmetic swapped out (store only, seed
+// only), with other strip heights / columns per lane, and with the number of resident workgroups capped.
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/q_probe.hip -o tools/probes/q_probe && tools/probes/q_probe [K]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../superscreen_amd/csrc/common.hpp"
+
+using namespace ssa;
+
+enum Mode { FULL = 0, STORE_ONLY = 1, SEED_ONLY = 2, COMPUTE_ONLY = 3 };
+
+__host__ __device__ inline void rows_of(int64_t n, int64_t groups, int64_t b, int64_t *i0, int *h) {
+    const int64_t base = n / groups, extra = n % groups;
+    *i0 = b * base + (b < extra ? b : extra);
+    *h = static_cast<int>(base + (b < extra ? 1 : 0));
+}
+
+// CPL columns per lane (2: one 16-byte store per row and lane; 4: two adjacent ones, 2 KiB per wave and row)
+template <int MODE, int TR, int CPL>
+__global__ __launch_bounds__(256) void q_kernel(const double *__restrict__ xy, const double *__restrict__ w, int64_t n,
+                                                double *__restrict__ Q, int64_t ldq, double *__restrict__ rowsum) {
+    extern __shared__ char pad_lds[];   // occupancy cap only
+    __shared__ double s_part[4][TR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t i0;
+    int h;
+    rows_of(n, gridDim.x, blockIdx.x, &i0, &h);
+    double xi[TR], yi[TR], acc[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const int64_t i = (r < h) ? i0 + r : i0;
+        xi[r] = xy[2 * i];
+        yi[r] = xy[2 * i + 1];
+        acc[r] = 0.0;
+    }
+    for (int64_t j = CPL * tid; j < n; j += CPL * 256) {
+        double xj[CPL], yj[CPL], wj[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool has = j + c < n;
+            xj[c] = has ? xy[2 * (j + c)] : 0.0;
+            yj[c] = has ? xy[2 * (j + c) + 1] : 0.0;
+            wj[c] = has ? w[j + c] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (r < h) {
+                const int64_t i = i0 + r;
+                double q[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    if (MODE == STORE_ONLY) {
+                        q[c] = xj[c];
+                    } else {
+                        const double dx = xi[r] - xj[c], dy = yi[r] - yj[c];
+                        const double r2 = __builtin_fma(dx, dx, dy * dy);
+                        q[c] = (MODE == SEED_ONLY) ? __builtin_amdgcn_rsq(r2) : inv_r3_over_4pi(r2);
+                        q[c] = (i == j + c || j + c >= n) ? 0.0 : q[c];
+                        acc[r] = __builtin_fma(q[c], wj[c], acc[r]);
+                    }
+                }
+                if (MODE != COMPUTE_ONLY) {
+#pragma unroll
+                    for (int c = 0; c < CPL; c += 2) {
+                        double2 v;
+                        v.x = -q[c];
+                        v.y = -q[c + 1];
+                        *reinterpret_cast<double2 *>(Q + i * ldq + j + c) = v;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const double s = wave_sum(acc[r]);
+        if (lane == 0) s_part[wave][r] = s;
+    }
+    __syncthreads();
+    if (tid < h) rowsum[i0 + tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+}
+
+static std::vector<double> ring_points(int K) {
+    std::vector<double> p;
+    p.push_back(0.0);
+    p.push_back(0.0);
+    for (int k = 1; k <= K; ++k)
+        for (int m = 0; m < 6 * k; ++m) {
+            const double rad = 5.5 * k / K, phi = 2.0 * M_PI * m / (6.0 * k) + 0.1 * k;
+            p.push_back(rad * cos(phi));
+            p.push_back(rad * sin(phi));
+        }
+    return p;
+}
+
+template <typename F>
+static double time_ms(F f, int reps = 7) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    f();
+    hipDeviceSynchronize();
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        hipEventRecord(a);
+        f();
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+template <int MODE, int TR, int CPL>
+static void run(const char *name, const double *xy, const double *w, int64_t n, double *Q, int64_t ld, double *rs,
+                int groups_per_cu, size_t lds_pad) {
+    if (lds_pad > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&q_kernel<MODE, TR, CPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds_pad));
+    const int64_t slots = 256 * groups_per_cu;
+    const int64_t groups = slots * ((n + static_cast<int64_t>(TR) * slots - 1) / (static_cast<int64_t>(TR) * slots));
+    const double ms = time_ms([&] { hipLaunchKernelGGL((q_kernel<MODE, TR, CPL>), dim3(groups), dim3(256), lds_pad, 0, xy, w, n, Q, ld, rs); });
+    const double gb = static_cast<double>(n) * n * 8 / 1e9;
+    printf("%-44s TR=%2d cpl=%d wg/cu=%d groups=%5lld: %7.3f ms  %6.0f GB/s\n", name, TR, CPL, groups_per_cu,
+           static_cast<long long>(groups), ms, gb / ms * 1e3);
+}
+
+int main(int argc, char **argv) {
+    const int K = argc > 1 ? atoi(argv[1]) : 91;
+    std::vector<double> p = ring_points(K);
+    const int64_t n = static_cast<int64_t>(p.size() / 2), ld = (n + 15) / 16 * 16;
+    std::vector<double> wh(n, 1e-3);
+    double *xy, *w, *Q, *rs;
+    hipMalloc(&xy, p.size() * 8);
+    hipMalloc(&w, n * 8);
+    hipMalloc(&rs, n * 8);
+    hipMalloc(&Q, static_cast<size_t>(n) * ld * 8);
+    hipMemcpy(xy, p.data(), p.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(w, wh.data(), n * 8, hipMemcpyHostToDevice);
+    printf("n = %lld (K = %d), %.2f GB\n", static_cast<long long>(n), K, static_cast<double>(n) * n * 8 / 1e9);
+    const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
+    printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<FULL, 16, 2>("full (production shape)", xy, w, n, Q, ld, rs, 7, 0);
+        run<FULL, 16, 2>("full, 8 wg/cu", xy, w, n, Q, ld, rs, 8, 0);
+        run<STORE_ONLY, 16, 2>("store only", xy, w, n, Q, ld, rs, 7, 0);
+        run<SEED_ONLY, 16, 2>("rsq seed only", xy, w, n, Q, ld, rs, 7, 0);
+        run<COMPUTE_ONLY, 16, 2>("compute only", xy, w, n, Q, ld, rs, 7, 0);
+        run<FULL, 16, 2>("full, 4 wg/cu (LDS cap)", xy, w, n, Q, ld, rs, 4, 40 * 1024);
+        run<FULL, 16, 2>("full, 2 wg/cu (LDS cap)", xy, w, n, Q, ld, rs, 2, 80 * 1024);
+        run<FULL, 16, 2>("full, 1 wg/cu (LDS cap)", xy, w, n, Q, ld, rs, 1, 150 * 1024);
+        run<STORE_ONLY, 16, 2>("store only, 2 wg/cu", xy, w, n, Q, ld, rs, 2, 80 * 1024);
+        run<STORE_ONLY, 16, 2>("store only, 1 wg/cu", xy, w, n, Q, ld, rs, 1, 150 * 1024);
+        run<FULL, 8, 2>("full", xy, w, n, Q, ld, rs, 8, 0);
+        run<FULL, 8, 4>("full", xy, w, n, Q, ld, rs, 8, 0);
+        run<FULL, 8, 4>("full, 4 wg/cu", xy, w, n, Q, ld, rs, 4, 40 * 1024);
+        run<FULL, 4, 4>("full", xy, w, n, Q, ld, rs, 8, 0);
+        run<STORE_ONLY, 8, 4>("store only", xy, w, n, Q, ld, rs, 8, 0);
+        run<FULL, 32, 2>("full", xy, w, n, Q, ld, rs, 4, 0);
+    }
+    return 0;
+}
