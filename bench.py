@@ -679,13 +679,18 @@ def main():
     _hip.check(lib.ssa_profile_end(), "ssa_profile_end")
     # the chains' strips and panel products: one more factorization (untimed) with only that kind bracketed
     model = None
-    _hip.check(lib.ssa_profile_begin_kinds(0b100), "ssa_profile_begin_kinds")
+    _hip.check(lib.ssa_profile_begin_kinds(0b11100), "ssa_profile_begin_kinds")
     model = sc.factorize_model(device=device, current_units="uA")
     torch.cuda.synchronize()
-    ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-    _hip.check(lib.ssa_profile_read(2, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)), "ssa_profile_read")
     chain_label = [k for k in prof if "strips" in k][0]
-    prof[chain_label] = (ms.value, fl.value, cnt.value)
+    for kind, label in ((2, chain_label),
+                        (3, "ssa::chol_tail_round_kernel<double> (rounds of the last 10 240 columns: the films' diagonal-block "
+                            "kernels + the lower tiles of their pending updates in one launch; flops of the tiles)"),
+                        (4, "ssa::gemm_nt_small_batch_kernel<double> (the rounds' batched L21 = A21 W^T and next-block-column "
+                            "products)")):
+        ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        _hip.check(lib.ssa_profile_read(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)), "ssa_profile_read")
+        prof[label] = (ms.value, fl.value, cnt.value)
     _hip.check(lib.ssa_profile_end(), "ssa_profile_end")
     labels = list(prof)
     dom_label = max(labels[:2], key=lambda k: prof[k][0])
@@ -879,9 +884,10 @@ def main():
                                          "SQ_INSTS_VALU_MFMA_MOPS_F64 pass of this command)"} if mfma_doc else None),
                 "factorization_frac": extras.get("factorization_frac"),
                 "other_kernels": {
-                    labels[2]: {"launches": int(strip_n), "avg_launch_us": strip_ms * 1e3 / max(1, strip_n),
-                                "TFLOPs": (strip_fl / (strip_ms * 1e-3) / 1e12) if strip_ms > 0 else 0.0,
-                                "measured": "one factorization outside the timed region"},
+                    lab: {"launches": int(prof[lab][2]), "avg_launch_us": prof[lab][0] * 1e3 / max(1, prof[lab][2]),
+                          "TFLOPs": (prof[lab][1] / (prof[lab][0] * 1e-3) / 1e12) if prof[lab][0] > 0 else 0.0,
+                          "measured": "one factorization outside the timed region"}
+                    for lab in labels[2:]
                 },
             },
             "extras": extras,

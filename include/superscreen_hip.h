@@ -356,6 +356,10 @@ int ssa_gemm_ex(int opA, int opB, int lower_only, int64_t M, int64_t N, int64_t 
  *           entries on / below the diagonal: K * M * (M + 1))
  *   kind 2: gemm_op_kernel<double, N, T>, all tiles   (the Cholesky chain's strips and L21 = A21 W^T
  *           panel products; 2 M N K)
+ *   kind 3: chol_tail_round_kernel<double>            (the round launches of the Cholesky schedule's last part:
+ *           diagonal-block kernels of all films + lower tiles of their pending updates; flops of the tiles)
+ *   kind 4: gemm_nt_small_batch_kernel<double>        (the rounds' batched panel and strip products; 2 M N K,
+ *           panel products 1.5 M 256^2)
  * ssa_profile_begin_kinds(mask) brackets only the kinds whose bit is set in `mask` (bit k = kind k): an
  * event pair costs a few microseconds on its stream, which matters for the ~ 1300 short launches of kind 2
  * per factorization and not for the ~ 100 trailing updates; ssa_profile_begin() = all kinds.

@@ -730,6 +730,16 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 updated[i] = true;
             }
             if (!delay) pending_from[i] = c;
+            // the solve-phase data of the SNB blocks that have become final (all their columns lie left of c): whole
+            // launches on the matrix' low-priority stream, behind the chain (beside the rounds they go out in slices)
+            FinishPlan<T> &fp = plans[i];
+            if (c / SNB > fp.done && fp.done < fp.nfull()) {
+                if (hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
+                rc = fp.run_blocks(c / SNB, false, ln.finish);
+                if (rc != SSA_OK) return rc;
+                if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
+                on_finish[i] = true;
+            }
         }
     }
     for (int i = 0; i < count; ++i) {  // join, then the inverses of the diagonal blocks

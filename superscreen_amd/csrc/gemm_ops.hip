@@ -624,6 +624,7 @@ int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st) {
     constexpr int64_t kStage = (sizeof(T) == 8) ? KC : 2 * KC;
     SmallBatchArgs a{};
     int64_t total = 0;
+    double flops = 0.0;
     for (int i = 0; i < njobs; ++i) {
         const SmallNtJob &s = jobs[i];
         if (s.M <= 0 || s.N <= 0) continue;
@@ -648,6 +649,7 @@ int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st) {
         J.pair = s.pair;
         a.wg_begin[a.njobs] = total;
         total += s.pair ? J.ntm : J.ntm * (s.N / BN);
+        flops += (s.pair ? 1.5 : 2.0) * static_cast<double>(s.M) * static_cast<double>(s.N) * static_cast<double>(s.K);
         ++a.njobs;
     }
     if (total == 0) return SSA_OK;
@@ -656,6 +658,7 @@ int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st) {
     if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&gemm_nt_small_batch_kernel<T>), sizeof(SmallSmem)}}) !=
         SSA_OK)
         return SSA_ERR_HIP;
+    ProfileScope scope(sizeof(T) == 8, kProfileSmallBatch, flops, st);
     hipLaunchKernelGGL((gemm_nt_small_batch_kernel<T>), dim3(static_cast<unsigned>(total)), dim3(kGemmThreads),
                        sizeof(SmallSmem), st, a);
     SSA_RETURN_IF_LAUNCH_FAILED();
@@ -711,6 +714,7 @@ int chol_tail_round(int nfilms, const TailRoundJob *jobs, int exclusive, hipStre
     TailRoundArgs a{};
     a.nfilms = nfilms;
     int64_t tiles = 0;
+    double flops = 0.0;
     for (int i = 0; i < nfilms; ++i) {
         TailRoundJob J = jobs[i];
         if (J.M < 0 || J.M % BM != 0 || (J.M > 0 && (J.K <= 0 || J.K % kStage != 0))) return SSA_ERR_INVALID_ARGUMENT;
@@ -721,6 +725,7 @@ int chol_tail_round(int nfilms, const TailRoundJob *jobs, int exclusive, hipStre
         a.tile_begin[i] = tiles;
         const int64_t ntm = J.M / BM;
         tiles += ntm * (ntm + 1) / 2;
+        flops += static_cast<double>(J.K) * static_cast<double>(J.M) * static_cast<double>(J.M + 1);
     }
     a.tile_begin[nfilms] = tiles;
     if (a.ndiag + tiles == 0) return SSA_OK;
@@ -728,6 +733,7 @@ int chol_tail_round(int nfilms, const TailRoundJob *jobs, int exclusive, hipStre
     static DeviceFlags flags;
     if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&chol_tail_round_kernel<T>), kExclusiveLds}}) != SSA_OK)
         return SSA_ERR_HIP;
+    ProfileScope scope(sizeof(T) == 8, kProfileRound, flops, st);
     hipLaunchKernelGGL((chol_tail_round_kernel<T>), dim3(static_cast<unsigned>(a.ndiag + tiles)), dim3(kGemmThreads),
                        exclusive ? kExclusiveLds : base, st, a);
     SSA_RETURN_IF_LAUNCH_FAILED();

@@ -15,7 +15,9 @@ enum ProfileKind : int {
     kProfileGemmNN = 0,    // gemm_kernel<double, true>            (LU trailing / in-panel updates)
     kProfileSyrkLower = 1, // gemm_op_kernel<double, N, T, lower>  (Cholesky trailing update)
     kProfileOpNT = 2,      // gemm_op_kernel<double, N, T, all tiles> (Cholesky strips and panel products)
-    kProfileKinds = 3
+    kProfileRound = 3,     // chol_tail_round_kernel<double>          (round launches: diagonal blocks + update tiles)
+    kProfileSmallBatch = 4, // gemm_nt_small_batch_kernel<double>     (the rounds' panel and strip products)
+    kProfileKinds = 5
 };
 
 struct GemmProfile {

@@ -721,19 +721,20 @@ def test_profile_kinds_mask(K):
     from superscreen_amd import _hip
     lib = _hip.load_library()
     rng = np.random.default_rng(0)
-    n = 1024
-    U = rng.standard_normal((n, 16))
-    S = np.tril(U @ U.T / 16 + np.diag(1.5 + rng.random(n)))
+    n = 11264   # above the 10 240 trailing columns where the schedule switches to rounds: updates and chain products first
+    U = dev(rng.standard_normal((n, 16)))
+    S = torch.tril(U @ U.T / 16 + torch.diag(1.5 + dev(rng.random(n))))
+    del U
 
     def factor():
         t = torch.zeros((n, K.padded_ld(n, "float64")), dtype=torch.float64, device="cuda")
-        t[:n, :n] = dev(S)
+        t[:n, :n] = S
         assert K.chol_factor(t, n).info == 0
         torch.cuda.synchronize()
 
     def counts():
         out = []
-        for kind in range(3):
+        for kind in range(5):
             ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
             _hip.check(lib.ssa_profile_read(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)), "read")
             out.append(cnt.value)
@@ -744,8 +745,9 @@ def test_profile_kinds_mask(K):
     everything = counts()
     _hip.check(lib.ssa_profile_end(), "end")
     assert everything[1] > 0 and everything[2] > 0            # trailing updates and chain products
+    assert everything[3] > 0 and everything[4] > 0            # round launches and their batched products
     _hip.check(lib.ssa_profile_begin_kinds(0b010), "begin_kinds")
     factor()
     only_syrk = counts()
     _hip.check(lib.ssa_profile_end(), "end")
-    assert only_syrk == [0, everything[1], 0]
+    assert only_syrk == [0, everything[1], 0, 0, 0]

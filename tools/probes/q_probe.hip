@@ -150,23 +150,16 @@ int main(int argc, char **argv) {
     printf("n = %lld (K = %d), %.2f GB\n", static_cast<long long>(n), K, static_cast<double>(n) * n * 8 / 1e9);
     const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
     printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
+    const size_t cap[9] = {0, 150 * 1024, 80 * 1024, 52 * 1024, 40 * 1024, 32 * 1024, 26 * 1024, 22 * 1024, 0};
     for (int rep = 0; rep < 2; ++rep) {
         run<FULL, 16, 2>("full (production shape)", xy, w, n, Q, ld, rs, 7, 0);
-        run<FULL, 16, 2>("full, 8 wg/cu", xy, w, n, Q, ld, rs, 8, 0);
         run<STORE_ONLY, 16, 2>("store only", xy, w, n, Q, ld, rs, 7, 0);
-        run<SEED_ONLY, 16, 2>("rsq seed only", xy, w, n, Q, ld, rs, 7, 0);
-        run<COMPUTE_ONLY, 16, 2>("compute only", xy, w, n, Q, ld, rs, 7, 0);
-        run<FULL, 16, 2>("full, 4 wg/cu (LDS cap)", xy, w, n, Q, ld, rs, 4, 40 * 1024);
-        run<FULL, 16, 2>("full, 2 wg/cu (LDS cap)", xy, w, n, Q, ld, rs, 2, 80 * 1024);
-        run<FULL, 16, 2>("full, 1 wg/cu (LDS cap)", xy, w, n, Q, ld, rs, 1, 150 * 1024);
-        run<STORE_ONLY, 16, 2>("store only, 2 wg/cu", xy, w, n, Q, ld, rs, 2, 80 * 1024);
-        run<STORE_ONLY, 16, 2>("store only, 1 wg/cu", xy, w, n, Q, ld, rs, 1, 150 * 1024);
-        run<FULL, 8, 2>("full", xy, w, n, Q, ld, rs, 8, 0);
-        run<FULL, 8, 4>("full", xy, w, n, Q, ld, rs, 8, 0);
-        run<FULL, 8, 4>("full, 4 wg/cu", xy, w, n, Q, ld, rs, 4, 40 * 1024);
-        run<FULL, 4, 4>("full", xy, w, n, Q, ld, rs, 8, 0);
-        run<STORE_ONLY, 8, 4>("store only", xy, w, n, Q, ld, rs, 8, 0);
-        run<FULL, 32, 2>("full", xy, w, n, Q, ld, rs, 4, 0);
+        for (int g = 2; g <= 6; ++g) run<FULL, 24, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
+        for (int g = 2; g <= 6; ++g) run<FULL, 32, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
+        for (int g = 2; g <= 5; ++g) run<FULL, 48, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
+        for (int g = 2; g <= 4; ++g) run<FULL, 64, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
+        run<STORE_ONLY, 32, 2>("store only", xy, w, n, Q, ld, rs, 4, cap[4]);
+        run<STORE_ONLY, 64, 2>("store only", xy, w, n, Q, ld, rs, 4, cap[4]);
     }
     return 0;
 }
