@@ -554,16 +554,23 @@ def config5_stack(sc, torch, dist, rank, world, iterations, steps=2):
     """Cold self-consistent solve of the 4-film stack (4 disks on the K = 100 mesh: 4 x 30 301 vertices, z = 0,
     0.5, 1.0, 1.5 um) on `world` ranks."""
     from superscreen_amd import synthetic
-    from superscreen_amd.parallel import CouplingPlan, FilmPlacement
+    from superscreen_amd.parallel import FilmPlacement
 
     K5 = int(os.environ.get("BENCH_CONFIG5_K", "100"))            # testing aid: smaller meshes
     device = synthetic.make_stack_device(K5, ("disk",) * 4, z_spacing=0.5, solve_dtype="float64")
     films = list(device.films)
     placement = coupling = None
-    if world > 1 and world <= len(films):
+    if world > 1 and world < 2 * len(films):
         placement, mode = FilmPlacement(rank=rank, world=world), "FilmPlacement (owner computes; one all-reduce of the result vectors per pass)"
     elif world > 1:
-        coupling, mode = CouplingPlan(rank=rank, world=world), "CouplingPlan (source slices; one fused all-reduce of the coupling vector per iteration; factor / solve replicated)"
+        # more ranks than films: one group of world // n_films ranks per film -- the owner factors and solves, every
+        # rank of the group takes a source slice of the coupling sums whose target is the group's film (summed inside
+        # the group); replicating the four factorizations on eight ranks (CouplingPlan) would be ~ 3 x slower than
+        # four owners
+        placement = FilmPlacement(rank=rank, world=world, n_films=len(films))
+        mode = (f"FilmPlacement with helper groups ({len(films)} groups of {placement.group_size} ranks: owner factors / solves, "
+                "coupling sums of the group's film split by source slice and summed inside the group; one all-reduce of the "
+                "result vectors per pass across groups)")
     else:
         mode = "single GPU"
 
@@ -594,11 +601,68 @@ def config5_stack(sc, torch, dist, rank, world, iterations, steps=2):
     g = sols[-1].film_solutions[films[0]].stream
     assert np.isfinite(g).all() and len(sols) == iterations + 1
     checksum = float(np.abs(g).max())
-    del model, sols
+    out = {"config5_solves_per_s": steps / elapsed, "config5_ms_per_solve": elapsed / steps * 1e3,
+           "config5_mode": mode, "config5_vertices_per_film": len(device.meshes[films[0]].sites),
+           "config5_max_abs_stream_film0": checksum}
+    if world == 1:
+        # what ONE rank of an N-GPU run does, measured here on one GPU (DESIGN.md section 6 derives the projected
+        # N = 2 / 4 / 8 times from these): one film's factorization, one film's pass, the coupling sums of one
+        # target film from all three sources and from half of every source (an owner / helper pair at N = 8)
+        from superscreen_amd import kernels
+
+        def timed(fn, reps=5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            ts = []
+            for _ in range(reps):
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return float(np.median(ts))
+
+        fds, info = model.film_data, model.film_info
+        tgt = films[0]
+        t, J = fds[tgt], {f: torch.from_numpy(np.ascontiguousarray(sols[-1].film_solutions[f].current_density)).cuda()
+                          for f in films}
+        buf = torch.zeros(t.n, dtype=t.tdtype, device="cuda")
+
+        def couple(frac):
+            for src in films[1:]:
+                sd = fds[src]
+                lo, hi = sd.src_range
+                kernels.biot_savart(sd.xy, sd.w_t, J[src], t.xy, info[tgt].z0 - info[src].z0, buf, accumulate=True,
+                                    src_begin=lo, src_end=lo + int((hi - lo) * frac))
+
+        out["config5_one_target_coupling_ms"] = timed(lambda: couple(1.0))
+        out["config5_one_target_half_sources_coupling_ms"] = timed(lambda: couple(0.5))
+        del model, sols, J, buf
+        torch.cuda.empty_cache()
+        one = synthetic.make_stack_device(K5, ("disk",), solve_dtype="float64")
+        tf = []
+        m1 = sc.factorize_model(device=one, current_units="uA")
+        for _ in range(3):
+            m1 = None
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            m1 = sc.factorize_model(device=one, current_units="uA")
+            torch.cuda.synchronize()
+            tf.append((time.perf_counter() - t1) * 1e3)
+        out["config5_one_film_factorize_ms"] = float(np.median(tf))
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sc.solve(model=m1, applied_field=sc.ConstantField(1.0), iterations=0, progress_bar=False)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        out["config5_one_film_pass_ms"] = float(np.median(ts[1:]))
+        del m1
+    else:
+        del model, sols
     torch.cuda.empty_cache()
-    return {"config5_solves_per_s": steps / elapsed, "config5_ms_per_solve": elapsed / steps * 1e3,
-            "config5_mode": mode, "config5_vertices_per_film": len(device.meshes[films[0]].sites),
-            "config5_max_abs_stream_film0": checksum}
+    return out
 
 
 def main():

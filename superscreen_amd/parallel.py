@@ -201,10 +201,21 @@ class FilmPlacement:
 
     Pass it to :func:`superscreen_amd.factorize_model` (the rank then factors only its films) and to
     :func:`superscreen_amd.solve`.  The process group (or the :class:`RcclCommunicator` ``comm``) must
-    already exist; the result vectors travel in one sum all-reduce per pass (:meth:`share`)."""
+    already exist; the result vectors travel in one sum all-reduce per pass (:meth:`share`).
+
+    **More ranks than films** (``n_films`` given and ``world >= 2 * n_films``; BASELINE config 5 on 8 GPUs): the
+    ranks form one group of ``world // n_films`` consecutive ranks per film.  The first rank of a group OWNS the
+    film (assembles, factors and solves it -- a film's dense factorization does not shard, SURVEY.md section 8e);
+    the others are its HELPERS: every rank of the group evaluates a source slice of the coupling sums whose
+    TARGET is the group's film (``solver/solve.py:499-515`` is a sum over sources), and one sum all-reduce INSIDE
+    the group (:meth:`reduce_coupling`: n values between xGMI neighbours) completes the field on the owner
+    before it solves.  The flat all-reduce of :meth:`share` stays the only collective that crosses groups.
+    Ranks beyond ``n_films * (world // n_films)`` idle (they take part in :meth:`share` with zeros).
+    Every rank of ``group`` must construct the placement (``torch.distributed.new_group`` is collective);
+    ``make_groups=False`` skips that (bookkeeping tests)."""
 
     def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None,
-                 comm: Optional[RcclCommunicator] = None):
+                 comm: Optional[RcclCommunicator] = None, n_films: Optional[int] = None, make_groups: bool = True):
         if comm is not None:
             rank, world = comm.rank, comm.world
         dist = _dist()
@@ -215,14 +226,67 @@ class FilmPlacement:
         if world < 1 or not (0 <= rank < world):
             raise ValueError(f"Invalid rank {rank} for world size {world}.")
         self.rank, self.world, self.group, self.comm = rank, world, group, comm
+        self.n_films = n_films
+        self.group_size = world // n_films if (n_films is not None and n_films >= 1 and world >= 2 * n_films) else 1
+        self.film_group = None       # torch.distributed group of this rank's film (owner + helpers)
+        if self.group_size > 1:
+            self.film_index = rank // self.group_size if rank < n_films * self.group_size else -1
+            self.slot = rank % self.group_size if self.film_index >= 0 else -1
+            if make_groups:
+                for f in range(n_films):                      # collective: every rank creates every group
+                    members = [self._global_rank(f * self.group_size + k) for k in range(self.group_size)]
+                    g = dist.new_group(ranks=members)
+                    if f == self.film_index:
+                        self.film_group = g
+        else:
+            self.film_index, self.slot = -1, 0
 
     def owners(self, films: Sequence[str]) -> Dict[str, int]:
-        """``{film: owning rank}``: round-robin in device order."""
+        """``{film: owning rank}``: round-robin in device order; with helper groups the first rank of each group."""
+        if self.group_size > 1:
+            self._check(films)
+            return {f: i * self.group_size for i, f in enumerate(films)}
         return {f: i % self.world for i, f in enumerate(films)}
 
     def mine(self, films: Sequence[str]) -> List[str]:
         own = self.owners(films)
         return [f for f in films if own[f] == self.rank]
+
+    def _check(self, films: Sequence[str]) -> None:
+        if self.n_films is not None and len(films) != self.n_films:
+            raise ValueError(f"This placement was made for {self.n_films} films, the device has {len(films)}.")
+
+    def coupling_targets(self, films: Sequence[str]) -> List[str]:
+        """The films whose coupling field (field from the other films) this rank works on: the films it owns, or --
+        with helper groups -- the film of its group."""
+        if self.group_size > 1:
+            self._check(films)
+            return [films[self.film_index]] if self.film_index >= 0 else []
+        return self.mine(films)
+
+    def source_slice(self, lo: int, hi: int) -> Tuple[int, int]:
+        """This rank's share of the sources ``[lo, hi)`` of a coupling sum (all of them without helper groups)."""
+        if self.group_size > 1 and self.slot >= 0:
+            b, e = shard_range(hi - lo, self.slot, self.group_size)
+            return lo + b, lo + e
+        return lo, hi
+
+    def reduce_coupling(self, fields: Sequence["object"]) -> None:
+        """Sums the partial coupling fields of this rank's film over the ranks of its group, in place (one collective
+        for all tensors of ``fields``; nothing to do without helper groups)."""
+        import torch
+
+        if self.group_size <= 1 or self.film_index < 0 or not fields:
+            return
+        if len(fields) == 1:
+            _dist().all_reduce(fields[0], op=_dist().ReduceOp.SUM, group=self.film_group)
+            return
+        flat = torch.cat([t.reshape(-1) for t in fields])
+        _dist().all_reduce(flat, op=_dist().ReduceOp.SUM, group=self.film_group)
+        off = 0
+        for t in fields:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
     def _global_rank(self, group_rank: int) -> int:
         dist = _dist()

@@ -1233,13 +1233,20 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
                         first = False
                     other_d[tgt].index_copy_(0, rows, compact)
             else:
+                # owner-computes: only this rank's target films; with helper ranks (more ranks than films) a source
+                # slice of the film of this rank's group, summed inside the group before the owner solves
+                targets = mine if placement is None else placement.coupling_targets(films)
                 for src, tgt in itertools.product(films, repeat=2):  # solve.py:499-515
-                    if src == tgt or tgt not in mine:  # owner-computes: only this rank's target films
+                    if src == tgt or tgt not in targets:
                         continue
                     s, t = model.film_data[src], model.film_data[tgt]
-                    kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,
-                                        film_info[tgt].z0 - film_info[src].z0, other_d[tgt],
-                                        accumulate=True, src_begin=s.src_range[0], src_end=s.src_range[1])
+                    b, e = s.src_range if placement is None else placement.source_slice(*s.src_range)
+                    if e > b:
+                        kernels.biot_savart(s.xy, s.w_t, results[src].J, t.xy,
+                                            film_info[tgt].z0 - film_info[src].z0, other_d[tgt],
+                                            accumulate=True, src_begin=b, src_end=e)
+                if placement is not None:
+                    placement.reduce_coupling([other_d[tgt] for tgt in targets])
             prev = results
             results = run_pass(other_d)  # Jacobi: every film sees the previous iterate
             if keep:

@@ -158,6 +158,138 @@ def test_film_placement_bookkeeping():
         FilmPlacement(rank=2, world=2)
 
 
+def test_film_placement_helper_groups_bookkeeping():
+    """More ranks than films: one group of world // n_films consecutive ranks per film; the first rank of a group
+    owns the film, all ranks of the group split the sources of the coupling sums whose target is that film."""
+    from superscreen_amd.parallel import FilmPlacement
+
+    films = ["a", "b", "c", "d"]
+    for world, gsize in ((8, 2), (9, 2), (12, 3), (16, 4)):
+        owned, cover = [], {f: [] for f in films}
+        for rank in range(world):
+            p = FilmPlacement(rank=rank, world=world, n_films=4, make_groups=False)
+            assert p.group_size == gsize
+            assert p.owners(films) == {f: i * gsize for i, f in enumerate(films)}
+            owned += p.mine(films)
+            tg = p.coupling_targets(films)
+            if rank >= 4 * gsize:                      # ranks beyond the groups idle
+                assert tg == [] and p.mine(films) == [] and p.source_slice(3, 103) == (3, 103)
+                continue
+            assert tg == [films[rank // gsize]]
+            cover[tg[0]].append(p.source_slice(3, 103))
+        assert owned == films
+        for pieces in cover.values():                  # the slices of a group tile [3, 103) exactly once
+            pieces.sort()
+            assert pieces[0][0] == 3 and pieces[-1][1] == 103 and all(x[1] == y[0] for x, y in zip(pieces, pieces[1:]))
+    # fewer ranks than 2 x films, or n_films not given: the round-robin placement, no groups
+    for world in (4, 7):
+        p = FilmPlacement(rank=1, world=world, n_films=4, make_groups=False)
+        assert p.group_size == 1 and p.coupling_targets(films) == p.mine(films) and p.source_slice(0, 10) == (0, 10)
+    with pytest.raises(ValueError):
+        FilmPlacement(rank=0, world=8, n_films=4, make_groups=False).owners(films[:3])
+
+
+def _helper_worker(rank, world, port, q):
+    """BASELINE config 5 on 8 ranks (gloo, CPU): the Jacobi loop of solve.py:491-536 with the CPU oracle standing in
+    for the kernels -- owners solve their film, every rank of a film's group evaluates a source slice of the film's
+    coupling field, one all-reduce inside the group, one flat all-reduce across the groups per pass."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import superscreen_oracle as orc
+    import torch.distributed as dist
+    from matplotlib.path import Path
+
+    from superscreen_amd import synthetic
+    from superscreen_amd.parallel import FilmPlacement
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        K, iterations = 7, 3
+        sites, elements, dr = synthetic.ring_disk_mesh(K)
+        mesh = orc.make_mesh(sites, elements)
+        in_film = Path(synthetic.circle_points((synthetic.film_rings(K) + 0.5) * dr), closed=True).contains_points(sites)
+        films = [orc.make_film(f"disk{i}", mesh, z0=0.5 * i, Lambda=0.1, in_film=in_film) for i in range(4)]
+        names = [f.name for f in films]
+        by_name = {f.name: f for f in films}
+        conv = orc.field_conversion_mT_to_uA_per_um()
+        applied = {f.name: 1.3 * conv * np.ones(len(sites)) for f in films}
+        placement = FilmPlacement(n_films=len(films))
+        assert placement.group_size == world // 4 and placement.film_group is not None
+        mine, targets = placement.mine(names), placement.coupling_targets(names)
+        assert len(targets) == 1 and (mine == targets if rank % placement.group_size == 0 else mine == [])
+        n = len(sites)
+        shapes = {f: {"g": (n,), "J": (n, 2), "other": (n,)} for f in names}
+        dtypes = {f: {"g": torch.float64, "J": torch.float64, "other": torch.float64} for f in names}
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda *a, **kw: (calls.append(kw.get("group")), real(*a, **kw))[1]
+
+        def one_pass(other):
+            payload = {f: {} for f in names}
+            for f in mine:     # the owner solves its film (solve_film.py:440-574)
+                sol = orc.solve_film(by_name[f], applied[f], field_conversion=conv,
+                                     field_from_other_films=None if other is None else other[f].numpy())
+                payload[f] = {"g": torch.from_numpy(sol.stream.copy()), "J": torch.from_numpy(sol.current_density.copy()),
+                              "other": other[f] if other is not None else torch.zeros(n, dtype=torch.float64)}
+            placement.share(names, payload, shapes, dtypes, torch.device("cpu"))
+            return payload
+
+        trace = [one_pass(None)]
+        for _ in range(iterations):
+            prev = trace[-1]
+            other = {f: torch.zeros(n, dtype=torch.float64) for f in names}
+            for src in names:
+                for tgt in targets:
+                    if src == tgt:
+                        continue
+                    b, e = placement.source_slice(0, n)
+                    other[tgt] += torch.from_numpy(orc.biot_savart_film_to_film(
+                        film1_sites=sites[b:e], film1_z0=by_name[src].z0, film1_areas=by_name[src].weights[b:e],
+                        film1_J=prev[src]["J"].numpy()[b:e], film2_sites=sites, film2_z0=by_name[tgt].z0))
+            placement.reduce_coupling([other[t] for t in targets])
+            trace.append(one_pass(other))
+        dist.all_reduce = real
+        # per pass: one flat all-reduce across the groups; per iteration one more inside this rank's group
+        ok = calls.count(None) == iterations + 1 and calls.count(placement.film_group) == iterations
+        ok = ok and len(calls) == 2 * iterations + 1
+        ref = orc.solve(films, 1.3, iterations=iterations)
+        worst = 0.0
+        for got, want in zip(trace, ref):
+            for f in names:
+                for a, b in ((got[f]["g"].numpy(), want[f].stream), (got[f]["J"].numpy(), want[f].current_density)):
+                    worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+        for f in names:   # the coupling field of the last iterate, complete on every rank
+            a, b = trace[-1][f]["other"].numpy() / conv, ref[-1][f].field_from_other_films   # (solve_film.py:566-574)
+            worst = max(worst, float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+        q.put((rank, bool(ok), worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_film_placement_helper_groups_world8_gloo():
+    """Config 5 with more ranks than films (4 films, 8 ranks): equal to the single-process Jacobi loop to 1e-12, with
+    one cross-group and one in-group collective per pass."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_helper_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, worst in out:
+        assert ok, (rank, out)
+        assert worst < 1e-12, (rank, worst)
+
+
 def _share_worker(rank, world, port, q):
     import sys
 

@@ -549,6 +549,28 @@ def test_film_placement_two_ranks():
     assert out.stdout.count("owner-computes == single process") == 2
 
 
+def test_film_placement_helper_groups_four_ranks():
+    """parallel.FilmPlacement with more ranks than films (BASELINE config 5 on 8 GPUs: groups of an owner and its
+    helpers): four ranks share this GPU, two films -- the owner of a film factors and solves it, owner and helper
+    each take half of the sources of the film's coupling sums, summed inside the group; equal to the single-process
+    solve to 1e-12 (the source slices change the order of the sums), one cross-group collective per pass."""
+    import socket
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "workers", "placement_helpers_worker.py")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("helper groups == single process") == 4
+
+
 def test_nccl_backend_single_rank():
     """The ``nccl`` (= RCCL) backend itself: one rank on this GPU (RCCL does not admit two ranks on one
     device, so the 2-rank test above stays on gloo).  The worker runs the coupling plan, the C-ABI
