@@ -183,6 +183,21 @@ def cpu_baseline(K: int, iterations: int, budget_s: float, gpu_solutions=None, g
             sweep[t] = (2 / 3) * n_probe ** 3 / (time.perf_counter() - t0) / 1e9
     threads = max(sweep, key=sweep.get)
     del probe
+    # ... and at the benchmark's own size (the LU of the larger film, n_i = 20 419 at K = 91): the small probe
+    # collapses at high thread counts on some boxes where the large factorization does not.  The baseline uses the
+    # thread count that is fastest AT SIZE.
+    n_size = {91: 20419, 81: 16207, 129: 41419}.get(K, 0)
+    sweep_at_size = {}
+    if n_size and n_size <= 24000:
+        big = rng.random((n_size, n_size))
+        big[np.diag_indices(n_size)] += n_size
+        for t in sorted({threads, min(32, phys), min(64, phys)}):
+            with threadpool_limits(limits=t):
+                t0 = time.perf_counter()
+                la.lu_factor(big, check_finite=False)
+                sweep_at_size[t] = (2 / 3) * n_size ** 3 / (time.perf_counter() - t0) / 1e9
+        threads = max(sweep_at_size, key=sweep_at_size.get)
+        del big
 
     def median_timed(fn, spent, cap=3):
         """Median wall time of up to `cap` runs of fn, stopping early once the CPU budget is used up."""
@@ -270,6 +285,7 @@ def cpu_baseline(K: int, iterations: int, budget_s: float, gpu_solutions=None, g
         "logical_cpus": logical,
         "physical_cores": phys,
         "lu_thread_sweep_GFLOPs_n6000": {str(k): v for k, v in sweep.items()},
+        "lu_GFLOPs_by_threads_at_size": {str(k): v for k, v in sweep_at_size.items()},
     }
 
 
@@ -421,6 +437,112 @@ def config3_two_films(sc, torch, iterations):
             res["config3_iterations_to_1e-8"] = len(sols) - 1
     torch.cuda.empty_cache()
     return res
+
+
+def configH_float32(sc, torch, K, iterations, steps=6):
+    """Config H in the reference's DEFAULT precision (``Device(..., solve_dtype="float32")``, device/device.py:57): the
+    same cold self-consistent solve as the headline, float32 factor and solves (sheet currents and coupling sums stay
+    float64 as in the reference, solve.py:508-515).  The factorization is priced against the FP32 matrix peak."""
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(K, ("washer", "disk"), solve_dtype="float32")
+
+    def cold(field):
+        model = sc.factorize_model(device=device, current_units="uA")
+        return model, sc.solve(model=model, applied_field=sc.ConstantField(field), field_units="mT",
+                               iterations=iterations, progress_bar=False)
+
+    model = sols = None
+    for i in range(2):
+        model = sols = None
+        model, sols = cold(0.1 * (i + 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model = sols = None
+        model, sols = cold(0.1 * (i + 3))
+    torch.cuda.synchronize()
+    ms_step = (time.perf_counter() - t0) / steps * 1e3
+    assert len(sols) == iterations + 1 and sols[-1].film_solutions["disk1"].stream.dtype == np.float32
+    unknowns = [int(len(s_.indices)) for s_ in model.film_systems.values()]
+    used_chol = all(s_.chol is not None for s_ in model.film_systems.values())
+    tf = []
+    for _ in range(5):
+        model = sols = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model = sc.factorize_model(device=device, current_units="uA")
+        torch.cuda.synchronize()
+        tf.append((time.perf_counter() - t1) * 1e3)
+    t_fact = float(np.median(tf))
+    flops = sum(u ** 3 / 3.0 for u in unknowns) * (1.0 if used_chol else 2.0)
+    del model, sols
+    torch.cuda.empty_cache()
+    return {"configH_float32_ms_per_step": ms_step, "configH_float32_solves_per_s": 1e3 / ms_step,
+            "configH_float32_factorization_ms": t_fact,
+            "configH_float32_factorization_TFLOPs": flops / (t_fact * 1e-3) / 1e12,
+            "configH_float32_factorization_frac_of_fp32_matrix_peak": flops / (t_fact * 1e-3) / 1e12 / 157.3,
+            "configH_float32_note": "reference default solve_dtype; parity of this precision: "
+                                    "tests/test_headline_gpu.py::test_configH_float32_no_worse_than_the_reference_in_float32"}
+
+
+def pipelined_cold_solves(sc, torch, device, iterations, steps=8):
+    """Throughput of back-to-back cold solves when solve i and the factorization of solve i + 1 overlap (what a scan
+    over devices or geometries can do; the headline stays the sequential step): the passes of a solve are bound by
+    HBM (GEMV chains, matrix pipes idle), a factorization by the matrix pipes.  Two models alive, two host threads,
+    each phase on a stream of its own; a model changes hands after a host-side wait for its factorization."""
+    import threading
+
+    s_fact, s_solve = torch.cuda.Stream(), torch.cuda.Stream()
+    errors = []
+
+    def factorize(box):
+        try:
+            with torch.cuda.stream(s_fact):
+                box.append(sc.factorize_model(device=device, current_units="uA"))
+            s_fact.synchronize()
+        except BaseException as exc:   # noqa: BLE001 -- reported by the caller
+            errors.append(exc)
+
+    def solve(model, field, box):
+        try:
+            with torch.cuda.stream(s_solve):
+                box.append(sc.solve(model=model, applied_field=sc.ConstantField(field), field_units="mT",
+                                    iterations=iterations, progress_bar=False))
+            s_solve.synchronize()
+        except BaseException as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    def run(n):
+        box = []
+        factorize(box)
+        model, done = box[0], 0
+        for i in range(n):
+            nxt, out = [], []
+            threads = [threading.Thread(target=solve, args=(model, 0.1 * (i + 1), out))]
+            if i + 1 < n:
+                threads.append(threading.Thread(target=factorize, args=(nxt,)))
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            assert len(out[0]) == iterations + 1
+            done += 1
+            model = nxt[0] if nxt else None
+        return done
+
+    run(2)                                                         # warm-up: streams, chain-stream calibration, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = run(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    torch.cuda.empty_cache()
+    return {"pipelined_cold_solves_per_s": n / elapsed, "pipelined_cold_solve_ms": elapsed / n * 1e3,
+            "pipelined_note": f"{n} cold solves, factorization of solve i + 1 beside the passes of solve i (two streams, two "
+                              "models alive); includes the first factorization, which overlaps nothing"}
 
 
 def configH_alt_2x50k(sc, torch, iterations):
@@ -876,6 +998,8 @@ def main():
         # BASELINE configs 2 and 3 and the 2 x 50 311 reading of the headline, on this rank's GPU
         extras.update(config3_two_films(sc, torch, args.iterations))
         extras.update(config2_single_film(sc, torch, kernels))
+        extras.update(pipelined_cold_solves(sc, torch, device, args.iterations))
+        extras.update(configH_float32(sc, torch, args.K, args.iterations))
         extras.update(configH_alt_2x50k(sc, torch, args.iterations))
     if not args.no_extras:
         # BASELINE configs 4 and 5 on all ranks (collective calls: every rank takes part)

@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 4
+#define SSA_ABI_VERSION 5
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);
@@ -180,7 +180,10 @@ int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void 
  * HOST arrays of `count` entries with the arguments of ssa_chol_solve for nrhs = 1, ldb = 1 (workspace_bytes[i] >=
  * ssa_chol_solve_workspace_bytes(n[i], 1, dtype)).  b_is_padded != 0: every B[i] holds ssa_chol_padded_n(n[i])
  * elements, zero from n[i] on, and is solved where it is (no staging copies; the padding stays zero) - what a caller
- * that runs many passes with the same buffers wants.  Results bit-identical to `count` ssa_chol_solve calls. */
+ * that runs many passes with the same buffers wants.  Results bit-identical to `count` ssa_chol_solve calls.
+ * Every L[i] and aux[i] must be 16-byte aligned with lda[i] * sizeof(element) a multiple of 16 (what the package's
+ * padded buffers are); otherwise SSA_ERR_INVALID_ARGUMENT - ssa_chol_solve, which has a scalar path, takes such
+ * factors. */
 int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
                          const void *const *aux, void *const *B, int b_is_padded, int dtype, void *const *workspace,
                          const size_t *workspace_bytes, void *stream);
@@ -197,6 +200,10 @@ int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, cons
  * factorization on this device).
  */
 int ssa_chol_chain_stream_costs(double *microseconds, int32_t *pipe_group, int capacity);
+/* Forgets the measurements of the current device (they are kept per caller stream, least recently used first out):
+ * the next factorization measures again.  For callers that create or destroy streams between factorizations (the
+ * runtime may move hardware queues between pipes then) or recycle stream handles. */
+int ssa_chol_chain_streams_invalidate(void);
 
 /*
  * Replaces the numba kernels _biot_savart_2d_z / _biot_savart_2d_vector

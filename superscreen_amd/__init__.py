@@ -6,9 +6,10 @@ gfx950 behind the C ABI declared in ``include/superscreen_hip.h``.  See DESIGN.m
 """
 # Process-global HIP settings are the application's to choose, not this package's: nothing is changed at import.
 # One that matters for stacks of >= 3 films: HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES
-# (default 4) hardware queues per priority level and the factorization schedules keep two high-priority chain
-# streams per film busy (csrc/chol.hip, lu.hip); a four-film stack factors 3 % faster with
-# GPU_MAX_HW_QUEUES=8 set BEFORE the HIP runtime starts (bench.py does that).
+# (default 4) hardware queues per priority level and the factorization schedules keep one high-priority chain
+# stream (and, for >= 3 films, one update stream) per film busy while the trailing matrices are large
+# (csrc/chol.hip, lu.hip); a four-film stack factors 3 % faster with GPU_MAX_HW_QUEUES=8 set BEFORE the HIP
+# runtime starts (bench.py does that).
 
 from .version import __version__  # noqa: F401
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SSA_LIB_PATH") or os.path.join(_PKG, "lib", "libsuper
 
 SSA_F32 = 0
 SSA_F64 = 1
-ABI_VERSION = 4   # SSA_ABI_VERSION of include/superscreen_hip.h
+ABI_VERSION = 5   # SSA_ABI_VERSION of include/superscreen_hip.h
 
 
 class HipLibraryError(RuntimeError):
@@ -81,6 +81,7 @@ SIGNATURES = {
     "ssa_biot_savart_multi": (c_int, [P, P, P, I64, P, I64, c_double, I64, P, c_int, c_int, P, c_size_t, P]),
     "ssa_fill_probe": (c_int, [P, c_size_t, P]),
     "ssa_mfma_probe": (c_int, [c_int, P, P, P]),
+    "ssa_chol_chain_streams_invalidate": (c_int, []),
     "ssa_profile_begin": (c_int, []),
     "ssa_profile_begin_kinds": (c_int, [ctypes.c_uint]),
     "ssa_profile_end": (c_int, []),

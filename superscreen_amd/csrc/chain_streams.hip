@@ -35,9 +35,10 @@ __global__ void pipe_calibration_stop_kernel(int32_t *stop) { __atomic_store_n(s
 
 // The chain streams of one device and what was measured for them, per load stream (a few are remembered: the
 // Cholesky schedule's updates run on its caller's stream, the LU schedule's on a stream of its own).
-constexpr int kMaxMeasurements = 4;
+constexpr int kMaxMeasurements = 8;
 struct Measurement {
     bool valid = false;
+    unsigned long long used = 0;  // tick of the last chain_streams_get that returned it (least recently used goes first)
     hipStream_t load = nullptr;
     float us[kChainPool] = {};    // per dependent launch, alone beside the load stream
     int pipe[kChainPool] = {};    // 0: shares the load stream's pipe; 1, 2, ...: groups of streams that share a pipe
@@ -47,7 +48,8 @@ struct ChainSet {
     hipStream_t chain_pool[kChainPool] = {};
     bool pool_made = false;
     Measurement measured[kMaxMeasurements];
-    int next_slot = 0, last = -1;
+    unsigned long long tick = 0;
+    int last = -1;
     int32_t *calib_stop = nullptr;   // device flag of the calibration load
 };
 ChainSet g_chain_sets[kMaxDevices];
@@ -215,14 +217,42 @@ int chain_streams_get(hipStream_t load, int count, hipStream_t *out) {
     for (int m = 0; m < kMaxMeasurements; ++m)
         if (set.measured[m].valid && set.measured[m].load == load) slot = m;
     if (slot < 0) {
-        slot = set.next_slot;
-        set.next_slot = (set.next_slot + 1) % kMaxMeasurements;
+        // a free slot, else the least recently used one: a caller that alternates between a few streams keeps its
+        // measurements
+        slot = 0;
+        for (int m = 0; m < kMaxMeasurements; ++m) {
+            if (!set.measured[m].valid) {
+                slot = m;
+                break;
+            }
+            if (set.measured[m].used < set.measured[slot].used) slot = m;
+        }
         set.measured[slot].valid = false;
+        // The measurement wants the chain streams and the load stream idle: schedules only join them into their
+        // caller's stream asynchronously, so an earlier factorization (of the other route, or on another stream) may
+        // still be running.
+        for (hipStream_t c : set.chain_pool)
+            if (hipStreamSynchronize(c) != hipSuccess) return SSA_ERR_HIP;
+        if (hipStreamSynchronize(load) != hipSuccess) return SSA_ERR_HIP;
         const int rc = calibrate_chain_streams(set, load, set.measured[slot]);
         if (rc != SSA_OK) return rc;
     }
+    set.measured[slot].used = ++set.tick;
     set.last = slot;
     for (int i = 0; i < count; ++i) out[i] = set.chain_pool[set.measured[slot].order[i % kChainPool]];
+    return SSA_OK;
+}
+
+// Forgets every measurement of the current device: the next schedule measures again (after the process has created
+// or destroyed streams -- which can move hardware queues between the command processor's pipes -- or when a
+// stream handle that was measured has been destroyed and its value may be handed out again).
+int chain_streams_invalidate() {
+    std::lock_guard<std::mutex> lock(g_chain_mutex);
+    int dev = 0;
+    if (current_device(&dev) != SSA_OK) return SSA_ERR_HIP;
+    ChainSet &set = g_chain_sets[dev];
+    for (Measurement &m : set.measured) m.valid = false;
+    set.last = -1;
     return SSA_OK;
 }
 

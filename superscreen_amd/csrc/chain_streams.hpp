@@ -19,6 +19,9 @@ int chain_streams_get(hipStream_t load, int count, hipStream_t *out);
 // Returns the number of chain streams, 0 if nothing has been measured on this device.
 int chain_streams_costs(double *microseconds, int32_t *pipe_group, int capacity);
 
+// Forgets the measurements of the current device; the next schedule measures again.
+int chain_streams_invalidate();
+
 int chain_streams_shutdown();
 
 }  // namespace ssa

@@ -819,6 +819,8 @@ extern "C" int ssa_chol_chain_stream_costs(double *microseconds, int32_t *pipe_g
     return chain_streams_costs(microseconds, pipe_group, capacity);
 }
 
+extern "C" int ssa_chol_chain_streams_invalidate(void) { return chain_streams_invalidate(); }
+
 extern "C" int64_t ssa_chol_padded_n(int64_t n) { return ceil_div(n, CNB) * CNB; }
 
 namespace ssa {

@@ -20,7 +20,10 @@ namespace ssa {
 enum : int { OP_N = 0, OP_T = 1 };
 
 constexpr int KMINOR_STRIDE = BN + 16;
-constexpr int64_t kSmallTileMaxTiles = 64;    // (round 3, update-bound factorization: 0 / 8 / 20 / 40 / 64 / 80 / 160 / 320 tiles -> 104.7 / 101.6 / 103.5 / 101.4 / 102.9 / 101.4 / 102.5-104.0 / 104.0 ms over two boxes: the fewer of the chains' products run on the small tile, the less they cost the update)   // 128 x 128 tiles of a launch below which the 32 x 128 tile is used
+// 128 x 128 tiles of a launch below which the 32 x 128 tile is used.  (Round 3, update-bound factorization: 0 / 8 / 20 /
+// 40 / 64 / 80 / 160 / 320 tiles -> 104.7 / 101.6 / 103.5 / 101.4 / 102.9 / 101.4 / 102.5-104.0 / 104.0 ms over two
+// boxes: the fewer of the chains' products run on the small tile, the less they cost the update.)
+constexpr int64_t kSmallTileMaxTiles = 64;
 constexpr int IMG_ELEMS = KC * KMINOR_STRIDE;  // the larger of the two images
 
 struct OpSmemF64 {

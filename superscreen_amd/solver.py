@@ -238,8 +238,22 @@ class FilmDeviceData:
         vertices) ahead of the host work that prepares its index sets; the constructor picks the result up."""
         from . import kernels
 
+        import threading
+
         geo = FilmDeviceData.device_geometry(mesh, dtype)
-        geo["_row_sums"] = (bool(store_Q),) + tuple(kernels.q_assemble(geo["xy"], geo["w"], geo["C"], dtype, want_Q=store_Q))
+        # parked per calling thread (two threads may factorize devices that share a mesh); whoever started them
+        # drops what the constructor has not picked up (drop_row_sums: factorize_model's finally clause)
+        geo.setdefault("_row_sums", {})[threading.get_ident()] = \
+            (bool(store_Q),) + tuple(kernels.q_assemble(geo["xy"], geo["w"], geo["C"], dtype, want_Q=store_Q))
+
+    @staticmethod
+    def drop_row_sums(mesh, dtype: np.dtype) -> None:
+        """Forgets row sums started by this thread that no constructor picked up (an exception on the way, a film
+        another rank owns): they may hold an n x n matrix."""
+        import threading
+
+        geo = FilmDeviceData.device_geometry(mesh, dtype)
+        geo.get("_row_sums", {}).pop(threading.get_ident(), None)
 
     def __init__(self, info: FilmInfo, mesh, dtype: np.dtype, store_Q: bool, geometry_only: bool = False):
         import torch
@@ -263,7 +277,9 @@ class FilmDeviceData:
         # Q_ii needs the full row sums over all n vertices: one all-pairs pass, no n^2 output
         # unless the dense Q is wanted for the self-field GEMV.  (Launched before the host work below: the row sums
         # are the first kernel of a cold step.)
-        started = geo.pop("_row_sums", None)   # (FilmDeviceData.start_row_sums)
+        import threading
+
+        started = geo.get("_row_sums", {}).pop(threading.get_ident(), None)   # (FilmDeviceData.start_row_sums)
         if geometry_only:  # a film owned by another rank: only a coupling source / target geometry
             self.Q = self.qdiag = None
         elif started is not None and started[0] == bool(store_Q):
@@ -701,12 +717,16 @@ def factorize_model(*, device: Device, current_units: str,
         mine_first = list(device.films) if placement is None else placement.mine(list(device.films))
         for name in mine_first:
             FilmDeviceData.start_row_sums(device.meshes[name], device.solve_dtype, self_field == "dense")
-    film_info = make_film_info(device=device, vortices=vortices,
-                               circulating_currents=circulating_currents,
-                               terminal_currents=terminal_currents)
-    owned = None if placement is None else placement.mine(list(device.films))
-    film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
-        device, film_info, store_Q=(self_field == "dense"), method=method, owned=owned)
+    try:
+        film_info = make_film_info(device=device, vortices=vortices,
+                                   circulating_currents=circulating_currents,
+                                   terminal_currents=terminal_currents)
+        owned = None if placement is None else placement.mine(list(device.films))
+        film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
+            device, film_info, store_Q=(self_field == "dense"), method=method, owned=owned)
+    finally:
+        for name in mine_first:
+            FilmDeviceData.drop_row_sums(device.meshes[name], device.solve_dtype)
     model = FactorizedModel(device, film_info, film_systems, hole_systems, terminal_systems,
                             terminal_currents, circulating_currents, vortices, current_units,
                             film_data=film_data, self_field_mode=self_field, method=method)
@@ -1133,6 +1153,11 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     # multi-vector launch after the last pass (config H: 0.44 ms instead of 11 x 0.23 ms) and patched into the
     # Solutions before they are returned.  Not with a file (iterates are written as they come) and not with films
     # spread over ranks (the owners' vectors travel after every pass).
+    # INVARIANT while ``batch_exterior`` is set: per pass, ``other_d[film]`` (the coupling field) and the self field are
+    # valid on ``system.indices`` (the unknowns' rows) only -- all the iteration reads (``h = Hz[indices] - ...``); the
+    # other rows are patched into the returned Solutions after the last pass.  ``solve(save_path=...)`` and placement
+    # solves evaluate every row in every pass, so their fields agree with this route to rounding, not bit for bit
+    # (tests/test_solve_gpu.py::test_output_only_rows_batched_equal_per_pass_route).
     batch_exterior = return_solutions and save_path is None and placement is None and len(films) >= 2 and iterations >= 1
     deferred: List[Dict[str, _DeviceFilmResult]] = []   # one entry per pass: the results with missing rows
     pass_cache: Dict[str, object] = {}                  # per film: what is the same in every pass of this solve

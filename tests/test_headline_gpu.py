@@ -272,7 +272,10 @@ def test_four_film_stack_vs_oracle(sc):
 # ------------------------------------------------------------------------------------------------
 # (e) the north_star's acceptance number at its own size: config H against the oracle
 # ------------------------------------------------------------------------------------------------
-def _oracle_films_full_size(K, kinds, threads=16):
+_FULL_SIZE_CACHE = {}   # (K, kinds) -> (mesh with its dense Q, masks): the float64 and float32 oracles share it
+
+
+def _oracle_films_full_size(K, kinds, threads=16, dtype="float64"):
     """Oracle films of the K-ring stack at full size: dense Q by the OpenMP C port of ``q_matrix``
     (distance.py:87-115; held against the numpy restatement by the CPU tests), ``A = Q[ix, ix] w - Lambda Del2``
     (solve_film.py:296-305) and ``lu_factor(-A)`` (:279) by scipy."""
@@ -283,21 +286,26 @@ def _oracle_films_full_size(K, kinds, threads=16):
     from superscreen_amd import synthetic
 
     build_oracle.build(verbose=False)
-    sites, elements, dr = synthetic.ring_disk_mesh(K)
-    mesh = orc.make_mesh(sites, elements, build_Q=False)
-    Kf = synthetic.film_rings(K)
-    in_film = Path(synthetic.circle_points((Kf + 0.5) * dr), closed=True).contains_points(sites)
-    in_hole = Path(synthetic.circle_points((Kf // 3 + 0.5) * dr, 201), closed=True).contains_points(sites)
-    q = cpu_kernels.q_matrix(sites)
-    C = orc.C_vector(sites)
-    diag = -(C + np.einsum("ij, j -> i", q, mesh.weights)) / mesh.weights   # device/mesh.py:453-458
-    np.fill_diagonal(q, diag)
-    np.negative(q, out=q)
-    mesh.Q = q
+    if (K, kinds) not in _FULL_SIZE_CACHE:
+        _FULL_SIZE_CACHE.clear()
+        sites, elements, dr = synthetic.ring_disk_mesh(K)
+        mesh = orc.make_mesh(sites, elements, build_Q=False)
+        Kf = synthetic.film_rings(K)
+        in_film = Path(synthetic.circle_points((Kf + 0.5) * dr), closed=True).contains_points(sites)
+        in_hole = Path(synthetic.circle_points((Kf // 3 + 0.5) * dr, 201), closed=True).contains_points(sites)
+        q = cpu_kernels.q_matrix(sites)
+        C = orc.C_vector(sites)
+        diag = -(C + np.einsum("ij, j -> i", q, mesh.weights)) / mesh.weights   # device/mesh.py:453-458
+        np.fill_diagonal(q, diag)
+        np.negative(q, out=q)
+        mesh.Q = q
+        _FULL_SIZE_CACHE[(K, kinds)] = (mesh, in_film, in_hole)
+    mesh, in_film, in_hole = _FULL_SIZE_CACHE[(K, kinds)]
     films = []
     for i, kind in enumerate(kinds):
         holes = {f"hole{i}": in_hole} if kind == "washer" else {}
-        films.append(orc.make_film(f"{kind}{i}", mesh, z0=0.5 * i, Lambda=0.1, in_film=in_film, holes_mask=holes))
+        films.append(orc.make_film(f"{kind}{i}", mesh, z0=0.5 * i, Lambda=0.1, in_film=in_film, holes_mask=holes,
+                                   dtype=dtype))
     return films, cpu_kernels
 
 
@@ -328,6 +336,40 @@ def test_configH_full_size_vs_oracle(sc):
             if it:
                 assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < 1e-9, (it, nm)
     print(f"config H vs oracle: stream max-rel-error {worst:.2e} over {iters + 1} iterates")
+
+
+def test_configH_float32_no_worse_than_the_reference_in_float32(sc):
+    """The reference's DEFAULT precision (``solve_dtype="float32"``, device/device.py:57; Q, the Laplacian and the
+    weights cast to float32, ``lu_factor`` = sgetrf, solver/utils.py:290-292) on the headline device: the float32
+    answer of this build is no further from the float64 reference than the reference's own float32 answer is --
+    ``err(gpu32 vs ref64) <= 2 err(ref32 vs ref64)`` for the stream function of every film and iterate."""
+    from threadpoolctl import threadpool_limits
+
+    from superscreen_amd import synthetic
+
+    K, kinds, iters, field = 91, ("washer", "disk"), 10, 0.3
+    device = synthetic.make_stack_device(K, kinds, solve_dtype="float32")
+    sols = sc.solve(device, applied_field=sc.ConstantField(field), iterations=iters, progress_bar=False)
+    assert sols[0].film_solutions["disk1"].stream.dtype == np.float32
+    with threadpool_limits(limits=16):
+        films64, cpu_kernels = _oracle_films_full_size(K, kinds)
+        ref64 = orc.solve(films64, field, iterations=iters, biot_savart=cpu_kernels.biot_savart_film_to_film)
+        ref64 = [{nm: r[nm].stream.copy() for nm in device.films} for r in ref64]
+        del films64
+        films32, _ = _oracle_films_full_size(K, kinds, dtype="float32")
+        assert films32[0].lu_piv[0].dtype == np.float32
+        ref32 = orc.solve(films32, field, iterations=iters, biot_savart=cpu_kernels.biot_savart_film_to_film)
+        del films32
+    worst_gpu = worst_ref = 0.0
+    for it, (sol, r32, r64) in enumerate(zip(sols, ref32, ref64)):
+        for nm in device.films:
+            e_gpu = relerr(sol.film_solutions[nm].stream, r64[nm])
+            e_ref = relerr(r32[nm].stream, r64[nm])
+            worst_gpu, worst_ref = max(worst_gpu, e_gpu), max(worst_ref, e_ref)
+            assert e_gpu <= 2 * e_ref + 1e-7, (it, nm, e_gpu, e_ref)
+    assert worst_gpu < 1e-3
+    print(f"config H float32: stream max-rel-error vs the float64 reference {worst_gpu:.2e} (this build), "
+          f"{worst_ref:.2e} (reference algorithm in float32)")
 
 
 def _host_rows_of_A(sites, weights, C, lap, Lambda, rows_v, cols_v):

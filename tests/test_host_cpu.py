@@ -132,7 +132,7 @@ def test_library_exports_every_declared_symbol():
 
         hip_build.build(force=False, verbose=False)  # cross-compiles for gfx950 without a GPU
     lib = _hip.load_library()  # checks every symbol; no compute call is made without a GPU
-    assert lib.ssa_abi_version() == _hip.ABI_VERSION == 4
+    assert lib.ssa_abi_version() == _hip.ABI_VERSION == 5
     assert lib.ssa_error_string(-3).decode().startswith("workspace")
     perm = np.empty(4, dtype=np.int64)
     ipiv = np.array([2, 1, 3, 3], dtype=np.int32)
@@ -351,3 +351,24 @@ def test_lu_concurrency_groups():
     assert lu_concurrency_groups([70000, 100, 100], 256) == [[0], [1, 2]]          # an oversize matrix runs alone
     assert lu_concurrency_groups([100, 65000, 100], 256) == [[0, 1, 2]]                 # 1 + 254 + 1
     assert lu_concurrency_groups([100, 65300, 100], 256) == [[0], [1], [2]]             # 1 | 256 | 1
+
+
+def test_diag_block_kernel_prefetch_stays_inside_its_scratch():
+    """csrc/chol_diag2.hpp: the W phase of the diagonal-block kernel prefetches the L tile of product k + 8 of block
+    column c through ``tri_img(c, k)`` = image of tile (min(c + u_k, 15), min(c + v_k, row)); the scratch holds the
+    136 lower tiles of the block as 256-element images and is the LAST region of ``aux`` (``ssa_chol_aux_bytes``), so a
+    request past it would read beyond the caller's allocation.  The index arithmetic, restated: every request of every
+    column lands inside the scratch."""
+    NT, elems = 16, (16 * 17 // 2) * 256
+    tri = [(u, v) for u in range(1, NT) for v in range(u)]
+    assert len(tri) == NT * (NT - 1) // 2
+    worst = 0
+    for c in range(NT):
+        for k in range(len(tri)):
+            row = min(c + tri[k][0], NT - 1)
+            col = min(c + tri[k][1], row)
+            img = (row * (row + 1) // 2 + col) * 256
+            worst = max(worst, img + 256)
+    assert worst <= elems
+    src = open(os.path.join(ROOT, "superscreen_amd", "csrc", "chol_diag2.hpp")).read()
+    assert "img_of(I, min(c + kTriV[k], I))" in src and "scratch + tri_img(c, k" in src

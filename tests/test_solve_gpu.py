@@ -978,6 +978,24 @@ def test_chain_streams_are_calibrated():
     assert sorted(groups[:pipes]) == list(range(1, pipes + 1)), (costs, groups)   # ... one of every pipe to begin with,
     assert costs[:pipes] == sorted(costs[:pipes]), (costs, groups)                # the cheapest pipe first
     assert costs[0] == min(costs), (costs, groups)
+    # the measurements can be dropped (a caller that creates / destroys streams between factorizations): nothing is
+    # known until the next factorization, which measures again -- with four matrices in one schedule this time
+    from superscreen_amd import _hip
+    _hip.check(_hip.load_library().ssa_chol_chain_streams_invalidate(), "ssa_chol_chain_streams_invalidate")
+    assert kernels.chol_chain_stream_costs() == ([], [])
+    four = []
+    for k in range(4):
+        t = torch.zeros((npad, npad), dtype=torch.float64, device="cuda")
+        t[:n, :n] = torch.from_numpy(S_host + k * np.eye(n)).cuda()
+        four.append((t, n))
+    fs = kernels.chol_factor_batch(four)
+    torch.cuda.synchronize()
+    assert all(int(x.info_device.item()) == 0 for x in fs)
+    for k, x in enumerate(fs):
+        Lk = torch.tril(x.L[:n, :n]).cpu().numpy()
+        assert np.abs(Lk @ Lk.T - (S_host + k * np.eye(n))).max() < 1e-9 * np.abs(S_host).max()
+    costs2, groups2 = kernels.chol_chain_stream_costs()
+    assert len(costs2) == 16 and sum(g > 0 for g in groups2) >= 2, (costs2, groups2)
 
 
 @pytest.mark.gpu
