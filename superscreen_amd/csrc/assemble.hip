@@ -15,7 +15,9 @@
 
 namespace ssa {
 
-constexpr int kStripRows = 16;
+constexpr int kStripRows = 16;    // system_assemble_kernel
+constexpr int kQStripRows = 24;   // q_assemble_kernel: at most this many rows per workgroup
+constexpr int kQGroupsPerCu = 5;  // ... and a whole number of rounds of this many workgroups per CU
 constexpr int kAsmThreads = 256;
 
 template <typename OutT>
@@ -39,10 +41,14 @@ __device__ __forceinline__ void store_pair(OutT *p, OutT a, OutT b) {
 
 // Q_ij = -q_ij (i != j), Q_ii = (C_i + sum_{l != i} q_il w_l) / w_i.
 //
-// Rows per workgroup: the grid is a whole number of "rounds" of the chip's resident workgroup slots and the
-// n rows are dealt out evenly (heights differ by at most one row, <= TR): with fixed 16-row strips a matrix
-// of 25 117 rows is 1 570 workgroups on 1 024 slots, i.e. two rounds of 16 rows for 1.53 rounds of work
-// (every workgroup streams at the same rate, so the second round runs half empty).
+// Rows per workgroup: the grid is a whole number of "rounds" of kQGroupsPerCu workgroups per CU and the n rows are
+// dealt out evenly (heights differ by at most one row, <= TR).  Measured (tools/probes/q_probe.hip, round 4, same
+// box, n = 25 117 / 50 311): 16-row strips on 7-8 resident workgroups per CU 4.97-5.05 / 5.40-5.42 TB/s, 24-row
+// strips in rounds of 5 per CU 5.31-5.35 / 5.58-5.66 TB/s against 5.44-5.47 / 5.55-5.69 TB/s for the same store
+// stream with nothing to compute -- fewer, taller workgroups keep fewer write streams open at a time.  What the
+// loop keeps out of scalar registers matters as much: per-row store addresses and row indices as scalars cost 88
+// SGPR spills (a v_readlane per use) in the 16-row version, 4.5 TB/s; here the store address advances by one row
+// per step and the diagonal is found from the lane's own distance to the strip, row coordinates come from LDS.
 __host__ __device__ inline void strip_rows(int64_t n, int64_t groups, int64_t b, int64_t *i0, int *h) {
     const int64_t base = n / groups, extra = n % groups;
     *i0 = b * base + (b < extra ? b : extra);
@@ -54,46 +60,56 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
     const double *__restrict__ xy, const double *__restrict__ w, const double *__restrict__ C,
     int64_t n, OutT *__restrict__ Q, int64_t ldq, double *__restrict__ qdiag) {
     __shared__ double s_part[kAsmThreads / kWave][TR];
+    __shared__ double2 s_xy[TR];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     int64_t i0;
     int h;  // rows of this workgroup, 1 .. TR (workgroup-uniform)
     strip_rows(n, gridDim.x, blockIdx.x, &i0, &h);
-
-    // Row coordinates are workgroup-uniform: scalar loads into SGPRs, no LDS traffic.
-    double xi[TR], yi[TR];
-#pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        const int64_t i = (r < h) ? i0 + r : i0;
-        xi[r] = xy[2 * i];
-        yi[r] = xy[2 * i + 1];
+    if (tid < TR) {
+        const int64_t i = (tid < h) ? i0 + tid : i0;
+        s_xy[tid] = *reinterpret_cast<const double2 *>(xy + 2 * i);
     }
+    __syncthreads();
     double acc[TR];
 #pragma unroll
     for (int r = 0; r < TR; ++r) acc[r] = 0.0;
 
-    for (int64_t j = 2 * tid; j < n; j += 2 * kAsmThreads) {
+    // Workgroup b starts its sweep 512 columns further right than workgroup b - 1 and wraps around: the workgroups
+    // resident at a time then do not all write the same column range of their rows (store stream alone at
+    // n = 50 311: 5.55 -> 5.66-5.69 TB/s).
+    const int64_t span = ((n + 2 * kAsmThreads - 1) / (2 * kAsmThreads)) * (2 * kAsmThreads);
+    const int64_t shift = (static_cast<int64_t>(blockIdx.x) * 2 * kAsmThreads) % span;
+    for (int64_t jj = 2 * tid; jj < span; jj += 2 * kAsmThreads) {
+        int64_t j = jj + shift;
+        if (j >= span) j -= span;
+        if (j >= n) continue;
         const bool has1 = (j + 1 < n);
         const double xj0 = xy[2 * j], yj0 = xy[2 * j + 1];
         const double xj1 = has1 ? xy[2 * j + 2] : 0.0;
         const double yj1 = has1 ? xy[2 * j + 3] : 0.0;
         const double w0 = w[j];
         const double w1 = has1 ? w[j + 1] : 0.0;
+        OutT *qp = (Q != nullptr) ? Q + i0 * ldq + j : nullptr;
+        const int dj = static_cast<int>(j - i0);   // row r is on the diagonal of column j when dj == r
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             if (r < h) {  // uniform branch: rows beyond this workgroup's share cost nothing
-                const int64_t i = i0 + r;
-                const double dx0 = xi[r] - xj0, dy0 = yi[r] - yj0;
-                const double dx1 = xi[r] - xj1, dy1 = yi[r] - yj1;
+                int off = r * 16;   // one LDS read per use (hidden from loop-invariant code motion: 4 TR registers)
+                asm volatile("" : "+v"(off));
+                const double2 pr = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_xy) + off);
+                const double dx0 = pr.x - xj0, dy0 = pr.y - yj0;
+                const double dx1 = pr.x - xj1, dy1 = pr.y - yj1;
                 double q0 = inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
                 double q1 = inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
-                q0 = (i == j) ? 0.0 : q0;                  // distance.py:104-105
-                q1 = (i == j + 1 || !has1) ? 0.0 : q1;
+                q0 = (dj == r) ? 0.0 : q0;                   // distance.py:104-105
+                q1 = (dj + 1 == r || !has1) ? 0.0 : q1;
                 acc[r] = __builtin_fma(q0, w0, acc[r]);
                 acc[r] = __builtin_fma(q1, w1, acc[r]);
                 if (Q != nullptr) {
-                    store_pair<OutT>(Q + i * ldq + j, static_cast<OutT>(-q0), static_cast<OutT>(-q1));
+                    store_pair<OutT>(qp, static_cast<OutT>(-q0), static_cast<OutT>(-q1));
+                    qp += ldq;
                 }
             }
         }
@@ -116,25 +132,14 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
     }
 }
 
-// Number of workgroups for n rows: a whole number of rounds of the kernel's resident slots on this device
-// (every CU then holds the same number of equally long workgroups), plain ceil(n / TR) strips for small n.
-template <typename Kernel>
-inline int64_t balanced_groups(Kernel kernel, int64_t n, int tr) {
-    static int slots_of_device[kMaxDevices] = {};
-    int dev = 0;
-    int64_t plain = ceil_div(n, tr);
-    if (current_device(&dev) != SSA_OK) return plain;
-    if (slots_of_device[dev] == 0) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kAsmThreads, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu <= 0)
-            return plain;
-        slots_of_device[dev] = per_cu * cus;
-    }
-    // one workgroup per slot and round; below ~8 rows per workgroup the per-row share of the column loads
-    // grows and the launch is latency bound anyway: plain strips
-    const int64_t slots = slots_of_device[dev];
-    if (n < 8 * slots) return plain;
+// Number of workgroups for n rows: a whole number of rounds of kQGroupsPerCu workgroups per CU (every CU then holds
+// the same number of equally long workgroups), plain ceil(n / TR) strips for small n.
+inline int64_t balanced_groups(int64_t n, int tr) {
+    const int64_t plain = ceil_div(n, tr);
+    const int64_t slots = static_cast<int64_t>(device_cu_count()) * kQGroupsPerCu;
+    // below ~8 rows per workgroup the per-row share of the column loads grows and the launch is latency bound
+    // anyway: plain strips
+    if (slots <= 0 || n < 8 * slots) return plain;
     return slots * ceil_div(n, static_cast<int64_t>(tr) * slots);
 }
 
@@ -253,12 +258,12 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
     if (Q && (ldq < n || (ldq & 1))) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype == SSA_F64) {
-        const dim3 grid(static_cast<unsigned>(balanced_groups(q_assemble_kernel<double, kStripRows>, n, kStripRows)));
-        hipLaunchKernelGGL((q_assemble_kernel<double, kStripRows>), grid, dim3(kAsmThreads), 0,
+        const dim3 grid(static_cast<unsigned>(balanced_groups(n, kQStripRows)));
+        hipLaunchKernelGGL((q_assemble_kernel<double, kQStripRows>), grid, dim3(kAsmThreads), 0,
                            as_stream(stream), xy, w, C, n, static_cast<double *>(Q), ldq, qdiag);
     } else {
-        const dim3 grid(static_cast<unsigned>(balanced_groups(q_assemble_kernel<float, kStripRows>, n, kStripRows)));
-        hipLaunchKernelGGL((q_assemble_kernel<float, kStripRows>), grid, dim3(kAsmThreads), 0,
+        const dim3 grid(static_cast<unsigned>(balanced_groups(n, kQStripRows)));
+        hipLaunchKernelGGL((q_assemble_kernel<float, kQStripRows>), grid, dim3(kAsmThreads), 0,
                            as_stream(stream), xy, w, C, n, static_cast<float *>(Q), ldq, qdiag);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();

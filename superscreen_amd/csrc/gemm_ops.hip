@@ -163,23 +163,22 @@ __device__ __forceinline__ void tile_full_f32_nt(int64_t K, float alpha, const f
     opa.issue(0, sm.a[0], wave);
     opb.issue(0, sm.b[0], wave);
 
-    acc_t acc[4][4];
+    // float32: products summed from zero, C joins in the epilogue (see gemm_tile_full_f32, gemm.hip: with the
+    // accumulators started at C every product is rounded at the magnitude of C); C is loaded here all the same
+    acc_t acc[4][4], cin[4][4];
     float *Cw = C + (m0 + wm * 64) * ldc + n0 + wn * 64 + li;
-    if (beta != 0.0f) {
-        const float scale = beta / alpha;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = acc_t{0, 0, 0, 0};
+            if (beta != 0.0f) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = scale * Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-    }
+                for (int r = 0; r < 4; ++r) cin[i][j][r] = Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+            } else {
+                cin[i][j] = acc_t{0, 0, 0, 0};
+            }
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -220,7 +219,8 @@ __device__ __forceinline__ void tile_full_f32_nt(int64_t K, float alpha, const f
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] =
+                    __builtin_fmaf(alpha, acc[i][j][r], beta * cin[i][j][r]);
 }
 
 // ---- SMALL-TILE path, NT: 32 x 128 tile per workgroup ------------------------------------------
@@ -280,23 +280,26 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
     };
     // the C tile first (oldest in the vmcnt order; raw values, scaled after the first wait so that nothing
     // forces them to arrive before the stages are issued), then the first SNST - 1 stages
-    acc_t acc[2][2];
+    // (float32: the C tile is kept apart and joins the products in the epilogue, see gemm_tile_full_f32, gemm.hip)
+    constexpr bool kSplitC = sizeof(T) == 4;
+    acc_t acc[2][2], cin[2][2];
     T *Cw = C + m0 * ldc + n0 + wave * 32 + li;
     const bool has_c = (beta != T(0));
-    if (has_c) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = acc_t{0, 0, 0, 0};
+            cin[i][j] = acc_t{0, 0, 0, 0};
+            if (has_c) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-    }
+                for (int r = 0; r < 4; ++r) {
+                    const T v = Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16];
+                    if (kSplitC) cin[i][j][r] = v;
+                    else acc[i][j][r] = v;
+                }
+            }
+        }
     const int64_t nk = K8 / KC;
 #pragma unroll
     for (int p = 0; p < SNST - 1; ++p)
@@ -312,7 +315,7 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
         // raw barrier: __syncthreads() carries a fence that drains every load in flight (vmcnt(0)), which is
         // exactly what the ring must not do; each wave has waited for its own share of stage kt above
         __builtin_amdgcn_s_barrier();
-        if (kt == 0 && has_c) {
+        if (kt == 0 && has_c && !kSplitC) {
             const T scale = beta / alpha;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -349,7 +352,8 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] = alpha * acc[i][j][r];
+                Cw[static_cast<int64_t>(i * 16 + MF::row(lane, r)) * ldc + j * 16] =
+                    kSplitC ? alpha * acc[i][j][r] + beta * cin[i][j][r] : alpha * acc[i][j][r];
 }
 
 template <typename T>

@@ -23,7 +23,7 @@ __host__ __device__ inline void rows_of(int64_t n, int64_t groups, int64_t b, in
 }
 
 // CPL columns per lane (2: one 16-byte store per row and lane; 4: two adjacent ones, 2 KiB per wave and row)
-template <int MODE, int TR, int CPL>
+template <int MODE, int TR, int CPL, bool LDSROWS = false, int STAGGER = 0>
 __global__ __launch_bounds__(256) void q_kernel(const double *__restrict__ xy, const double *__restrict__ w, int64_t n,
                                                 double *__restrict__ Q, int64_t ldq, double *__restrict__ rowsum) {
     extern __shared__ char pad_lds[];   // occupancy cap only
@@ -32,15 +32,32 @@ __global__ __launch_bounds__(256) void q_kernel(const double *__restrict__ xy, c
     int64_t i0;
     int h;
     rows_of(n, gridDim.x, blockIdx.x, &i0, &h);
-    double xi[TR], yi[TR], acc[TR];
+    __shared__ double2 s_xy[TR];
+    double xi[LDSROWS ? 1 : TR], yi[LDSROWS ? 1 : TR], acc[TR];
+    if (LDSROWS) {
+        if (tid < TR) {
+            const int64_t i = (tid < h) ? i0 + tid : i0;
+            s_xy[tid] = *reinterpret_cast<const double2 *>(xy + 2 * i);
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < TR; ++r) {
-        const int64_t i = (r < h) ? i0 + r : i0;
-        xi[r] = xy[2 * i];
-        yi[r] = xy[2 * i + 1];
+        if (!LDSROWS) {
+            const int64_t i = (r < h) ? i0 + r : i0;
+            xi[r] = xy[2 * i];
+            yi[r] = xy[2 * i + 1];
+        }
         acc[r] = 0.0;
     }
-    for (int64_t j = CPL * tid; j < n; j += CPL * 256) {
+    // STAGGER: workgroup b starts its sweep STAGGER x 512 columns further right than workgroup b - 1 (and wraps), so
+    // that the workgroups resident at a time do not all write the same column range of their rows
+    const int64_t span = (n + CPL * 256 - 1) / (CPL * 256) * (CPL * 256);
+    const int64_t shift = STAGGER ? (static_cast<int64_t>(blockIdx.x) * STAGGER * CPL * 256) % span : 0;
+    for (int64_t jj = CPL * tid; jj < span; jj += CPL * 256) {
+        int64_t j = jj + shift;
+        if (j >= span) j -= span;
+        if (j >= n) continue;
         double xj[CPL], yj[CPL], wj[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -49,20 +66,31 @@ __global__ __launch_bounds__(256) void q_kernel(const double *__restrict__ xy, c
             yj[c] = has ? xy[2 * (j + c) + 1] : 0.0;
             wj[c] = has ? w[j + c] : 0.0;
         }
+        // row-invariant scalars kept out of SGPRs: the store address advances by one row per step, the diagonal is
+        // found by the lane's own distance to the strip's first row
+        double *qp = Q + i0 * ldq + j;
+        const int dj = static_cast<int>(j - i0);   // row r is on the diagonal of column j + c when dj + c == r
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             if (r < h) {
-                const int64_t i = i0 + r;
                 double q[CPL];
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     if (MODE == STORE_ONLY) {
                         q[c] = xj[c];
                     } else {
-                        const double dx = xi[r] - xj[c], dy = yi[r] - yj[c];
+                        double2 pr;
+                        if (LDSROWS) {
+                            int off = r * 16;   // an LDS read per use: hidden from loop-invariant code motion
+                            asm volatile("" : "+v"(off));
+                            pr = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_xy) + off);
+                        } else {
+                            pr = double2{xi[r], yi[r]};
+                        }
+                        const double dx = pr.x - xj[c], dy = pr.y - yj[c];
                         const double r2 = __builtin_fma(dx, dx, dy * dy);
                         q[c] = (MODE == SEED_ONLY) ? __builtin_amdgcn_rsq(r2) : inv_r3_over_4pi(r2);
-                        q[c] = (i == j + c || j + c >= n) ? 0.0 : q[c];
+                        q[c] = (dj + c == r || j + c >= n) ? 0.0 : q[c];
                         acc[r] = __builtin_fma(q[c], wj[c], acc[r]);
                     }
                 }
@@ -72,9 +100,10 @@ __global__ __launch_bounds__(256) void q_kernel(const double *__restrict__ xy, c
                         double2 v;
                         v.x = -q[c];
                         v.y = -q[c + 1];
-                        *reinterpret_cast<double2 *>(Q + i * ldq + j + c) = v;
+                        *reinterpret_cast<double2 *>(qp + c) = v;
                     }
                 }
+                qp += ldq;
             }
         }
     }
@@ -121,17 +150,17 @@ static double time_ms(F f, int reps = 7) {
     return ts[ts.size() / 2];
 }
 
-template <int MODE, int TR, int CPL>
+template <int MODE, int TR, int CPL, bool LDSROWS = false, int STAGGER = 0>
 static void run(const char *name, const double *xy, const double *w, int64_t n, double *Q, int64_t ld, double *rs,
                 int groups_per_cu, size_t lds_pad) {
     if (lds_pad > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&q_kernel<MODE, TR, CPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&q_kernel<MODE, TR, CPL, LDSROWS, STAGGER>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds_pad));
     const int64_t slots = 256 * groups_per_cu;
     const int64_t groups = slots * ((n + static_cast<int64_t>(TR) * slots - 1) / (static_cast<int64_t>(TR) * slots));
-    const double ms = time_ms([&] { hipLaunchKernelGGL((q_kernel<MODE, TR, CPL>), dim3(groups), dim3(256), lds_pad, 0, xy, w, n, Q, ld, rs); });
+    const double ms = time_ms([&] { hipLaunchKernelGGL((q_kernel<MODE, TR, CPL, LDSROWS, STAGGER>), dim3(groups), dim3(256), lds_pad, 0, xy, w, n, Q, ld, rs); });
     const double gb = static_cast<double>(n) * n * 8 / 1e9;
-    printf("%-44s TR=%2d cpl=%d wg/cu=%d groups=%5lld: %7.3f ms  %6.0f GB/s\n", name, TR, CPL, groups_per_cu,
+    printf("%-30s stagger=%d lds=%d cap=%3zuK TR=%2d cpl=%d wg/cu=%d groups=%5lld: %7.3f ms  %6.0f GB/s\n", name, STAGGER, int(LDSROWS), lds_pad >> 10, TR, CPL, groups_per_cu,
            static_cast<long long>(groups), ms, gb / ms * 1e3);
 }
 
@@ -150,16 +179,23 @@ int main(int argc, char **argv) {
     printf("n = %lld (K = %d), %.2f GB\n", static_cast<long long>(n), K, static_cast<double>(n) * n * 8 / 1e9);
     const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
     printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
-    const size_t cap[9] = {0, 150 * 1024, 80 * 1024, 52 * 1024, 40 * 1024, 32 * 1024, 26 * 1024, 22 * 1024, 0};
-    for (int rep = 0; rep < 2; ++rep) {
-        run<FULL, 16, 2>("full (production shape)", xy, w, n, Q, ld, rs, 7, 0);
+    for (int rep = 0; rep < 3; ++rep) {
+        run<FULL, 16, 2>("production", xy, w, n, Q, ld, rs, 7, 0);
         run<STORE_ONLY, 16, 2>("store only", xy, w, n, Q, ld, rs, 7, 0);
-        for (int g = 2; g <= 6; ++g) run<FULL, 24, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
-        for (int g = 2; g <= 6; ++g) run<FULL, 32, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
-        for (int g = 2; g <= 5; ++g) run<FULL, 48, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
-        for (int g = 2; g <= 4; ++g) run<FULL, 64, 2>("full", xy, w, n, Q, ld, rs, g, cap[g]);
-        run<STORE_ONLY, 32, 2>("store only", xy, w, n, Q, ld, rs, 4, cap[4]);
-        run<STORE_ONLY, 64, 2>("store only", xy, w, n, Q, ld, rs, 4, cap[4]);
+        run<STORE_ONLY, 16, 2, false, 1>("store only", xy, w, n, Q, ld, rs, 7, 0);
+        run<STORE_ONLY, 16, 2, false, 3>("store only", xy, w, n, Q, ld, rs, 7, 0);
+        run<STORE_ONLY, 16, 2, false, 7>("store only", xy, w, n, Q, ld, rs, 7, 0);
+        run<STORE_ONLY, 32, 2, true, 1>("store only", xy, w, n, Q, ld, rs, 4, 0);
+        run<STORE_ONLY, 32, 2, true, 5>("store only", xy, w, n, Q, ld, rs, 4, 0);
+        run<STORE_ONLY, 8, 2, false, 1>("store only", xy, w, n, Q, ld, rs, 8, 0);
+        run<FULL, 16, 2, false, 1>("full", xy, w, n, Q, ld, rs, 7, 0);
+        run<FULL, 16, 2, false, 3>("full", xy, w, n, Q, ld, rs, 7, 0);
+        run<FULL, 24, 2, false, 1>("full", xy, w, n, Q, ld, rs, 5, 0);
+        run<FULL, 24, 2, false, 3>("full", xy, w, n, Q, ld, rs, 5, 0);
+        run<FULL, 32, 2, true, 1>("full", xy, w, n, Q, ld, rs, 4, 0);
+        run<FULL, 32, 2, true, 3>("full", xy, w, n, Q, ld, rs, 4, 0);
+        run<FULL, 24, 2>("full", xy, w, n, Q, ld, rs, 5, 0);
+        run<FULL, 32, 2, true>("full", xy, w, n, Q, ld, rs, 4, 0);
     }
     return 0;
 }
