@@ -15,7 +15,7 @@
 
 namespace ssa {
 
-constexpr int kStripRows = 16;    // system_assemble_kernel
+constexpr int kStripRows = 24;    // system_assemble_kernel
 constexpr int kQStripRows = 24;   // q_assemble_kernel: at most this many rows per workgroup
 constexpr int kQGroupsPerCu = 5;  // ... and a whole number of rounds of this many workgroups per CU
 constexpr int kAsmThreads = 256;
@@ -182,9 +182,15 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     // lower_only: a strip's work grows with its row index; the long strips go first so that the short
-    // ones fill the end of the launch
+    // ones fill the end of the launch.  Full matrices: the rows are dealt out evenly over the grid (a whole number
+    // of rounds of kQGroupsPerCu workgroups per CU, see q_assemble_kernel), nr_end = first row of the next strip.
     const int64_t strip = lower_only ? static_cast<int64_t>(gridDim.x) - 1 - blockIdx.x : blockIdx.x;
-    const int64_t r0 = strip * TR;
+    int64_t r0 = strip * TR, nr_end = nr;
+    if (!lower_only) {
+        int h;
+        strip_rows(nr, gridDim.x, blockIdx.x, &r0, &h);
+        nr_end = r0 + h;
+    }
     if (tid < TR) {
         const int64_t r = (r0 + tid < nr) ? r0 + tid : nr - 1;
         s_x[tid] = row_x[r];
@@ -197,7 +203,13 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
 
     // lower_only (rows == cols): nothing right of the strip's last diagonal entry is needed
     const int64_t c_end = (lower_only && r0 + TR < nc) ? r0 + TR : nc;
-    for (int64_t c = 2 * tid; c < c_end; c += 2 * kAsmThreads) {
+    // (full matrices: staggered sweeps, see q_assemble_kernel)
+    const int64_t span = (c_end + 2 * kAsmThreads - 1) / (2 * kAsmThreads) * (2 * kAsmThreads);
+    const int64_t shift = lower_only ? 0 : (static_cast<int64_t>(blockIdx.x) * 2 * kAsmThreads) % span;
+    for (int64_t cc = 2 * tid; cc < span; cc += 2 * kAsmThreads) {
+        int64_t c = cc + shift;
+        if (c >= span) c -= span;
+        if (c >= c_end) continue;
         const bool has1 = (c + 1 < nc);
         const double xj0 = col_x[c], yj0 = col_y[c];
         const double xj1 = has1 ? col_x[c + 1] : 0.0;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
         const int64_t id1 = has1 ? col_id[c + 1] : -1;
 #pragma unroll 8
         for (int r = 0; r < TR; ++r) {
-            if (r0 + r >= nr) break;
+            if (r0 + r >= nr_end) break;
             const int64_t i = s_id[r];
             const double xi = s_x[r], yi = s_y[r];
             const double dx0 = xi - xj0, dy0 = yi - yj0;
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
 
     // - Lambda[j] * Del2[i, j]: one wave per row walks the CSR row (about 7 entries).
     for (int r = wave; r < TR; r += kAsmThreads / kWave) {
-        if (r0 + r >= nr) break;
+        if (r0 + r >= nr_end) break;
         const int64_t i = s_id[r];
         const int64_t p1 = lap_indptr[i + 1];
         for (int64_t p = lap_indptr[i] + lane; p < p1; p += kWave) {
@@ -313,7 +325,7 @@ extern "C" int ssa_system_assemble(const double *xy, const double *w, const doub
     hipLaunchKernelGGL(gather_vertex_kernel, dim3(ceil_div(nc, tb)), dim3(tb), 0, st, xy, w,
                        Lambda, cols, nc, col_x, col_y, col_w, col_lam, col_id, col_pos);
     const double *rs = row_scale ? row_rs : nullptr;
-    const dim3 grid(static_cast<unsigned>(ceil_div(nr, kStripRows)));
+    const dim3 grid(static_cast<unsigned>(lower_only ? ceil_div(nr, kStripRows) : balanced_groups(nr, kStripRows)));
     if (dtype == SSA_F64) {
         hipLaunchKernelGGL((system_assemble_kernel<double, kStripRows>), grid, dim3(kAsmThreads),
                            0, st, row_x, row_y, row_qd, row_id, nr, col_x, col_y, col_w, col_lam,

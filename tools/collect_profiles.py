@@ -126,7 +126,7 @@ def main():
     hbm["note"] = ("rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of tools/hbm_kernels.py (config H's films: five dense "
                    "Q assemblies, five 11-pass solves; dispatches serialized by the profiler); counters in KiB, FETCH x2 "
                    "on gfx950")
-    json.dump(hbm, open(os.path.join(prof, f"{tag}_hbm_pmc.json"), "w"), indent=1)
+    n_vertices = line["vertices_per_film"]
 
     dm, _ = run_pass("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64",
                               "--kernel-trace"], out_dir, args)
@@ -159,7 +159,8 @@ def main():
     trace = {r["Dispatch_Id"]: (r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
              for r in rows(find(dp, "kernel_trace.csv"))}
     for needle, label, npairs in (("biot_savart_partial_kernel<double", "biot_savart_partial_kernel<double> (inter-film coupling)", None),
-                                  ("self_field_rows_partial_kernel<double", "self_field_rows_partial_kernel<double>", None)):
+                                  ("self_field_rows_partial_kernel<double", "self_field_rows_partial_kernel<double>", None),
+                                  ("q_assemble_kernel<double", "q_assemble_kernel<double> (dense Q: vector-ALU side)", None)):
         per = {}
         for r in rows(find(dp, "counter_collection.csv")):
             if needle in r["Kernel_Name"]:
@@ -182,6 +183,16 @@ def main():
             "lds_bank_conflict_cycles_per_launch": tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / len(sel),
             "lds_active_cycles_per_launch": tot.get("SQ_LDS_IDX_ACTIVE", 0.0) / len(sel),
         }
+    # the dense Q assembly's issue side goes with its memory side (hbm_pmc): is it the FP64 work or the store stream?
+    qk = "q_assemble_kernel<double> (dense Q: vector-ALU side)"
+    if qk in pairs:
+        q = pairs.pop(qk)
+        # the five dense launches are the long ones of the pass (the row-sum-only launches of the factorizations are short)
+        q["valu_instructions_per_output_element"] = q["valu_instructions_per_launch"] * 64.0 / float(n_vertices) ** 2
+        q["note"] = ("all q_assemble launches of the pass (dense Q and the factorizations' row-sum-only launches alike); "
+                     "SQ_INSTS_VALU counts wave instructions: x 64 lanes / n^2 elements")
+        hbm["q_assemble_kernel (vector-ALU counters)"] = q
+    json.dump(hbm, open(os.path.join(prof, f"{tag}_hbm_pmc.json"), "w"), indent=1)
     pairs["note"] = ("rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
                      "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass of tools/hbm_kernels.py (config H's films, five "
                      "11-pass solves: 25 117 x ~22 000 pairs per coupling launch); SQ_* activity counters are quad-cycles")
