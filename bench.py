@@ -67,24 +67,31 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILES = ("r03_syrk_pmc.json", "r02b_syrk_pmc.json", "r02_syrk_pmc.json")
-PMC_MFMA_FILES = ("r03_syrk_mfma_pmc.json", "r02b_syrk_mfma_pmc.json", "r02_syrk_mfma_pmc.json")
+PMC_TRAFFIC_FILES = ("r04_syrk_pmc.json", "r03_syrk_pmc.json", "r02b_syrk_pmc.json")
+PMC_MFMA_FILES = ("r04_syrk_mfma_pmc.json", "r03_syrk_mfma_pmc.json", "r02b_syrk_mfma_pmc.json")
 
 
 def chol_schedule(unknowns, elem=8):
     """The trailing-update launches of the Cholesky schedule (chol.hip potrf_batch) for films with the given
     numbers of unknowns: per launch the lower 128 x 128 tiles of the trailing block are read and written once and
     the pending panels below them (256 columns, or 512 when the previous step's update was kept pending: large
-    trailing matrices, every other step) are read once.  The block starts behind the next panel.
+    trailing matrices, every other step) are read once.  The block starts behind the next panel.  Only the stream
+    part of the schedule launches this kernel: once every film's trailing matrix is at most 10 240 columns the
+    updates are tiles of the round launches.
     Returns (average algorithmic bytes per launch, launches per factorization)."""
     total, launches = 0.0, 0
-    for n in unknowns:
-        npad = -(-n // 256) * 256
-        upd0 = 0
-        for k0 in range(0, npad - 256, 256):
-            c = k0 + 256
+    npads = [-(-n // 256) * 256 for n in unknowns]
+    nmax = max(npads)
+    upd0 = [0] * len(npads)
+    for k0 in range(0, nmax - 256, 256):
+        c = k0 + 256
+        if nmax - c <= 10240:   # from here on the schedule runs as rounds (chol_tail_round_kernel, not this kernel)
+            break
+        for f, npad in enumerate(npads):
+            if c >= npad:
+                continue
             right = npad - c
-            kp = c - upd0
+            kp = c - upd0[f]
             delay = kp < 512 and right > 8192 and ((k0 + npad) // 256) % 2 != 1
             if right > 256 and not delay:
                 m = npad - (c + 256)
@@ -92,7 +99,7 @@ def chol_schedule(unknowns, elem=8):
                 total += 2.0 * (nt * (nt + 1) // 2) * 128 * 128 * elem + m * kp * elem
                 launches += 1
             if not delay:
-                upd0 = c
+                upd0[f] = c
     return total / max(1, launches), launches
 
 
