@@ -481,7 +481,7 @@ __device__ __forceinline__ void lower_band_tile(int64_t id, int64_t ntm, int64_t
     } else {
         l -= r0 * R;
         int64_t j = 0;
-        while (l >= R - j) {  // column r0 + j holds rows r0 + j .. r0 + R - 1
+        while (j + 1 < R && l >= R - j) {  // column r0 + j holds rows r0 + j .. r0 + R - 1  (j < R: an id past the last tile ends here)
             l -= R - j;
             ++j;
         }
