@@ -114,13 +114,13 @@ def main():
             "algorithmic_bytes": n * n * 8, "avg_ms": sum(secs) / max(1, len(secs)) * 1e3,
             "HBM_write_TBps": (sum(big) / len(big) * 1024.0) / (sum(secs) / max(1, len(secs))) / 1e12 if secs else None}
     fg = [(r["Dispatch_Id"], float(r["Counter_Value"])) for r in rows(fcsv)
-          if r["Counter_Name"] == "FETCH_SIZE" and "gemv_kernel<double, 4, true, 0>" in r["Kernel_Name"]]
+          if r["Counter_Name"] == "FETCH_SIZE" and "gemv_batch_kernel<double, 0>" in r["Kernel_Name"]]
     tg = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-          for r in rows(find(df, "kernel_trace.csv")) if "gemv_kernel<double, 4, true, 0>" in r["Kernel_Name"]}
+          for r in rows(find(df, "kernel_trace.csv")) if "gemv_batch_kernel<double, 0>" in r["Kernel_Name"]}
     if fg:
         tot_b = 2.0 * sum(v for _, v in fg) * 1024.0
         tot_s = sum(tg[i] for i, _ in fg if i in tg)
-        hbm["gemv_kernel<double, 4, true, 0> (triangular-solve chain, all launches of the run)"] = {
+        hbm["gemv_batch_kernel<double, 0> (the rectangular blocks of the triangular-solve chain, all launches of the run)"] = {
             "launches": len(fg), "FETCH_SIZE_bytes_total_x2": tot_b, "total_ms": tot_s * 1e3,
             "HBM_read_TBps": tot_b / tot_s / 1e12 if tot_s else None}
     hbm["note"] = ("rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of tools/hbm_kernels.py (config H's films: five dense "

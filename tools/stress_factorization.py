@@ -33,3 +33,19 @@ for K, kinds in ((91, ("washer", "disk")), (60, ("washer", "disk", "washer", "di
         assert (g == ref).all(), (K, rep, "not reproducible")
         del model
     print(f"K={K} films={len(kinds)}: {reps} cold factorizations, worst residual {worst:.2e}, solutions bit-identical")
+
+# routes and precisions interleaved in one process (Cholesky and LU schedules share the chain-stream pool; every change
+# of route re-uses streams the other route just left)
+device64 = synthetic.make_stack_device(64, ("washer", "disk"), solve_dtype="float64")
+device32 = synthetic.make_stack_device(64, ("washer", "disk"), solve_dtype="float32")
+first = {}
+for rep in range(max(4, reps // 5)):
+    for dev, method in ((device64, "auto"), (device32, "auto"), (device64, "lu"), (device32, "lu")):
+        model = sc.factorize_model(device=dev, current_units="uA", method=method)
+        g = sc.solve(model=model, applied_field=sc.ConstantField(0.7), iterations=2)[-1].film_solutions["disk1"].stream
+        key = (dev.solve_dtype, method)
+        if key not in first:
+            first[key] = g
+        assert (g == first[key]).all(), (key, rep, "not reproducible")
+        del model
+print(f"interleaved routes: {max(4, reps // 5)} x (cholesky f64, cholesky f32, lu f64, lu f32), solutions bit-identical")
