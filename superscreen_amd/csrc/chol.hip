@@ -449,16 +449,22 @@ struct FinishPlan {
         const CholJob<T> &J = *job;
         if (upto > nfull()) upto = nfull();
         if (upto <= done) return SSA_OK;
-        int rc;
+        int rc = SSA_OK;
         for (int64_t h = 256; h < SNB; h *= 2) {
             rc = inverse_level(J, h, false, done, upto, st, sliced);
             if (rc != SSA_OK) return rc;
             rc = inverse_level(J, h, true, done, upto, st, sliced);
             if (rc != SSA_OK) return rc;
         }
-        rc = inverse_transposes(J, done, upto, st);
+        // (beside the rounds these two go out in pieces as well: a transpose launch of a whole block is 4 096 / 20 000
+        // short workgroups that take every free slot for 0.2-0.7 ms -- the rounds' panel and strip launches waited
+        // behind them for up to 0.9 ms)
+        for (int64_t j = done; j < upto && rc == SSA_OK; j += (sliced ? 1 : upto - done))
+            rc = inverse_transposes(J, j, sliced ? j + 1 : upto, st);
         if (rc != SSA_OK) return rc;
-        rc = mirror_columns(J, done * SNB, upto * SNB, st);
+        const int64_t piece = sliced ? 512 : (upto - done) * SNB;
+        for (int64_t c0 = done * SNB; c0 < upto * SNB && rc == SSA_OK; c0 += piece)
+            rc = mirror_columns(J, c0, std::min(c0 + piece, upto * SNB), st);
         if (rc != SSA_OK) return rc;
         done = upto;
         return SSA_OK;
