@@ -117,6 +117,26 @@ __global__ void fill_wave_rows16(u32x4 *__restrict__ dst, size_t n_rows, size_t 
             }
 }
 
+// band form: workgroup = (column band of BW 16-byte columns, row group); all workgroups sweep their rows top to bottom
+// in step, so the chip fills a window of `groups` consecutive rows at a time.  STORERS waves of the workgroup do the
+// storing (the others would only compute): STORERS = waves of the workgroup -> every wave stores its own share.
+template <int THREADS, int STORERS>
+__global__ __launch_bounds__(THREADS) void fill_bands16(u32x4 *__restrict__ dst, size_t n_rows, size_t row16, int bands, int groups) {
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    const int band = blockIdx.x % bands, grp = blockIdx.x / bands;
+    const size_t bw = (row16 + bands - 1) / bands;                 // 16-byte columns per band
+    const size_t c0 = band * bw, c1 = (c0 + bw < row16) ? c0 + bw : row16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= STORERS) return;
+    const size_t rows_per = (n_rows + groups - 1) / groups;
+    // row-interleaved groups: group g takes rows g, g + groups, ... -> at any time the chip is on `groups` ADJACENT rows
+    for (size_t k = 0; k < rows_per; ++k) {
+        const size_t r = k * groups + grp;
+        if (r >= n_rows) break;
+        for (size_t c = c0 + wave * 64 + lane; c < c1; c += STORERS * 64) dst[r * row16 + c] = v;
+    }
+}
+
 template <typename F>
 double time_ms(F launch, int reps = 7) {
     hipEvent_t a, b;
@@ -147,6 +167,27 @@ int main(int argc, char **argv) {
     printf("buffer %.3f GB (%zu rows x %zu B)\n", bytes / 1e9, n_rows, row16 * 16);
     auto report = [&](const char *name, double ms) { printf("%-58s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6); fflush(stdout); };
     u32x4 *d = static_cast<u32x4 *>(buf);
+    for (int thr : {256, 512, 1024})
+        for (int wgs : {128, 256, 512, 768}) {
+            char nm[128];
+            snprintf(nm, sizeof nm, "grid-stride 16B plain, %d WG x %d", wgs, thr);
+            report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(wgs), dim3(thr), 0, 0, d, count16); }));
+        }
+    report("hipMemsetAsync", time_ms([&] { hipMemsetAsync(buf, 0, bytes, 0); }));
+    for (int bands : {13, 25, 50}) {
+        const int groups = 256 / bands;
+        char nm[128];
+        snprintf(nm, sizeof nm, "bands: %d x %d groups, 256 thr, 4 storing waves", bands, groups);
+        report(nm, time_ms([&] { hipLaunchKernelGGL((fill_bands16<256, 4>), dim3(bands * groups), dim3(256), 0, 0, d, n_rows, row16, bands, groups); }));
+        snprintf(nm, sizeof nm, "bands: %d x %d groups, 1024 thr, 4 storing waves", bands, groups);
+        report(nm, time_ms([&] { hipLaunchKernelGGL((fill_bands16<1024, 4>), dim3(bands * groups), dim3(1024), 0, 0, d, n_rows, row16, bands, groups); }));
+        snprintf(nm, sizeof nm, "bands: %d x %d groups, 1024 thr, 16 storing waves", bands, groups);
+        report(nm, time_ms([&] { hipLaunchKernelGGL((fill_bands16<1024, 16>), dim3(bands * groups), dim3(1024), 0, 0, d, n_rows, row16, bands, groups); }));
+        snprintf(nm, sizeof nm, "bands: %d x %d groups, 512 thr, 8 storing waves", bands, groups);
+        report(nm, time_ms([&] { hipLaunchKernelGGL((fill_bands16<512, 8>), dim3(bands * groups), dim3(512), 0, 0, d, n_rows, row16, bands, groups); }));
+        snprintf(nm, sizeof nm, "bands: %d x %d groups (2 WG/CU), 256 thr, 4 storing waves", bands, 2 * groups);
+        report(nm, time_ms([&] { hipLaunchKernelGGL((fill_bands16<256, 4>), dim3(bands * 2 * groups), dim3(256), 0, 0, d, n_rows, row16, bands, 2 * groups); }));
+    }
     for (int wgs : {1024, 2048, 4096, 8192, 16384}) {
         char nm[128];
         snprintf(nm, sizeof nm, "grid-stride 16B plain, %d WG x 256", wgs);
