@@ -586,7 +586,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
     // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' products
-    constexpr int kDelayDepth = 2;            // (3 / 4 panels: 107 / 108 against 101.5-102.8 ms, round 3)
+    constexpr int kDelayDepth = 2;            // (3 / 4 panels: 107 / 108 against 101.5-102.8 ms in round 3; with the rounds
+                                              // behind the stream part, round 4: 96.4 / 100.4 against 94.6 ms)
     constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 16384: flat within 1 %, rounds 2 and 3)
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
