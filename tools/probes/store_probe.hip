@@ -137,6 +137,29 @@ __global__ __launch_bounds__(THREADS) void fill_bands16(u32x4 *__restrict__ dst,
     }
 }
 
+// address-ordered tasks: task t = (row group of R rows, chunk of CH x 4 KiB of those rows), tasks in address order
+// (row group major), dealt round-robin to a persistent grid: workgroup b runs tasks b, b + G, ...; a task = R rows x
+// (CH x 256 lanes x 16 B) written row by row.  R = 1: the grid-stride fill in row-aligned pieces.
+template <int R, int CH>
+__global__ __launch_bounds__(256) void fill_tasks16(u32x4 *__restrict__ dst, size_t n_rows, size_t row16) {
+    const u32x4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    const size_t chunk = static_cast<size_t>(CH) * 256;                       // 16-byte columns per task
+    const size_t chunks = (row16 + chunk - 1) / chunk, groups = (n_rows + R - 1) / R;
+    for (size_t t = blockIdx.x; t < groups * chunks; t += gridDim.x) {
+        const size_t g = t / chunks, c0 = (t % chunks) * chunk;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const size_t row = g * R + r;
+            if (row >= n_rows) break;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const size_t c = c0 + static_cast<size_t>(k) * 256 + threadIdx.x;
+                if (c < row16) dst[row * row16 + c] = v;
+            }
+        }
+    }
+}
+
 template <typename F>
 double time_ms(F launch, int reps = 7) {
     hipEvent_t a, b;
@@ -174,7 +197,16 @@ int main(int argc, char **argv) {
             report(nm, time_ms([&] { hipLaunchKernelGGL(fill_gridstride16<PLAIN16>, dim3(wgs), dim3(thr), 0, 0, d, count16); }));
         }
     report("hipMemsetAsync", time_ms([&] { hipMemsetAsync(buf, 0, bytes, 0); }));
-    for (int bands : {13, 25, 50}) {
+    for (int wgs : {256, 512}) {
+        char nm[128];
+#define TASKS(R, CH)                                                                                                    \
+    snprintf(nm, sizeof nm, "tasks in address order: %d rows x %d KiB, %d WG x 256", R, 4 * CH, wgs);                 \
+    report(nm, time_ms([&] { hipLaunchKernelGGL((fill_tasks16<R, CH>), dim3(wgs), dim3(256), 0, 0, d, n_rows, row16); }));
+        TASKS(1, 1) TASKS(1, 4) TASKS(2, 1) TASKS(2, 4) TASKS(4, 1) TASKS(4, 4) TASKS(8, 1) TASKS(8, 4) TASKS(16, 1) TASKS(16, 4)
+        TASKS(2, 8) TASKS(4, 8) TASKS(4, 16)
+#undef TASKS
+    }
+    for (int bands : {13}) {
         const int groups = 256 / bands;
         char nm[128];
         snprintf(nm, sizeof nm, "bands: %d x %d groups, 256 thr, 4 storing waves", bands, groups);
