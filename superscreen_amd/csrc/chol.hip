@@ -711,8 +711,10 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             T *C = J.A + c * J.lda + c;
             // every other panel of a large trailing matrix keeps its update pending: the next one then
             // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
-            // (the phase comes from the matrix' own size, not from its place in the batch: the result
-            // of a matrix does not depend on what else is factored with it)
+            // (the phase comes from the matrix' own size, not from its place in the batch: in float64, where the
+            // tiles accumulate onto C in k order, the factor of a matrix does not depend on what else is factored
+            // with it -- bit for bit; in float32, where a launch adds C once, it does to rounding: the switch to
+            // rounds comes with the LARGEST matrix of the batch)
             const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
                                ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done

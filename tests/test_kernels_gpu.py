@@ -410,6 +410,52 @@ def test_cholesky_batch_equals_single(K):
     assert res[0].info == 0 and res[1].info > 0
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-3)])
+def test_cholesky_schedule_parts_batch_equals_single(K, dtype, tol):
+    """The two parts of the schedule (panel chains beside the updates while a trailing matrix exceeds 10 240 columns,
+    single-stream rounds of batched launches after that) and the switch between them: matrices that start in the
+    stream part, one that runs out of panels there, one that joins for the rounds only -- factored together, alone
+    and in another order they give bit-identical factors in float64 (equal to rounding in float32), and the factors
+    solve S x = b."""
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(11)
+    sizes = [12100, 600, 11400, 5000]
+
+    def make(n):
+        U = torch.randn(n, 24, dtype=torch.float64, device="cuda", generator=g)
+        S = U @ U.T / 24
+        S.diagonal().add_(2.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
+        return S.to(tdt)
+
+    mats = [make(n) for n in sizes]
+
+    def buf(S):
+        n = S.shape[0]
+        npad = K.chol_padded_n(n)
+        t = torch.zeros((npad, K.padded_ld(npad, dtype)), dtype=tdt, device="cuda")
+        t[:n, :n] = torch.tril(S)
+        return t
+
+    alone = [K.chol_factor(buf(S), S.shape[0]) for S in mats]
+    together = K.chol_factor_batch([(buf(S), S.shape[0]) for S in mats])
+    swapped = K.chol_factor_batch([(buf(S), S.shape[0]) for S in mats[::-1]])[::-1]
+    for S, a, b, c in zip(mats, alone, together, swapped):
+        n = S.shape[0]
+        assert a.info == 0 and b.info == 0 and c.info == 0
+        if dtype == "float64":
+            assert torch.equal(a.L[:n, :n], b.L[:n, :n]) and torch.equal(a.L[:n, :n], c.L[:n, :n])
+        else:
+            # float32 tiles add C once per launch (csrc/gemm_ops.hip): a two-panel update and two one-panel updates
+            # round differently, and where a matrix switches to rounds depends on the largest matrix of the batch
+            scale = float(a.L[:n, :n].abs().max())
+            for other in (b, c):
+                assert float((a.L[:n, :n] - other.L[:n, :n]).abs().max()) < 1e-5 * scale
+        x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        rhs = (S.double() @ x).to(tdt)
+        got = K.chol_solve(b, rhs.clone()).double()
+        assert float((got - x).abs().max() / x.abs().max()) < tol
+
+
 def test_cholesky_full_size_residual(K):
     """BASELINE.json size (n_i = 20 419): S x = b to rounding, by a residual check that needs no
     O(n^3) host work (S = D + U U^T built on the GPU)."""
