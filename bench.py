@@ -199,6 +199,8 @@ def cpu_baseline(K: int, iterations: int, budget_s: float, gpu_solutions=None, g
         big = rng.random((n_size, n_size))
         big[np.diag_indices(n_size)] += n_size
         for t in sorted({threads, min(32, phys), min(64, phys)}):
+            if sweep_at_size and t > threads and sweep_at_size[max(sweep_at_size)] < 0.75 * max(sweep_at_size.values()):
+                break   # the rate is falling with the thread count: a larger count would only cost its 15-20 s
             with threadpool_limits(limits=t):
                 t0 = time.perf_counter()
                 la.lu_factor(big, check_finite=False)
