@@ -198,8 +198,9 @@ inline AuxLayout aux_layout(int64_t n) {
     a.tmp = 2 * a.nblk * SNB * SNB;
     a.scratch = a.tmp + a.nblk * (SNB * SNB / 4);
     // scratch of the diagonal-block kernel: one register image per lower 16 x 16 tile of the 256 x 256 block
-    // (chol_diag2.hpp: 34 816 elements)
-    a.total = a.scratch + cholk2::kScratchElems;
+    // (chol_diag2.hpp: 34 816 elements of the type the block is factored in -- float64 for both routes, so twice as
+    // many elements of a float32 matrix)
+    a.total = a.scratch + 2 * cholk2::kScratchElems;
     return a;
 }
 
@@ -353,10 +354,10 @@ int chol_panel_diag(const CholJob<T> &J, int64_t k0, hipStream_t s) {
     T *scratch = J.aux + aux_layout(n).scratch;
     if (lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside the block
     static DeviceFlags lds_flags2;   // the tile-layout form (chol_diag2.hpp), both precisions
-    if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel<T>),
-                                        sizeof(cholk2::Smem<T>)}}) != SSA_OK)
+    constexpr size_t smem = sizeof(cholk2::Smem<cholk2::factor_t<T>>);
+    if (raise_dynamic_lds(lds_flags2, {{reinterpret_cast<const void *>(&cholk2::chol_diag256_v2_kernel<T>), smem}}) != SSA_OK)
         return SSA_ERR_HIP;
-    hipLaunchKernelGGL((cholk2::chol_diag256_v2_kernel<T>), dim3(1), dim3(cholk2::kThreads), sizeof(cholk2::Smem<T>), s,
+    hipLaunchKernelGGL((cholk2::chol_diag256_v2_kernel<T>), dim3(1), dim3(cholk2::kThreads), smem, s,
                        J.A + k0 * (lda + 1), static_cast<int>(lda), chol_leaf(J, k0), static_cast<int>(SNB), scratch,
                        J.info, static_cast<int>(k0 + 1));
     SSA_RETURN_IF_LAUNCH_FAILED();

@@ -102,9 +102,9 @@ __device__ __forceinline__ Tile<T> image_load_transposed(const T *img, int lane)
     for (int r = 0; r < 4; ++r) t[r] = img[rp * 64 + col_of<T>(g, r) + 16 * gp];
     return t;
 }
-// tile (bi, bj) of a row-major matrix, S layout
-template <typename T>
-__device__ __forceinline__ Tile<T> global_load(const T *A, int ld, int bi, int bj, int lane) {
+// tile (bi, bj) of a row-major matrix, S layout.  IO: the type the matrix is stored in (the tile holds T)
+template <typename T, typename IO = T>
+__device__ __forceinline__ Tile<T> global_load(const IO *A, int ld, int bi, int bj, int lane) {
     const int i = lane & 15, g = lane >> 4;
     const int off = (16 * bi + i) * ld + 16 * bj;   // 32-bit element offset from the (uniform) base
     Tile<T> t;
@@ -113,8 +113,8 @@ __device__ __forceinline__ Tile<T> global_load(const T *A, int ld, int bi, int b
     return t;
 }
 // a diagonal tile, read from its lower triangle only (element [i][k] with k > i comes from [k][i])
-template <typename T>
-__device__ __forceinline__ Tile<T> global_load_sym(const T *A, int ld, int b, int lane) {
+template <typename T, typename IO = T>
+__device__ __forceinline__ Tile<T> global_load_sym(const IO *A, int ld, int b, int lane) {
     const int i = lane & 15, g = lane >> 4;
     const int base = (16 * b) * ld + 16 * b;
     Tile<T> t;
@@ -125,20 +125,20 @@ __device__ __forceinline__ Tile<T> global_load_sym(const T *A, int ld, int b, in
     }
     return t;
 }
-template <typename T>
-__device__ __forceinline__ void global_store(T *A, int ld, int bi, int bj, const Tile<T> &t, int lane) {
+template <typename T, typename IO = T>
+__device__ __forceinline__ void global_store(IO *A, int ld, int bi, int bj, const Tile<T> &t, int lane) {
     const int i = lane & 15, g = lane >> 4;
     const int off = (16 * bi + i) * ld + 16 * bj;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) A[off + col_of<T>(g, r)] = t[r];
+    for (int r = 0; r < 4; ++r) A[off + col_of<T>(g, r)] = static_cast<IO>(t[r]);
 }
 // the tile whose TRANSPOSE is held in S layout: element [col(g, r)][i] = t[r]
-template <typename T>
-__device__ __forceinline__ void global_store_transposed(T *A, int ld, int bi, int bj, const Tile<T> &t, int lane) {
+template <typename T, typename IO = T>
+__device__ __forceinline__ void global_store_transposed(IO *A, int ld, int bi, int bj, const Tile<T> &t, int lane) {
     const int i = lane & 15, g = lane >> 4;
     const int off = (16 * bi) * ld + 16 * bj + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) A[off + col_of<T>(g, r) * ld] = t[r];
+    for (int r = 0; r < 4; ++r) A[off + col_of<T>(g, r) * ld] = static_cast<IO>(t[r]);
 }
 
 __device__ __forceinline__ double bperm(double v, int byte_addr) {
@@ -300,8 +300,15 @@ __device__ __forceinline__ void chol16inv(Tile<T> &d, Tile<T> &w, bool &bad, int
 // The body is a device function: the stand-alone kernel below runs it as a launch of its own (panel chains of the
 // stream schedule), the tail rounds of the factorization run it as the first workgroups of a launch whose other
 // workgroups are trailing-update tiles (gemm_ops.hip, chol_tail_round_kernel).
-template <typename T>
-__device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ldw, T *scratch, int32_t *info, int col1,
+//
+// T is the type the block is FACTORED in, IO the type D and W are stored in.  The float32 route runs <double, float>:
+// the block's own factorization and inversion in float64 (the trailing updates that produced D, the panel product and
+// everything else stay float32).  Measured on the 20 419-unknown film of config H: backward error of the whole
+// factorization 8.0e-7 -> 4.7e-7 of max|S|, error of a float32 solve against float64 2.4 times smaller
+// (tools/r04/f32_panel_emulation.py: the panel through the explicit inverse is NOT what costs accuracy, the rounding
+// inside the diagonal blocks is); the kernel is latency-bound, so it costs little time.
+template <typename T, typename IO = T>
+__device__ __forceinline__ void chol_diag256_v2_body(IO *D, int lda, IO *W, int ldw, T *scratch, int32_t *info, int col1,
                                                      char *cholk2_smem_raw CHOLK2_TIMING_ARG) {
     Smem<T> &sm = *reinterpret_cast<Smem<T> *>(cholk2_smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -319,7 +326,7 @@ __device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ld
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int Kq = (K + q <= row) ? K + q : row;
-                t[q] = (Kq == row) ? global_load_sym<T>(D, lda, row, lane) : global_load<T>(D, lda, row, Kq, lane);
+                t[q] = (Kq == row) ? global_load_sym<T, IO>(D, lda, row, lane) : global_load<T, IO>(D, lda, row, Kq, lane);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -363,7 +370,7 @@ __device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ld
 #ifdef CHOLK2_TIMING
                 if (lane == 0) tstamp[16 + j] = __builtin_amdgcn_s_memtime() - tb0;
 #endif
-                global_store<T>(D, lda, j, j, dt, lane);
+                global_store<T, IO>(D, lda, j, j, dt, lane);
                 image_store<T>(sm.w, wt, lane);
                 image_store<T>(sm.wdiag[j], wt, lane);
             }
@@ -377,7 +384,7 @@ __device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ld
                         P[h][0] = mma_xyT<T>(zero_tile<T>(), P[h][0], wjj);
                         image_store<T>(sm.lp[row], P[h][0], lane);
                         image_store<T>(scratch + img_of(row, j), P[h][0], lane);
-                        global_store<T>(D, lda, row, j, P[h][0], lane);
+                        global_store<T, IO>(D, lda, row, j, P[h][0], lane);
                     }
                 }
             }
@@ -484,10 +491,10 @@ __device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ld
                 U[u] = mma_xyT<T>(zero_tile<T>(), nacc, wii);
             }
         }
-        global_store<T>(W, ldw, c, c, wcc, lane);                               // W_cc as it is
+        global_store<T, IO>(W, ldw, c, c, wcc, lane);                               // W_cc as it is
 #pragma unroll
         for (int u = 1; u < NT; ++u)
-            if (c + u < NT) global_store_transposed<T>(W, ldw, c + u, c, U[u], lane);
+            if (c + u < NT) global_store_transposed<T, IO>(W, ldw, c + u, c, U[u], lane);
         if (wave == 0) CHOLK2_STAMP(13 + (pass & 1));
     }
     __syncthreads();
@@ -499,11 +506,18 @@ __device__ __forceinline__ void chol_diag256_v2_body(T *D, int lda, T *W, int ld
 #else
 #define CHOLK2_TIMING_PASS
 #endif
-template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(T *D, int lda, T *W, int ldw, T *scratch,
+// type a block stored as IO is factored in
+template <typename IO>
+struct FactorIn { using type = double; };
+template <typename IO>
+using factor_t = typename FactorIn<IO>::type;
+
+template <typename IO>
+__global__ __launch_bounds__(kThreads, 2) void chol_diag256_v2_kernel(IO *D, int lda, IO *W, int ldw, IO *scratch,
                                                                      int32_t *info, int col1 CHOLK2_TIMING_ARG) {
     extern __shared__ __attribute__((aligned(16))) char cholk2_smem_raw[];
-    chol_diag256_v2_body<T>(D, lda, W, ldw, scratch, info, col1, cholk2_smem_raw CHOLK2_TIMING_PASS);
+    chol_diag256_v2_body<factor_t<IO>, IO>(D, lda, W, ldw, reinterpret_cast<factor_t<IO> *>(scratch), info, col1,
+                                           cholk2_smem_raw CHOLK2_TIMING_PASS);
 }
 
 }  // namespace cholk2

@@ -696,8 +696,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void chol_tail_round_kernel(TailRo
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (static_cast<int>(blockIdx.x) < a.ndiag) {
         const TailRoundJob &F = a.f[a.diag_film[blockIdx.x]];
-        cholk2::chol_diag256_v2_body<T>(static_cast<T *>(F.D), F.lda, static_cast<T *>(F.W), F.ldw,
-                                        static_cast<T *>(F.scratch), F.info, F.col1, smem_raw);
+        cholk2::chol_diag256_v2_body<cholk2::factor_t<T>, T>(static_cast<T *>(F.D), F.lda, static_cast<T *>(F.W), F.ldw,
+                                                             static_cast<cholk2::factor_t<T> *>(F.scratch), F.info, F.col1,
+                                                             smem_raw);
         return;
     }
     // (equal blockIdx.x % 8 = equal XCD holds for the shifted ids as well)
@@ -736,7 +737,8 @@ int chol_tail_round(int nfilms, const TailRoundJob *jobs, int exclusive, hipStre
     }
     a.tile_begin[nfilms] = tiles;
     if (a.ndiag + tiles == 0) return SSA_OK;
-    const size_t base = sizeof(OpSmemF64) > sizeof(cholk2::Smem<T>) ? sizeof(OpSmemF64) : sizeof(cholk2::Smem<T>);
+    constexpr size_t diag_lds = sizeof(cholk2::Smem<cholk2::factor_t<T>>);
+    const size_t base = sizeof(OpSmemF64) > diag_lds ? sizeof(OpSmemF64) : diag_lds;
     static DeviceFlags flags;
     if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&chol_tail_round_kernel<T>), kExclusiveLds}}) != SSA_OK)
         return SSA_ERR_HIP;

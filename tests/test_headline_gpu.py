@@ -341,11 +341,13 @@ def test_configH_full_size_vs_oracle(sc):
 def test_configH_float32_no_worse_than_the_reference_in_float32(sc):
     """The reference's DEFAULT precision (``solve_dtype="float32"``, device/device.py:57; Q, the Laplacian and the
     weights cast to float32, ``lu_factor`` = sgetrf, solver/utils.py:290-292) on the headline device: the float32
-    answer of this build stays within a small factor of the reference algorithm's own float32 error --
-    ``err(gpu32 vs ref64) <= 3 err(ref32 vs ref64)`` for the stream function of every film and iterate.  (Measured,
-    round 4: 1.0e-4 against 4.6e-5 in the worst film and iterate, a factor of 2.3 -- the panels go through explicit
-    inverses of the 256-blocks where LAPACK substitutes; until the float32 MFMA tiles stopped accumulating onto C
-    the factor was 25-50.)"""
+    answer of this build stays within a small factor of the reference algorithm's own float32 error:
+    ``err(gpu32 vs ref64) <= 2 err(ref32 vs ref64)`` for the worst film and iterate, 3 for every single one (the
+    reference's own float32 error moves by a factor of 3 with the host's LAPACK blocking: 4.6e-5 .. 1.5e-4 measured on
+    two boxes).  Measured, round 4: 1.8e-4 against 1.5e-4.  History: 25-50 times the reference's error until the
+    float32 MFMA tiles stopped accumulating onto C, 2.3 times until the 256 x 256 diagonal blocks were factored and
+    inverted in float64 (chol_diag2.hpp; the backward error of the float32 factorization is now LAPACK spotrf's,
+    tools/r04/f32_attrib.py)."""
     from threadpoolctl import threadpool_limits
 
     from superscreen_amd import synthetic
@@ -370,6 +372,7 @@ def test_configH_float32_no_worse_than_the_reference_in_float32(sc):
             e_ref = relerr(r32[nm].stream, r64[nm])
             worst_gpu, worst_ref = max(worst_gpu, e_gpu), max(worst_ref, e_ref)
             assert e_gpu <= 3 * e_ref + 1e-7, (it, nm, e_gpu, e_ref)
+    assert worst_gpu <= 2 * worst_ref, (worst_gpu, worst_ref)
     assert worst_gpu < 5e-4
     print(f"config H float32: stream max-rel-error vs the float64 reference {worst_gpu:.2e} (this build), "
           f"{worst_ref:.2e} (reference algorithm in float32)")
