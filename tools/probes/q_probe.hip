@@ -116,6 +116,94 @@ __global__ __launch_bounds__(256) void q_kernel(const double *__restrict__ xy, c
     if (tid < h) rowsum[i0 + tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
 }
 
+static std::vector<double> ring_points(int K);
+template <typename F>
+static double time_ms(F f, int reps = 7);
+
+// FLAT order: the whole device writes ONE contiguous window per iteration (gridDim.x x 4 KiB), workgroup b the b-th
+// 4 KiB of it -- the shape of a grid-stride fill, the only store shape that reaches the memset rate
+// (store_probe.hip).  A lane owns two adjacent elements per iteration; row and column follow the flat index
+// incrementally; ld % 128 == 0, so that a wave's 128 elements lie in one row (row data by scalar loads, row-sum
+// partial one value per wave and iteration, partial[row][column / 128]).
+// ROWSUM: 0 none, 1 butterfly (ds_bpermute), 2 on the matrix pipe (ones-matrix products)
+template <int MODE, int ROWSUM, int PREFETCH>
+__global__ __launch_bounds__(256) void q_flat_kernel(const double *__restrict__ xy, const double *__restrict__ w, int64_t n,
+                                                     double *__restrict__ Q, int64_t ld, double *__restrict__ partial) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t total = n * ld, step = static_cast<int64_t>(gridDim.x) * 512;
+    int64_t e = static_cast<int64_t>(blockIdx.x) * 512 + 2 * tid;
+    int i = static_cast<int>(e / ld), j = static_cast<int>(e - static_cast<int64_t>(i) * ld);
+    const int qs = static_cast<int>(step / ld), rs = static_cast<int>(step - static_cast<int64_t>(qs) * ld);
+    const int nn = static_cast<int>(n), cpr = static_cast<int>(ld >> 7);
+    auto fetch = [&](int jj, double2 &p0, double2 &p1, double2 &ww) {
+        const int jc = jj + 1 < nn ? jj : (nn - 2);   // pad columns read a valid pair (values unused)
+        p0 = *reinterpret_cast<const double2 *>(xy + 2 * static_cast<int64_t>(jc));
+        p1 = *reinterpret_cast<const double2 *>(xy + 2 * static_cast<int64_t>(jc) + 2);
+        ww = *reinterpret_cast<const double2 *>(w + jc);
+    };
+    double2 p0, p1, ww;
+    if (e < total) fetch(j, p0, p1, ww);
+    while (e < total) {
+        int i2 = i + qs, j2 = j + rs;
+        if (j2 >= static_cast<int>(ld)) {
+            j2 -= static_cast<int>(ld);
+            ++i2;
+        }
+        double2 n0 = p0, n1 = p1, nw = ww;
+        if (PREFETCH && e + step < total) fetch(j2, n0, n1, nw);
+        const int iu = __builtin_amdgcn_readfirstlane(i);
+        const double2 pi = *reinterpret_cast<const double2 *>(xy + 2 * static_cast<int64_t>(iu));
+        double q[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double2 pj = c ? p1 : p0;
+            if (MODE == STORE_ONLY) {
+                q[c] = pj.x;
+            } else {
+                const double dx = pi.x - pj.x, dy = pi.y - pj.y;
+                const double r2 = __builtin_fma(dx, dx, dy * dy);
+                q[c] = inv_r3_over_4pi(r2);
+                q[c] = (j + c == iu || j + c >= nn) ? 0.0 : q[c];
+            }
+        }
+        double2 v;
+        v.x = -q[0];
+        v.y = -q[1];
+        *reinterpret_cast<double2 *>(Q + e) = v;
+        if (ROWSUM == 1) {
+            const double s = wave_sum(__builtin_fma(q[0], ww.x, q[1] * ww.y));
+            if (lane == 0) partial[static_cast<int64_t>(iu) * cpr + (j >> 7)] = s;
+        } else if (ROWSUM == 2) {
+            // total over the wave on the (idle) matrix pipe: D1[a][b] = sum_k A[a][k], A[a][k] = lane (a + 16 k);
+            // then D2 += ones x B_r with B_r[k][b] = register r of lane (b + 16 k) of D1: every lane holds the total
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            const double sl = __builtin_fma(q[0], ww.x, q[1] * ww.y);
+            d4 z = {0.0, 0.0, 0.0, 0.0};
+            const d4 d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sl, 1.0, z, 0, 0, 0);
+            d4 d2 = z;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, d1[r], d2, 0, 0, 0);
+            if (lane == 0) partial[static_cast<int64_t>(iu) * cpr + (j >> 7)] = d2[0];
+        }
+        if (!PREFETCH && e + step < total) fetch(j2, n0, n1, nw);
+        p0 = n0;
+        p1 = n1;
+        ww = nw;
+        e += step;
+        i = i2;
+        j = j2;
+    }
+}
+
+template <int MODE, int ROWSUM, int PREFETCH>
+static void run_flat(const char *name, const double *xy, const double *w, int64_t n, double *Q, int64_t ld, double *partial,
+                     int wgs) {
+    const double ms = time_ms([&] { hipLaunchKernelGGL((q_flat_kernel<MODE, ROWSUM, PREFETCH>), dim3(wgs), dim3(256), 0, 0, xy, w, n, Q, ld, partial); });
+    const double gb = static_cast<double>(n) * n * 8 / 1e9;
+    printf("flat %-12s rowsum=%d prefetch=%d wgs=%4d ld=%lld: %7.3f ms  %6.0f GB/s (n^2 x 8 bytes)\n", name, ROWSUM, PREFETCH, wgs,
+           static_cast<long long>(ld), ms, gb / ms * 1e3);
+}
+
 static std::vector<double> ring_points(int K) {
     std::vector<double> p;
     p.push_back(0.0);
@@ -130,7 +218,7 @@ static std::vector<double> ring_points(int K) {
 }
 
 template <typename F>
-static double time_ms(F f, int reps = 7) {
+static double time_ms(F f, int reps) {
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
@@ -167,20 +255,30 @@ static void run(const char *name, const double *xy, const double *w, int64_t n, 
 int main(int argc, char **argv) {
     const int K = argc > 1 ? atoi(argv[1]) : 91;
     std::vector<double> p = ring_points(K);
-    const int64_t n = static_cast<int64_t>(p.size() / 2), ld = (n + 15) / 16 * 16;
+    const int64_t n = static_cast<int64_t>(p.size() / 2), ld = (n + 15) / 16 * 16, ldf = (n + 127) / 128 * 128;
     std::vector<double> wh(n, 1e-3);
     double *xy, *w, *Q, *rs;
     hipMalloc(&xy, p.size() * 8);
     hipMalloc(&w, n * 8);
     hipMalloc(&rs, n * 8);
-    hipMalloc(&Q, static_cast<size_t>(n) * ld * 8);
+    hipMalloc(&Q, static_cast<size_t>(n) * ldf * 8);
+    double *partial;
+    hipMalloc(&partial, static_cast<size_t>(n) * (ldf / 128) * 8);
     hipMemcpy(xy, p.data(), p.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(w, wh.data(), n * 8, hipMemcpyHostToDevice);
     printf("n = %lld (K = %d), %.2f GB\n", static_cast<long long>(n), K, static_cast<double>(n) * n * 8 / 1e9);
     const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
     printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
     for (int rep = 0; rep < 3; ++rep) {
-        run<FULL, 16, 2>("production", xy, w, n, Q, ld, rs, 7, 0);
+        for (int wgs : {128, 256, 512}) {
+            run_flat<STORE_ONLY, 0, 1>("store only", xy, w, n, Q, ldf, partial, wgs);
+            run_flat<FULL, 0, 1>("full", xy, w, n, Q, ldf, partial, wgs);
+            run_flat<FULL, 0, 0>("full", xy, w, n, Q, ldf, partial, wgs);
+            run_flat<FULL, 1, 1>("full", xy, w, n, Q, ldf, partial, wgs);
+            run_flat<FULL, 2, 1>("full", xy, w, n, Q, ldf, partial, wgs);
+        }
+        run<FULL, 24, 2, true, 1>("production", xy, w, n, Q, ld, rs, 5, 0);
+        run<FULL, 16, 2>("round 3", xy, w, n, Q, ld, rs, 7, 0);
         run<STORE_ONLY, 16, 2>("store only", xy, w, n, Q, ld, rs, 7, 0);
         run<STORE_ONLY, 16, 2, false, 1>("store only", xy, w, n, Q, ld, rs, 7, 0);
         run<STORE_ONLY, 16, 2, false, 3>("store only", xy, w, n, Q, ld, rs, 7, 0);
