@@ -204,6 +204,90 @@ static void run_flat(const char *name, const double *xy, const double *w, int64_
            static_cast<long long>(ld), ms, gb / ms * 1e3);
 }
 
+// FLAT order, second form: a ring of D prefetched column sets per lane, so that D - 1 stores of a wave stay in
+// flight while it waits for a load (loads and stores retire through ONE in-order counter: with the next iteration's
+// loads issued right before they are used, every iteration waits for its own previous store to reach the L2).
+// Row sums: the wave's 64 per-lane partials are summed on the matrix pipe, two ones-matrix products
+// (16x16x4: D[a][b] = sum_k A[a][k]; then the four registers of a lane added, and the same product again).
+template <int MODE, int ROWSUM, int D>
+__global__ __launch_bounds__(256) void q_flat2_kernel(const double *__restrict__ xy, const double *__restrict__ w, int64_t n,
+                                                      double *__restrict__ Q, int64_t ld, double *__restrict__ partial) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t total = n * ld, step = static_cast<int64_t>(gridDim.x) * 512;
+    int64_t e = static_cast<int64_t>(blockIdx.x) * 512 + 2 * tid;
+    const int ldi = static_cast<int>(ld), nn = static_cast<int>(n), cpr = static_cast<int>(ld >> 7);
+    int i = static_cast<int>(e / ld), j = static_cast<int>(e - static_cast<int64_t>(i) * ld);
+    const int qs = static_cast<int>(step / ld), rs = static_cast<int>(step - static_cast<int64_t>(qs) * ld);
+    // head of the ring: iteration `ahead` of this lane
+    int64_t eh = e;
+    int jh = j;
+    double2 P0[D], P1[D], WW[D];
+    auto fetch = [&](int d) {
+        if (eh < total) {
+            const int jc = jh + 1 < nn ? jh : (nn - 2);
+            P0[d] = *reinterpret_cast<const double2 *>(xy + 2 * static_cast<int64_t>(jc));
+            P1[d] = *reinterpret_cast<const double2 *>(xy + 2 * static_cast<int64_t>(jc) + 2);
+            WW[d] = *reinterpret_cast<const double2 *>(w + jc);
+        }
+        eh += step;
+        jh += rs;
+        if (jh >= ldi) jh -= ldi;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d);
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    while (true) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (e >= total) return;
+            const int iu = __builtin_amdgcn_readfirstlane(i);
+            const double2 pi = *reinterpret_cast<const double2 *>(xy + 2 * static_cast<int64_t>(iu));
+            double q[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double2 pj = c ? P1[d] : P0[d];
+                if (MODE == STORE_ONLY) {
+                    q[c] = pj.x;
+                } else {
+                    const double dx = pi.x - pj.x, dy = pi.y - pj.y;
+                    const double r2 = __builtin_fma(dx, dx, dy * dy);
+                    q[c] = inv_r3_over_4pi(r2);
+                    q[c] = (j + c == iu || j + c >= nn) ? 0.0 : q[c];
+                }
+            }
+            double2 v;
+            v.x = -q[0];
+            v.y = -q[1];
+            *reinterpret_cast<double2 *>(Q + e) = v;
+            if (ROWSUM) {
+                const double sl = __builtin_fma(q[0], WW[d].x, q[1] * WW[d].y);
+                const d4 z = {0.0, 0.0, 0.0, 0.0};
+                const d4 d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sl, 1.0, z, 0, 0, 0);
+                const double t = (d1[0] + d1[1]) + (d1[2] + d1[3]);
+                const d4 d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
+                if (lane == 0) partial[static_cast<int64_t>(iu) * cpr + (j >> 7)] = d2[0];
+            }
+            fetch(d);
+            e += step;
+            i += qs;
+            j += rs;
+            if (j >= ldi) {
+                j -= ldi;
+                ++i;
+            }
+        }
+    }
+}
+
+template <int MODE, int ROWSUM, int D>
+static void run_flat2(const char *name, const double *xy, const double *w, int64_t n, double *Q, int64_t ld, double *partial,
+                      int wgs) {
+    const double ms = time_ms([&] { hipLaunchKernelGGL((q_flat2_kernel<MODE, ROWSUM, D>), dim3(wgs), dim3(256), 0, 0, xy, w, n, Q, ld, partial); });
+    const double gb = static_cast<double>(n) * n * 8 / 1e9;
+    printf("flat2 %-11s rowsum=%d ring=%2d wgs=%4d ld=%lld: %7.3f ms  %6.0f GB/s (n^2 x 8 bytes)\n", name, ROWSUM, D, wgs,
+           static_cast<long long>(ld), ms, gb / ms * 1e3);
+}
+
 static std::vector<double> ring_points(int K) {
     std::vector<double> p;
     p.push_back(0.0);
@@ -270,7 +354,16 @@ int main(int argc, char **argv) {
     const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
     printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
     for (int rep = 0; rep < 3; ++rep) {
-        for (int wgs : {128, 256, 512}) {
+        for (int wgs : {256, 512}) {
+            run_flat2<STORE_ONLY, 0, 4>("store only", xy, w, n, Q, ldf, partial, wgs);
+            run_flat2<STORE_ONLY, 0, 8>("store only", xy, w, n, Q, ldf, partial, wgs);
+            run_flat2<STORE_ONLY, 0, 12>("store only", xy, w, n, Q, ldf, partial, wgs);
+            run_flat2<FULL, 0, 8>("full", xy, w, n, Q, ldf, partial, wgs);
+            run_flat2<FULL, 0, 12>("full", xy, w, n, Q, ldf, partial, wgs);
+            run_flat2<FULL, 1, 8>("full", xy, w, n, Q, ldf, partial, wgs);
+            run_flat2<FULL, 1, 12>("full", xy, w, n, Q, ldf, partial, wgs);
+        }
+        for (int wgs : {256}) {
             run_flat<STORE_ONLY, 0, 1>("store only", xy, w, n, Q, ldf, partial, wgs);
             run_flat<FULL, 0, 1>("full", xy, w, n, Q, ldf, partial, wgs);
             run_flat<FULL, 0, 0>("full", xy, w, n, Q, ldf, partial, wgs);
