@@ -924,7 +924,7 @@ inline size_t np_workspace_bytes(int64_t np, size_t es) {
     const size_t nsub = static_cast<size_t>(np / PW);
     return PanelScratchBytes::cnt + PanelScratchBytes::hdr + 2 * static_cast<size_t>(kMaxPanelGroups) * PW * es +
            2 * nsub * sizeof(int) + static_cast<size_t>(NB) * PW * es + (NB / PW + 1) * 64 * 64 * es +
-           2 * static_cast<size_t>(NB) * NB * es + 6 * 64 * 64 * es + 16 * 256;
+           2 * static_cast<size_t>(NB) * NB * es + 2 * (3 * 256 * 256 + 6 * 64 * 64) * sizeof(float) + 16 * 256;
 }
 template <typename T>
 NpScratch<T> np_carve(void *workspace, int64_t np) {
@@ -941,7 +941,7 @@ NpScratch<T> np_carve(void *workspace, int64_t np) {
     s.top = cv.take<T>(64 * 64);
     s.WL = cv.take<T>(static_cast<size_t>(NB) * NB);
     s.WU = cv.take<T>(static_cast<size_t>(NB) * NB);
-    s.dscratch = cv.take<T>(6 * 64 * 64);
+    s.dscratch = cv.take<T>(luk::lu_diag_scratch_elems<T>());
     return s;
 }
 
@@ -1002,7 +1002,7 @@ NpLeaves<T> np_leaves(const NpJob<T> &J, int64_t k0) {
 template <typename T>
 int np_diag(const NpJob<T> &J, const NpScratch<T> &S, int64_t k0, hipStream_t s) {
     const NpLeaves<T> w = np_leaves(J, k0);
-    hipLaunchKernelGGL((luk::lu_diag256_kernel<T>), dim3(1), dim3(256), sizeof(luk::LuSmem<T>), s,
+    hipLaunchKernelGGL((luk::lu_diag256_kernel<T>), dim3(1), dim3(256), sizeof(luk::LuSmem<double>), s,
                        J.A + k0 * (J.lda + 1), static_cast<int>(J.lda), w.WL, w.WU, static_cast<int>(LSB), S.dscratch,
                        J.info);
     SSA_RETURN_IF_LAUNCH_FAILED();
@@ -1049,7 +1049,7 @@ int getrf_np_batch(const NpJob<T> *jobs, int count, hipStream_t st) {
     if (count <= 0 || count > kMaxLuLanes) return SSA_ERR_INVALID_ARGUMENT;
     static DeviceFlags lds_flags;
     if (raise_dynamic_lds(lds_flags, {{reinterpret_cast<const void *>(&luk::lu_diag256_kernel<T>),
-                                       sizeof(luk::LuSmem<T>)}}) != SSA_OK)
+                                       sizeof(luk::LuSmem<double>)}}) != SSA_OK)
         return SSA_ERR_HIP;
     LuLaneSet *lane_set = nullptr;
     int rc = get_lu_lanes(count, &lane_set);

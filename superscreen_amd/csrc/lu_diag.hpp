@@ -193,13 +193,12 @@ __device__ __forceinline__ void ge64_lu(T *D, int ld, T *WLout, T *WUout, int ld
 #define LUK_STAMP(i) do { } while (0)
 #endif
 template <typename T>
-__global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL, T *WU, int ldw, T *scratch,
-                                                            int32_t *info
+__device__ __forceinline__ void lu_diag256_body(T *D, int lda, T *WL, T *WU, int ldw, T *scratch, int32_t *info,
+                                                char *luk_smem_raw
 #ifdef LUK_TIMING
-                                                            , long long *tstamp
+                                                , long long *tstamp
 #endif
 ) {
-    extern __shared__ __attribute__((aligned(16))) char luk_smem_raw[];
     LuSmem<T> &sm = *reinterpret_cast<LuSmem<T> *>(luk_smem_raw);
     const int wave = threadIdx.x >> 6;
     using acc_t = typename Mfma<T>::acc_t;
@@ -300,6 +299,60 @@ __global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL
         }
         __syncthreads();
         LUK_STAMP(12 + 2 * d);
+    }
+}
+
+// Elements of `scratch` (of the matrix type) the kernel needs.  float64: the six 64 x 64 blocks of the inversion.
+// float32: the block is FACTORED AND INVERTED IN FLOAT64 (as the Cholesky route's diagonal blocks, chol_diag2.hpp):
+// a float64 copy of D, float64 WL and WU and the six blocks, 1.77 MB.
+template <typename T>
+constexpr int64_t lu_diag_scratch_elems() {
+    return sizeof(T) == 8 ? 6 * 64 * 64 : 2 * (3 * 256 * 256 + 6 * 64 * 64);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void lu_diag256_kernel(T *D, int lda, T *WL, T *WU, int ldw, T *scratch,
+                                                            int32_t *info
+#ifdef LUK_TIMING
+                                                            , long long *tstamp
+#endif
+) {
+    extern __shared__ __attribute__((aligned(16))) char luk_smem_raw[];   // LuSmem<double> for both precisions
+    if constexpr (sizeof(T) == 8) {
+        lu_diag256_body<T>(D, lda, WL, WU, ldw, scratch, info, luk_smem_raw
+#ifdef LUK_TIMING
+                           , tstamp
+#endif
+        );
+    } else {
+        double *Dd = reinterpret_cast<double *>(scratch), *WLd = Dd + 256 * 256, *WUd = WLd + 256 * 256;
+        double *scr = WUd + 256 * 256;
+        const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+        // rows of 256 floats as four 256-byte pieces per wave-instruction
+#pragma unroll 4
+        for (int r = wave; r < 256; r += 4)
+#pragma unroll
+            for (int c = lane; c < 256; c += 64) Dd[r * 256 + c] = static_cast<double>(D[r * lda + c]);
+        __syncthreads();
+        lu_diag256_body<double>(Dd, 256, WLd, WUd, 256, scr, info, luk_smem_raw
+#ifdef LUK_TIMING
+                                , tstamp
+#endif
+        );
+        __syncthreads();
+        // back to float32: L \ U whole, WL on and below, WU on and above the diagonal 64-blocks (the others are the
+        // caller's zeros)
+#pragma unroll 4
+        for (int r = wave; r < 256; r += 4) {
+            const int bi = r >> 6;
+#pragma unroll
+            for (int c = lane; c < 256; c += 64) {
+                const int bj = c >> 6;
+                D[r * lda + c] = static_cast<T>(Dd[r * 256 + c]);
+                if (bj <= bi) WL[r * ldw + c] = static_cast<T>(WLd[r * 256 + c]);
+                if (bj >= bi) WU[r * ldw + c] = static_cast<T>(WUd[r * 256 + c]);
+            }
+        }
     }
 }
 

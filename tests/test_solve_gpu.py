@@ -141,7 +141,7 @@ def _oracle_stack(K, kinds, z_spacing, Lambda, dtype):
     return films
 
 
-@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 5e-3)])
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 5e-4)])
 def test_two_film_vs_oracle_medium(sc, dtype, tol):
     """n = 1951 per film (K = 25): a size the reference-under-stubs cannot reach quickly."""
     from superscreen_amd import synthetic
