@@ -55,7 +55,7 @@ __host__ __device__ inline void strip_rows(int64_t n, int64_t groups, int64_t b,
     *h = static_cast<int>(base + (b < extra ? 1 : 0));
 }
 
-template <typename OutT, int TR>
+template <typename OutT, int TR, bool WANT_Q>
 __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
     const double *__restrict__ xy, const double *__restrict__ w, const double *__restrict__ C,
     int64_t n, OutT *__restrict__ Q, int64_t ldq, double *__restrict__ qdiag) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         const double yj1 = has1 ? xy[2 * j + 3] : 0.0;
         const double w0 = w[j];
         const double w1 = has1 ? w[j + 1] : 0.0;
-        OutT *qp = (Q != nullptr) ? Q + i0 * ldq + j : nullptr;
+        OutT *qp = WANT_Q ? Q + i0 * ldq + j : nullptr;
         const int dj = static_cast<int>(j - i0);   // row r is on the diagonal of column j when dj == r
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
                 q1 = (dj + 1 == r || !has1) ? 0.0 : q1;
                 acc[r] = __builtin_fma(q0, w0, acc[r]);
                 acc[r] = __builtin_fma(q1, w1, acc[r]);
-                if (Q != nullptr) {
+                if (WANT_Q) {
                     store_pair<OutT>(qp, static_cast<OutT>(-q0), static_cast<OutT>(-q1));
                     qp += ldq;
                 }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         for (int v = 0; v < kAsmThreads / kWave; ++v) s += s_part[v][tid];
         const double d = (C[i] + s) / w[i];  // device/mesh.py:455-457
         if (qdiag != nullptr) qdiag[i] = d;
-        if (Q != nullptr) Q[i * ldq + i] = static_cast<OutT>(d);
+        if (WANT_Q) Q[i * ldq + i] = static_cast<OutT>(d);
     }
 }
 
@@ -173,11 +173,13 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
     int64_t ldo, const int64_t *__restrict__ lap_indptr, const int64_t *__restrict__ lap_indices,
     const double *__restrict__ lap_data, const int32_t *__restrict__ col_pos,
     const double *__restrict__ row_rs, int lower_only) {
-    __shared__ double s_x[TR];
-    __shared__ double s_y[TR];
+    // per row of the strip: site, diagonal entry Q_ii, sign * row scale (already in the output type), vertex id and the
+    // COLUMN POSITION of that vertex (-1: not a column) -- the sweep finds the diagonal by comparing positions
+    __shared__ double2 s_xy[TR];
     __shared__ double s_rs[TR];
     __shared__ double s_qd[TR];
     __shared__ int64_t s_id[TR];
+    __shared__ int s_dpos[TR];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -187,17 +189,21 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
     const int64_t strip = lower_only ? static_cast<int64_t>(gridDim.x) - 1 - blockIdx.x : blockIdx.x;
     int64_t r0 = strip * TR, nr_end = nr;
     if (!lower_only) {
-        int h;
-        strip_rows(nr, gridDim.x, blockIdx.x, &r0, &h);
-        nr_end = r0 + h;
+        int hh;
+        strip_rows(nr, gridDim.x, blockIdx.x, &r0, &hh);
+        nr_end = r0 + hh;
+    } else if (nr_end > r0 + TR) {
+        nr_end = r0 + TR;
     }
+    const int h = static_cast<int>(nr_end - r0);   // rows of this workgroup, 1 .. TR (workgroup-uniform)
     if (tid < TR) {
         const int64_t r = (r0 + tid < nr) ? r0 + tid : nr - 1;
-        s_x[tid] = row_x[r];
-        s_y[tid] = row_y[r];
+        s_xy[tid] = double2{row_x[r], row_y[r]};
         s_qd[tid] = row_qd[r];
-        s_id[tid] = row_id[r];
-        s_rs[tid] = row_rs ? row_rs[r] : 1.0;
+        const int64_t id = row_id[r];
+        s_id[tid] = id;
+        s_dpos[tid] = col_pos[id];
+        s_rs[tid] = static_cast<double>(sign * static_cast<OutT>(row_rs ? row_rs[r] : 1.0));
     }
     __syncthreads();
 
@@ -216,29 +222,36 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
         const double yj1 = has1 ? col_y[c + 1] : 0.0;
         const OutT w0 = static_cast<OutT>(col_w[c]);
         const OutT w1 = has1 ? static_cast<OutT>(col_w[c + 1]) : OutT(0);
-        const int64_t id0 = col_id[c];
-        const int64_t id1 = has1 ? col_id[c + 1] : -1;
-#pragma unroll 8
+        const int ci = static_cast<int>(c);
+        const bool pair = has1 || c + 1 < ldo;
+        // (row-invariant quantities stay out of scalar registers, as in q_assemble_kernel: the store address advances
+        // by one row per step)
+        OutT *dst = out + r0 * ldo + c;
+#pragma unroll
         for (int r = 0; r < TR; ++r) {
-            if (r0 + r >= nr_end) break;
-            const int64_t i = s_id[r];
-            const double xi = s_x[r], yi = s_y[r];
-            const double dx0 = xi - xj0, dy0 = yi - yj0;
-            const double dx1 = xi - xj1, dy1 = yi - yj1;
-            double q0 = -inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
-            double q1 = -inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
-            q0 = (i == id0) ? s_qd[r] : q0;  // Q_ii
-            q1 = (i == id1) ? s_qd[r] : q1;
-            // Q is cast to the solve dtype before the product (solver/utils.py:291,
-            // solve_film.py:305): out = Q[ix,ix] * w[ix]  (column scaling).
-            const OutT rs = sign * static_cast<OutT>(s_rs[r]);  // optional row scaling (w_i: S = W A)
-            const OutT v0 = rs * (static_cast<OutT>(q0) * w0);
-            const OutT v1 = has1 ? rs * (static_cast<OutT>(q1) * w1) : OutT(0);
-            OutT *dst = out + (r0 + r) * ldo + c;
-            if (has1 || c + 1 < ldo) {
-                store_pair<OutT>(dst, v0, v1);
-            } else {
-                *dst = v0;
+            if (r < h) {   // uniform branch
+                int off = r * 16;   // one LDS read per use, hidden from loop-invariant code motion
+                asm volatile("" : "+v"(off));
+                const double2 pr = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_xy) + off);
+                const double dx0 = pr.x - xj0, dy0 = pr.y - yj0;
+                const double dx1 = pr.x - xj1, dy1 = pr.y - yj1;
+                double q0 = -inv_r3_over_4pi(__builtin_fma(dx0, dx0, dy0 * dy0));
+                double q1 = -inv_r3_over_4pi(__builtin_fma(dx1, dx1, dy1 * dy1));
+                const int dp = s_dpos[r];
+                const double qd = s_qd[r];
+                q0 = (ci == dp) ? qd : q0;  // Q_ii
+                q1 = (ci + 1 == dp) ? qd : q1;
+                // Q is cast to the solve dtype before the product (solver/utils.py:291,
+                // solve_film.py:305): out = Q[ix,ix] * w[ix]  (column scaling).
+                const OutT rs = static_cast<OutT>(s_rs[r]);  // sign * optional row scaling (w_i: S = W A)
+                const OutT v0 = rs * (static_cast<OutT>(q0) * w0);
+                const OutT v1 = has1 ? rs * (static_cast<OutT>(q1) * w1) : OutT(0);
+                if (pair) {
+                    store_pair<OutT>(dst, v0, v1);
+                } else {
+                    *dst = v0;
+                }
+                dst += ldo;
             }
         }
     }
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
             if (c >= 0) {
                 OutT *dst = out + (r0 + r) * ldo + c;
                 const OutT t = static_cast<OutT>(col_lam[c]) * static_cast<OutT>(lap_data[p]);
-                if (!lower_only || c <= r0 + r) *dst = *dst - sign * static_cast<OutT>(s_rs[r]) * t;
+                if (!lower_only || c <= r0 + r) *dst = *dst - static_cast<OutT>(s_rs[r]) * t;   // s_rs: sign * row scale
             }
         }
     }
@@ -269,14 +282,24 @@ extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C
     if (n <= 0 || !xy || !w || !C) return SSA_ERR_INVALID_ARGUMENT;
     if (Q && (ldq < n || (ldq & 1))) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(balanced_groups(n, kQStripRows)));
+    hipStream_t st = as_stream(stream);
+    // (the row-sum-only form -- Q == nullptr: the factorizations need only the diagonal -- is its own instantiation:
+    // no store code in the sweep)
     if (dtype == SSA_F64) {
-        const dim3 grid(static_cast<unsigned>(balanced_groups(n, kQStripRows)));
-        hipLaunchKernelGGL((q_assemble_kernel<double, kQStripRows>), grid, dim3(kAsmThreads), 0,
-                           as_stream(stream), xy, w, C, n, static_cast<double *>(Q), ldq, qdiag);
+        if (Q)
+            hipLaunchKernelGGL((q_assemble_kernel<double, kQStripRows, true>), grid, dim3(kAsmThreads), 0, st, xy, w, C, n,
+                               static_cast<double *>(Q), ldq, qdiag);
+        else
+            hipLaunchKernelGGL((q_assemble_kernel<double, kQStripRows, false>), grid, dim3(kAsmThreads), 0, st, xy, w, C, n,
+                               static_cast<double *>(nullptr), ldq, qdiag);
     } else {
-        const dim3 grid(static_cast<unsigned>(balanced_groups(n, kQStripRows)));
-        hipLaunchKernelGGL((q_assemble_kernel<float, kQStripRows>), grid, dim3(kAsmThreads), 0,
-                           as_stream(stream), xy, w, C, n, static_cast<float *>(Q), ldq, qdiag);
+        if (Q)
+            hipLaunchKernelGGL((q_assemble_kernel<float, kQStripRows, true>), grid, dim3(kAsmThreads), 0, st, xy, w, C, n,
+                               static_cast<float *>(Q), ldq, qdiag);
+        else
+            hipLaunchKernelGGL((q_assemble_kernel<float, kQStripRows, false>), grid, dim3(kAsmThreads), 0, st, xy, w, C, n,
+                               static_cast<float *>(nullptr), ldq, qdiag);
     }
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;

@@ -3,6 +3,7 @@
 // only), with other strip heights / columns per lane, and with the number of resident workgroups capped.
 //   hipcc -O3 --offload-arch=gfx950 tools/probes/q_probe.hip -o tools/probes/q_probe && tools/probes/q_probe [K]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -353,7 +354,21 @@ int main(int argc, char **argv) {
     printf("n = %lld (K = %d), %.2f GB\n", static_cast<long long>(n), K, static_cast<double>(n) * n * 8 / 1e9);
     const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
     printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
-    for (int rep = 0; rep < 3; ++rep) {
+    // the library's own kernel through the C ABI, on the same buffers
+    typedef int (*q_fn)(const double *, const double *, const double *, int64_t, void *, int64_t, int, double *, void *);
+    void *lib = dlopen("superscreen_amd/lib/libsuperscreen_hip.so", RTLD_NOW);
+    q_fn q_assemble = lib ? reinterpret_cast<q_fn>(dlsym(lib, "ssa_q_assemble")) : nullptr;
+    if (q_assemble) {
+        for (int rep = 0; rep < 3; ++rep) {
+            const double ms = time_ms([&] { q_assemble(xy, w, w, n, Q, ld, 1, rs, nullptr); });
+            printf("library ssa_q_assemble (float64, ld=%lld): %7.3f ms  %6.0f GB/s\n", static_cast<long long>(ld), ms,
+                   static_cast<double>(n) * n * 8 / 1e9 / ms * 1e3);
+            run<FULL, 24, 2, true, 1>("probe copy of it", xy, w, n, Q, ld, rs, 5, 0);
+        }
+    } else {
+        printf("library not loaded: %s\n", dlerror());
+    }
+    for (int rep = 0; rep < 1; ++rep) {
         for (int wgs : {256, 512}) {
             run_flat2<STORE_ONLY, 0, 4>("store only", xy, w, n, Q, ldf, partial, wgs);
             run_flat2<STORE_ONLY, 0, 8>("store only", xy, w, n, Q, ldf, partial, wgs);
