@@ -1009,22 +1009,7 @@ def main():
         del conv
     model = sols = None
     torch.cuda.empty_cache()
-    if rank == 0 and not args.no_extras:
-        # BASELINE configs 2 and 3 and the 2 x 50 311 reading of the headline, on this rank's GPU
-        extras.update(config3_two_films(sc, torch, args.iterations))
-        extras.update(config2_single_film(sc, torch, kernels))
-        extras.update(pipelined_cold_solves(sc, torch, device, args.iterations))
-        extras.update(configH_float32(sc, torch, args.K, args.iterations))
-        extras.update(configH_alt_2x50k(sc, torch, args.iterations))
-    if not args.no_extras:
-        # BASELINE configs 4 and 5 on all ranks (collective calls: every rank takes part)
-        for fn in (config4_scan, config5_stack):
-            res = fn(sc, torch, dist, rank, world, args.iterations)
-            if rank == 0:
-                extras.update(res)
-            torch.cuda.empty_cache()
-
-    if rank == 0:
+    def build_line():
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         avg_us = gemm_ms * 1e3 / max(1, gemm_n)
         avg_gflop = gemm_fl / max(1, gemm_n) / 1e9
@@ -1100,7 +1085,62 @@ def main():
             out["parity"] = base.pop("parity")
             out["cpu_baseline"] = base
             out["extras"]["gpu_over_cpu_baseline"] = value / base["value"]
-        print(json.dumps(out), flush=True)
+        return out
+
+    def guarded(name, fn):
+        """An extra that fails costs its own numbers, never the line."""
+        try:
+            return fn()
+        except Exception as exc:   # noqa: BLE001 -- reported in the line
+            torch.cuda.empty_cache()
+            return {f"{name}_error": f"{type(exc).__name__}: {exc}"[:300]}
+
+    if rank == 0 and not args.no_extras:
+        # BASELINE configs 2 and 3 and the 2 x 50 311 reading of the headline, on this rank's GPU
+        extras.update(guarded("config3", lambda: config3_two_films(sc, torch, args.iterations)))
+        extras.update(guarded("config2", lambda: config2_single_film(sc, torch, kernels)))
+        extras.update(guarded("pipelined", lambda: pipelined_cold_solves(sc, torch, device, args.iterations)))
+        extras.update(guarded("configH_float32", lambda: configH_float32(sc, torch, args.K, args.iterations)))
+        extras.update(guarded("configH_alt_2x50k", lambda: configH_alt_2x50k(sc, torch, args.iterations)))
+
+    def emit_line():
+        if rank == 0:
+            print(json.dumps(build_line()), flush=True)
+
+    if not args.no_extras:
+        # BASELINE configs 4 and 5 on all ranks (collective calls: every rank takes part).  With more than one rank a
+        # failure on ONE rank leaves the others inside a collective: a watchdog then prints the line as it stands
+        # (headline measured, collective extras marked) and ends the process, so that the record of the run survives.
+        watchdog = None
+        if world > 1:
+            import threading
+
+            limit = float(os.environ.get("BENCH_COLLECTIVE_EXTRAS_TIMEOUT_S", "420"))
+
+            def give_up():
+                extras["collective_extras_error"] = f"configs 4 / 5 did not finish within {limit:.0f} s on {world} ranks"
+                emit_line()
+                os._exit(0)
+
+            watchdog = threading.Timer(limit, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+            if rank == 0:
+                import signal
+
+                # the launcher ends the surviving ranks with SIGTERM when one of them dies: the line goes out first
+                signal.signal(signal.SIGTERM, lambda *_: give_up())
+        for name, fn in (("config4", config4_scan), ("config5", config5_stack)):
+            res = guarded(name, lambda: fn(sc, torch, dist, rank, world, args.iterations))
+            if rank == 0:
+                extras.update(res)
+            torch.cuda.empty_cache()
+        if watchdog is not None:
+            watchdog.cancel()
+            if rank == 0:
+                signal.signal(signal.SIGTERM, signal.SIG_DFL)
+
+    emit_line()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
