@@ -158,7 +158,12 @@ int ssa_lu_solve(const void *LU, int64_t n, int64_t lda, const void *aux, void *
  *                    chain on its own internal side stream, hidden behind the other films'
  *                    updates.  A, n, lda, info, aux: HOST arrays of `count` entries with the
  *                    per-matrix arguments of ssa_chol_factor.  Results identical to `count`
- *                    separate ssa_chol_factor calls.
+ *                    separate ssa_chol_factor calls (float64: bit for bit; float32: to rounding, the
+ *                    schedule's two-panel steps depend on the largest matrix of the batch).
+ *   float32 (SSA_F32): storage, trailing updates, panels and solves are float32; the 256 x 256 diagonal
+ *                    blocks are factored and inverted in float64 inside the diagonal-block kernel and
+ *                    rounded back (ssa_lu_factor's route without interchanges does the same), which brings
+ *                    the backward error of the factorization to LAPACK spotrf / sgetrf's.
  *   ssa_chol_solve:  L L^T X = B in place, nrhs >= 1; workspace ssa_chol_solve_workspace_bytes.
  *                    nrhs = 1: triangular GEMV chain at the HBM rate; 2..64 (float64): the factor is
  *                    streamed once by an MFMA kernel that takes its operands straight from global memory;
