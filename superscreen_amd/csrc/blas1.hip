@@ -40,7 +40,7 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return __bui
 // TRI = 1 / 2: M is lower / upper triangular (zero on the other side); a wave then only streams
 // the columns up to / from the diagonal of its rows (whole vectors: the extra elements are zeros).
 // The rows [row0, row0 + ROWS) of one wave:
-template <typename T, int ROWS, bool VECTOR, int TRI>
+template <typename T, int ROWS, bool VECTOR, int TRI, int UNR = 2>
 __device__ __forceinline__ void gemv_wave_rows(const T *__restrict__ M, int64_t nr, int64_t nc, int64_t ldm,
                                                const T *__restrict__ x, const T *__restrict__ xscale,
                                                const int64_t *__restrict__ xidx, T *__restrict__ y, T alpha, T beta,
@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemv_wave_rows(const T *__restrict__ M, int64_t 
     if (nc_vec < c_begin) nc_vec = c_begin;
     if (VECTOR) {
         using V = typename Vec16<T>::type;
-#pragma unroll 2
+#pragma unroll UNR
         for (int64_t c = c_begin + static_cast<int64_t>(lane) * VN; c < nc_vec; c += 64 * VN) {
             T xv[VN];
 #pragma unroll
@@ -98,6 +98,20 @@ __device__ __forceinline__ void gemv_wave_rows(const T *__restrict__ M, int64_t 
     }
 }
 
+// Triangular blocks (TRI = 1 lower, 2 upper), rows in PAIRS: wave g of ceil(nr / 2) takes the rows g and nr - 1 - g, a
+// short and a long one -- the same amount of data for every wave.  (With consecutive rows per wave the last
+// workgroups of a launch read twice the average and the launch lasts as long as they do: 4.6 TB/s on the 4096-row
+// inverse blocks where the rectangular blocks of the same chain reach 5.8.)  A row is still summed by one wave.
+template <typename T, int TRI>
+__device__ __forceinline__ void gemv_wave_tri_pair(const T *__restrict__ M, int64_t nr, int64_t nc, int64_t ldm,
+                                                   const T *__restrict__ x, T *__restrict__ y, T alpha, T beta,
+                                                   int64_t g, int lane) {
+    const int64_t other = nr - 1 - g;
+    if (g > other) return;
+    gemv_wave_rows<T, 1, true, TRI, 4>(M, nr, nc, ldm, x, nullptr, nullptr, y, alpha, beta, g, lane);
+    if (other != g) gemv_wave_rows<T, 1, true, TRI, 4>(M, nr, nc, ldm, x, nullptr, nullptr, y, alpha, beta, other, lane);
+}
+
 template <typename T, int ROWS, bool VECTOR, int TRI = 0>
 __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int64_t nr,
                                                    int64_t nc, int64_t ldm,
@@ -108,7 +122,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T *__restrict__ M, int6
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * ROWS;
-    gemv_wave_rows<T, ROWS, VECTOR, TRI>(M, nr, nc, ldm, x, xscale, xidx, y, alpha, beta, row0, lane);
+    if constexpr (TRI != 0 && VECTOR && ROWS == 2)
+        gemv_wave_tri_pair<T, TRI>(M, nr, nc, ldm, x, y, alpha, beta, row0 / 2, lane);
+    else
+        gemv_wave_rows<T, ROWS, VECTOR, TRI>(M, nr, nc, ldm, x, xscale, xidx, y, alpha, beta, row0, lane);
 }
 
 template <typename T, int ROWS>
@@ -203,6 +220,10 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(GemvBatch<T> b, T alpha
     const int64_t local = blockIdx.x - b.first_block[p];
     const int rows = b.rows[p];
     const int64_t row0 = (local * 4 + wave) * rows;
+    if constexpr (TRI != 0 && SSA_TRMV_ROWS == 2) {
+        gemv_wave_tri_pair<T, TRI>(b.M[p], b.nr[p], b.nc[p], b.ldm[p], b.x[p], b.y[p], alpha, beta, local * 4 + wave, lane);
+        return;
+    }
     if (rows == 4)
         gemv_wave_rows<T, 4, true, TRI>(b.M[p], b.nr[p], b.nc[p], b.ldm[p], b.x[p], nullptr, nullptr, b.y[p], alpha, beta, row0, lane);
     else if (rows == 2)
