@@ -111,6 +111,23 @@ __device__ __forceinline__ double inv_r3_over_4pi(double r2) {
     return __builtin_fma(k3 * e, p, k3);
 }
 
+// sum_{k < count} p[k * stride], added in index order (the order is part of the result), eight loads in flight at a
+// time (a plain loop waits for every load before it issues the next): the fixed-order reductions of the split sums.
+template <typename T>
+__device__ __forceinline__ T sum_strided(const T *__restrict__ p, int count, int64_t stride) {
+    T s = T(0);
+    int k = 0;
+    for (; k + 8 <= count; k += 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[static_cast<int64_t>(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < count; ++k) s += p[static_cast<int64_t>(k) * stride];
+    return s;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

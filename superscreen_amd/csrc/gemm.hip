@@ -612,8 +612,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const T *__restrict_
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
     const int64_t r = idx / N, c = idx - r * N;
-    T acc = T(0);
-    for (int s = 0; s < splits; ++s) acc += partial[static_cast<int64_t>(s) * M * N + idx];
+    const T acc = sum_strided(partial + idx, splits, M * N);
     T *dst = C + r * ldc + c;
     *dst = (beta == T(0)) ? alpha * acc : alpha * acc + beta * *dst;
 }
@@ -758,8 +757,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const double *__rest
     if (idx >= M * N) return;
     const int64_t i = idx / N;
     const int c = static_cast<int>(idx - i * N);
-    double acc = 0.0;
-    for (int p = 0; p < pieces; ++p) acc += partial[(static_cast<int64_t>(p) * M + i) * nv + c];
+    const double acc = sum_strided(partial + i * nv + c, pieces, M * nv);
     double *dst = C + i * ldc + c;
     *dst = (beta == 0.0) ? alpha * acc : alpha * acc + beta * *dst;
 }

@@ -25,23 +25,6 @@ struct alignas(16) Source {
 constexpr int kTPL = 2;   // measured at 25 117 x 25 117 (same box): self field 1.52 / 1.75 / 1.71 Tpair/s for 4 / 2 / 1
 constexpr double kFarAway = 1.0e15;
 
-// Sum over the slices of one entry of a partial-sum workspace [slices][count], in slice order (the order is part of
-// the result), eight loads in flight at a time (a plain loop waits for every load before it issues the next: 15 us
-// for 40 slices of 25 000 entries).
-__device__ __forceinline__ double sum_slices(const double *__restrict__ partial, int slices, int64_t count, int64_t i) {
-    double s = 0.0;
-    int k = 0;
-    for (; k + 8 <= slices; k += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = partial[static_cast<int64_t>(k + u) * count + i];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; k < slices; ++k) s += partial[static_cast<int64_t>(k) * count + i];
-    return s;
-}
-
 template <typename T>
 __global__ __launch_bounds__(kPairThreads) void biot_savart_partial_kernel(
     const double *__restrict__ src_xy, const T *__restrict__ src_areas,
@@ -208,7 +191,7 @@ __global__ void sheet_field_combine_kernel(const double *__restrict__ partial, i
                                            double prefactor, double *__restrict__ out) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    double s = sum_slices(partial, slices, count, i);
+    double s = sum_strided(partial + i, slices, count);
     out[i] = prefactor * s;
 }
 
@@ -302,7 +285,7 @@ __global__ void combine_partials_kernel(const double *__restrict__ partial, int 
                                         int64_t nt, T *__restrict__ out, int accumulate) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nt) return;
-    double s = sum_slices(partial, slices, nt, i);
+    double s = sum_strided(partial + i, slices, nt);
     if (accumulate) s += static_cast<double>(out[i]);  // solver/solve.py:508 (f64 add, one cast)
     out[i] = static_cast<T>(s);
 }
@@ -315,7 +298,7 @@ __global__ void self_field_combine_kernel(const double *__restrict__ partial, in
                                           T *__restrict__ out) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double s = sum_slices(partial, slices, n, i);
+    double s = sum_strided(partial + i, slices, n);
     const double d = qdiag[i] * (w[i] * static_cast<double>(g[i]));
     out[i] = static_cast<T>(alpha * (d - s));
 }

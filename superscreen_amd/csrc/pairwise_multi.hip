@@ -315,8 +315,7 @@ __global__ void biot_savart_multi_combine_kernel(const double *__restrict__ part
     if (t >= nt * nv) return;  // nt = number of targets (rows of the list when there is one)
     const int64_t i = t / nv;
     const int v = static_cast<int>(t - i * nv);
-    double s = 0.0;
-    for (int k = 0; k < slices; ++k) s += partial[(static_cast<int64_t>(k) * nt + i) * pstride + v];
+    double s = sum_strided(partial + i * pstride + v, slices, nt * pstride);
     T *dst = out + (rows ? rows[i] : i) * nvec + v0 + v;
     if (accumulate) s += static_cast<double>(*dst);
     *dst = static_cast<T>(s);
