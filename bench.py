@@ -696,6 +696,8 @@ def config5_stack(sc, torch, dist, rank, world, iterations, steps=2):
     placement = coupling = None
     if world > 1 and world < 2 * len(films):
         placement, mode = FilmPlacement(rank=rank, world=world), "FilmPlacement (owner computes; one all-reduce of the result vectors per pass)"
+        if world > len(films):
+            mode += f"; ranks {len(films)}..{world - 1} own no film and idle (fewer than two ranks per film: no helper groups)"
     elif world > 1:
         # more ranks than films: one group of world // n_films ranks per film -- the owner factors and solves, every
         # rank of the group takes a source slice of the coupling sums whose target is the group's film (summed inside
@@ -1117,10 +1119,13 @@ def main():
 
             limit = float(os.environ.get("BENCH_COLLECTIVE_EXTRAS_TIMEOUT_S", "420"))
 
-            def give_up():
-                extras["collective_extras_error"] = f"configs 4 / 5 did not finish within {limit:.0f} s on {world} ranks"
+            def give_up(reason=None):
+                # The headline was measured before the collective extras started, so the line still goes out -- but
+                # a process that stalled or was killed must NOT look like a success: exit status 3.
+                extras["collective_extras_error"] = reason or (
+                    f"configs 4 / 5 did not finish within {limit:.0f} s on {world} ranks")
                 emit_line()
-                os._exit(0)
+                os._exit(3)
 
             watchdog = threading.Timer(limit, give_up)
             watchdog.daemon = True
@@ -1129,7 +1134,8 @@ def main():
                 import signal
 
                 # the launcher ends the surviving ranks with SIGTERM when one of them dies: the line goes out first
-                signal.signal(signal.SIGTERM, lambda *_: give_up())
+                signal.signal(signal.SIGTERM, lambda *_: give_up(
+                    f"terminated by the launcher (SIGTERM) during configs 4 / 5 on {world} ranks"))
         for name, fn in (("config4", config4_scan), ("config5", config5_stack)):
             res = guarded(name, lambda: fn(sc, torch, dist, rank, world, args.iterations))
             if rank == 0:

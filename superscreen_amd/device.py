@@ -38,24 +38,18 @@ class Layer:
     def __init__(self, name: str, Lambda: Union[float, Parameter, None] = None,
                  london_lambda: Union[float, Parameter, None] = None,
                  thickness: Optional[float] = None, z0: float = 0):
-        self.name = name
-        self.thickness = thickness
-        self.london_lambda = london_lambda
-        self.z0 = z0
-        if Lambda is None:
-            if london_lambda is None or thickness is None:
-                raise ValueError(
-                    "You must provide either an effective penetration depth Lambda "
-                    "or both a london_lambda and a thickness."
-                )
-            self._Lambda = None
-        else:
-            if london_lambda is not None or thickness is not None:
-                raise ValueError(
-                    "You must provide either an effective penetration depth Lambda "
-                    "or both a london_lambda and a thickness (but not all three)."
-                )
-            self._Lambda = Lambda
+        # exactly one description of the screening length: Lambda itself, or the pair it is derived from
+        # (``device/layer.py:40-58``: the same two ValueErrors)
+        pair_given = (london_lambda is not None, thickness is not None)
+        if Lambda is None and not all(pair_given):
+            raise ValueError("You must provide either an effective penetration depth Lambda "
+                             "or both a london_lambda and a thickness.")
+        if Lambda is not None and any(pair_given):
+            raise ValueError("You must provide either an effective penetration depth Lambda "
+                             "or both a london_lambda and a thickness (but not all three).")
+        self.name, self.z0 = name, z0
+        self.london_lambda, self.thickness = london_lambda, thickness
+        self._Lambda = Lambda          # None: derived from london_lambda and thickness on access
 
     @property
     def Lambda(self) -> Union[float, Parameter]:
@@ -186,6 +180,40 @@ class Polygon:
         if index:
             return np.where(mask)[0]
         return mask
+
+    # -- affine transforms (``device/polygon.py:226-300``; shapely.affinity there, plain numpy here) --
+    def _origin(self, origin) -> np.ndarray:
+        if isinstance(origin, str):
+            if origin == "center":       # centre of the bounding box
+                pts = self.points
+                return 0.5 * (pts.min(axis=0) + pts.max(axis=0))
+            if origin == "centroid":     # centre of mass of the polygon
+                x, y = self.points[:, 0], self.points[:, 1]
+                cross = x[:-1] * y[1:] - x[1:] * y[:-1]
+                return np.array([np.sum((x[:-1] + x[1:]) * cross), np.sum((y[:-1] + y[1:]) * cross)]) \
+                    / (3.0 * np.sum(cross))
+            raise ValueError(f"Unknown origin {origin!r}; expected (x, y), 'center' or 'centroid'.")
+        return np.asarray(origin, dtype=float)
+
+    def rotate(self, degrees: float, origin=(0.0, 0.0), inplace: bool = False) -> "Polygon":
+        """Rotates the polygon counterclockwise by ``degrees`` about ``origin``."""
+        polygon = self if inplace else self.copy()
+        o = self._origin(origin)
+        c, s_ = np.cos(np.radians(degrees)), np.sin(np.radians(degrees))
+        polygon.points = (self.points - o) @ np.array([[c, s_], [-s_, c]]) + o
+        return polygon
+
+    def translate(self, dx: float = 0.0, dy: float = 0.0, inplace: bool = False) -> "Polygon":
+        polygon = self if inplace else self.copy()
+        polygon.points = self.points + np.array([dx, dy], dtype=float)
+        return polygon
+
+    def scale(self, xfact: float = 1.0, yfact: float = 1.0, origin=(0, 0), inplace: bool = False) -> "Polygon":
+        """Scales by ``xfact`` / ``yfact`` about ``origin``; negative factors mirror the polygon."""
+        polygon = self if inplace else self.copy()
+        o = self._origin(origin)
+        polygon.points = (self.points - o) * np.array([xfact, yfact], dtype=float) + o
+        return polygon
 
     def on_boundary(self, points: np.ndarray, radius: float = 1e-3, index: bool = False):
         """Points within ``radius`` of the polygon's boundary (``device/polygon.py:164-190``)."""
@@ -466,10 +494,70 @@ class Device:
             return result[0]
         return result
 
-    # (The reference's rigid transforms of a device -- scale / rotate / mirror_layers / translate,
-    # ``device/device.py:256-381``, and of a polygon, ``device/polygon.py:226-300`` -- are not part of the path this
-    # package replaces, SURVEY.md section 2, and are not provided: build the transformed geometry with numpy and
-    # construct a new Device.)
+    # -- rigid transforms of the whole device (``device/device.py:256-381``) ------------------------
+    def _warn_if_mesh_exist(self, method: str) -> None:
+        if self.meshes:
+            logger.warning(f"Calling device.{method} on a device whose mesh already exists returns a new device "
+                           f"with no mesh. Call new_device.make_mesh() to generate the mesh for the new device.")
+
+    @staticmethod
+    def _check_origin(origin) -> None:
+        import numbers
+
+        if not (isinstance(origin, tuple) and len(origin) == 2
+                and all(isinstance(val, numbers.Real) for val in origin)):
+            raise TypeError("Origin must be a tuple of floats (x, y).")
+
+    def scale(self, xfact: float = 1, yfact: float = 1, origin: Tuple[float, float] = (0, 0)) -> "Device":
+        self._check_origin(origin)
+        self._warn_if_mesh_exist("scale()")
+        device = self.copy(with_mesh=False)
+        for polygon in device.get_polygons():
+            polygon.scale(xfact=xfact, yfact=yfact, origin=origin, inplace=True)
+        return device
+
+    def rotate(self, degrees: float, origin: Tuple[float, float] = (0, 0)) -> "Device":
+        self._check_origin(origin)
+        self._warn_if_mesh_exist("rotate()")
+        device = self.copy(with_mesh=False)
+        for polygon in device.get_polygons():
+            polygon.rotate(degrees, origin=origin, inplace=True)
+        return device
+
+    def mirror_layers(self, about_z: float = 0.0) -> "Device":
+        self._warn_if_mesh_exist("mirror_layers()")
+        device = self.copy(with_mesh=False)
+        for layer in device.layers.values():
+            layer.z0 = about_z - layer.z0
+        return device
+
+    def translate(self, dx: float = 0, dy: float = 0, dz: float = 0, inplace: bool = False) -> "Device":
+        """Moves polygons, mesh sites and (``dz``) layers; the mesh survives (``device/device.py:334-365``)."""
+        device = self if inplace else self.copy(with_mesh=True, copy_mesh=True)
+        for polygon in device.get_polygons():
+            polygon.translate(dx, dy, inplace=True)
+        for mesh in (device.meshes or {}).values():
+            mesh.sites += np.array([[dx, dy]], dtype=float)
+            mesh.triangle_centroids += np.array([[dx, dy]], dtype=float)
+            mesh._triangulation = None
+        if dz:
+            for layer in device.layers.values():
+                layer.z0 += dz
+        return device
+
+    def translation(self, dx: float, dy: float, dz: float = 0):
+        """Context manager: the device is translated inside the block and moved back afterwards."""
+        from contextlib import contextmanager
+
+        @contextmanager
+        def moved():
+            try:
+                self.translate(dx, dy, dz=dz, inplace=True)
+                yield
+            finally:
+                self.translate(-dx, -dy, dz=-dz, inplace=True)
+
+        return moved()
 
     def to_hdf5(self, path_or_group, save_mesh: bool = True, compress: bool = True) -> None:
         """Serializes the device (``device/device.py:936-977``): same group / attribute names as the

@@ -278,6 +278,12 @@ class FilmPlacement:
 
         if self.group_size <= 1 or self.film_index < 0 or not fields:
             return
+        if self.film_group is None:
+            # (make_groups=False, or a placement built on an RcclCommunicator: without the film's own group the
+            # all-reduce would run over the WORLD group and add the partial fields of DIFFERENT films together)
+            raise RuntimeError("FilmPlacement with helper groups has no process group for this rank's film "
+                               "(constructed with make_groups=False or without torch.distributed): the coupling "
+                               "sums of a film can only be reduced inside its own group.")
         if len(fields) == 1:
             _dist().all_reduce(fields[0], op=_dist().ReduceOp.SUM, group=self.film_group)
             return

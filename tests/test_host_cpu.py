@@ -299,15 +299,43 @@ def _linear_lambda(x, y, offset=0.0):
     return offset + 0.1 * (x + y)
 
 
-def test_polygon_boundary_distance():
-    """``Polygon.on_boundary`` (device/polygon.py:164-190)."""
+def test_polygon_and_device_transforms():
+    """Affine transforms of polygons and devices (device/polygon.py:226-300, device/device.py:256-381),
+    numpy restatements of what shapely.affinity does in the reference."""
     from superscreen_amd.geometry import box
 
     rect = sc.Polygon("r", layer="base", points=box(4.0, 2.0, points=41, center=(1.0, 0.5)))
     assert rect.area == pytest.approx(8.0)
+    moved = rect.translate(dx=1.0, dy=-2.0)
+    assert moved is not rect and np.allclose(moved.points, rect.points + [1.0, -2.0]) and moved.name == "r"
+    turned = rect.rotate(90)                                    # about (0, 0), counterclockwise
+    assert np.allclose(turned.extents, (2.0, 4.0)) and turned.contains_points(np.array([[-0.5, 1.0]])).all()
+    assert np.allclose(rect.rotate(90, origin="center").extents, (2.0, 4.0))
+    assert rect.rotate(90, origin="center").contains_points(np.array([[1.0, 0.5]])).all()
+    assert np.allclose(rect._origin("centroid"), (1.0, 0.5)) and np.allclose(rect._origin("center"), (1.0, 0.5))
+    big = rect.scale(xfact=2.0, yfact=-1.0)                     # negative factor mirrors; stays a valid CCW ring
+    assert big.area == pytest.approx(16.0) and np.allclose(big.extents, (8.0, 2.0))
+    same = rect.copy()
+    assert same.rotate(30, inplace=True) is same and not np.allclose(same.points, rect.points)
     edge = rect.on_boundary(np.array([[3.0, 0.5], [1.0, 0.5], [9.0, 9.0]]), radius=1e-2)
     assert edge.tolist() == [True, False, False]
     assert rect.on_boundary(np.array([[3.0, 0.5], [1.0, 0.5]]), radius=1e-2, index=True).tolist() == [0]
+
+    device = synthetic.make_strip_device(8, 4, hole_radius=0.5)
+    sites = device.meshes["strip"].sites.copy()
+    shifted = device.translate(dx=2.0, dy=1.0, dz=0.25)
+    assert np.allclose(shifted.meshes["strip"].sites, sites + [2.0, 1.0]) and np.allclose(device.meshes["strip"].sites, sites)
+    assert shifted.layers["base"].z0 == 0.25 and np.allclose(shifted.holes["hole"].points, device.holes["hole"].points + [2.0, 1.0])
+    assert np.allclose(shifted.terminals["strip"][0].points, device.terminals["strip"][0].points + [2.0, 1.0])
+    with device.translation(1.0, 0.0, dz=1.0):
+        assert np.allclose(device.meshes["strip"].sites, sites + [1.0, 0.0]) and device.layers["base"].z0 == 1.0
+    assert np.allclose(device.meshes["strip"].sites, sites) and device.layers["base"].z0 == 0.0
+    rotated = device.rotate(90)
+    assert not rotated.meshes and np.allclose(rotated.films["strip"].extents, device.films["strip"].extents[::-1])
+    assert device.scale(xfact=2.0).films["strip"].area == pytest.approx(2 * device.films["strip"].area)
+    assert device.translate(dz=0.3).mirror_layers(about_z=1.0).layers["base"].z0 == pytest.approx(0.7)
+    with pytest.raises(TypeError):
+        device.rotate(10, origin=[0, 0])
 
 
 def test_lu_concurrency_groups():

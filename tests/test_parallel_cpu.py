@@ -187,6 +187,13 @@ def test_film_placement_helper_groups_bookkeeping():
         assert p.group_size == 1 and p.coupling_targets(films) == p.mine(films) and p.source_slice(0, 10) == (0, 10)
     with pytest.raises(ValueError):
         FilmPlacement(rank=0, world=8, n_films=4, make_groups=False).owners(films[:3])
+    # a helper-group placement without its film's process group must refuse to reduce (the world group would add the
+    # partial fields of DIFFERENT films together); without helper groups there is nothing to reduce
+    import torch
+
+    with pytest.raises(RuntimeError, match="own group"):
+        FilmPlacement(rank=0, world=8, n_films=4, make_groups=False).reduce_coupling([torch.zeros(3)])
+    FilmPlacement(rank=1, world=4, n_films=4, make_groups=False).reduce_coupling([torch.zeros(3)])
 
 
 def _helper_worker(rank, world, port, q):
