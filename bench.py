@@ -326,8 +326,11 @@ def oracle_parity(orc, cpu_kernels, films, field_mT, iterations, gpu_solutions):
                 worst["field_from_other_films"] = max(worst["field_from_other_films"],
                                                       rel(got.field_from_other_films, ref.field_from_other_films))
         per_iterate.append(err_it)
+    fluxoid = fluxoid_parity(orc, films, trace, gpu_solutions)
     return {
         "max_rel_err_stream": worst["stream"],
+        "max_rel_err_fluxoid": fluxoid["max_rel_err_fluxoid"],
+        "fluxoid": fluxoid,
         "per_film": per_film,
         "per_iterate_stream": per_iterate,
         "max_rel_err_current_density": worst["current_density"],
@@ -336,12 +339,43 @@ def oracle_parity(orc, cpu_kernels, films, field_mT, iterations, gpu_solutions):
         "iterations": iterations,
         "applied_field_mT": field_mT,
         "tolerance": 1e-6,
-        "passed": bool(worst["stream"] < 1e-6),
+        "passed": bool(worst["stream"] < 1e-6 and fluxoid["max_rel_err_fluxoid"] < 1e-6),
         "definition": "max|g_gpu - g_ref| / max|g_ref| per film and iterate, all iterates of the last timed GPU step",
         "reference": ("CPU oracle: scipy lu_factor(-A) / lu_solve (solve_film.py:279, 526-531), A = Q[ix,ix] w - "
                       "Lambda Del2 (:296-305), Jacobi loop of solve.py:491-536, at the benchmark size"),
         "oracle_seconds": time.perf_counter() - t0,
     }
+
+
+def fluxoid_parity(orc, films, trace, gpu_solutions):
+    """Fluxoids of the benchmark solve against the oracle (north_star: "stream functions and fluxoids";
+    solution.py:484-563, 565-609): a ring half way between the washer's hole and the film's rim, on every film (the
+    washer's is the fluxoid of its hole, the disk's that of a simply connected region), every iterate.  Error of a
+    fluxoid = the larger of |flux part - ref| and |supercurrent part - ref| over the larger of the two reference
+    parts (both parts in mT um^2)."""
+    device = gpu_solutions[0].device
+    names = list(gpu_solutions[0].film_solutions)
+    from superscreen_amd import Polygon, synthetic
+
+    film_poly = device.films[names[0]].points
+    r_film = float(np.max(np.hypot(film_poly[:, 0], film_poly[:, 1])))
+    holes = list(device.holes.values())
+    r_hole = float(np.max(np.hypot(holes[0].points[:, 0], holes[0].points[:, 1]))) if holes else 0.0
+    ring = Polygon(points=synthetic.circle_points(0.5 * (r_hole + r_film), 301)).points
+    worst, last = 0.0, {}
+    for it, ref in enumerate(trace):
+        for f, nm in zip(films, names):
+            got = gpu_solutions[it].polygon_fluxoid(ring, film=nm, units="mT * um**2", with_units=False)
+            want = orc.polygon_fluxoid_mT_um2(f, ref[f.name], ring, device.films[nm].points)
+            scale = max(abs(want[0]), abs(want[1]))
+            err = max(abs(got.flux_part - want[0]), abs(got.supercurrent_part - want[1])) / scale
+            worst = max(worst, err)
+            if it == len(trace) - 1:
+                last[nm] = {"gpu_mT_um2": [got.flux_part, got.supercurrent_part], "oracle_mT_um2": list(want),
+                            "fluxoid_Phi0": (got.flux_part + got.supercurrent_part) * 1e-15 / orc.PHI_0}
+    return {"max_rel_err_fluxoid": worst, "ring_radius_um": 0.5 * (r_hole + r_film), "last_iterate": last,
+            "definition": "max over films and iterates of max(|flux part - ref|, |supercurrent part - ref|) / "
+                          "max(|ref flux part|, |ref supercurrent part|)"}
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -642,6 +642,22 @@ def polygon_fluxoid_raw(film: OracleFilm, sol: OracleFilmSolution, polygon_point
     return flux_part, int_J
 
 
+def polygon_fluxoid_mT_um2(film: OracleFilm, sol: OracleFilmSolution, polygon_points: np.ndarray,
+                           film_outline: np.ndarray) -> Tuple[float, float]:
+    """``Solution.polygon_fluxoid(polygon, film=...)`` (solution.py:484-563) of one oracle film solution as
+    ``(flux_part, supercurrent_part)``, both in mT um^2 (``units="mT * um**2"``): the vertex test of the flux part
+    is ``Polygon.contains_points`` = matplotlib ``Path.contains_points`` with radius 0 (device/polygon.py:159), the
+    in-film test of the polygon vertices the same on the film's outline (solution.py:313-315).  ``polygon_points``:
+    the closed, counter-clockwise ring as ``Polygon.points`` holds it."""
+    from matplotlib.path import Path
+
+    polygon_points = np.asarray(polygon_points, dtype=np.float64)
+    in_polygon = Path(polygon_points, closed=True).contains_points(film.mesh.sites, radius=0)
+    in_film_poly = Path(np.asarray(film_outline, dtype=np.float64), closed=True).contains_points(polygon_points, radius=0)
+    flux_raw, int_J = polygon_fluxoid_raw(film, sol, polygon_points, in_polygon, in_film_poly)
+    return flux_raw, MU_0 * int_J * 1e-12 / (1e-3 * 1e-12)   # mu_0 [uA um] -> mT um^2
+
+
 def fluxoid_in_Phi0(flux_part_mT_um2: float, int_J_uA_um: float) -> Tuple[float, float]:
     """Unit conversion of the two parts to Phi_0 (solution.py:538, 560-561)."""
     flux = flux_part_mT_um2 * 1e-3 * 1e-12 / PHI_0

@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <string>
 #include <utility>
 
 #include "chain_streams.hpp"
@@ -495,6 +496,42 @@ struct FinishPlan {
     }
 };
 
+// Debugging knobs of the schedule (never set in production; tools/chol_race_hunt.py): the environment variable
+// SSA_CHOL_DEBUG holds comma-separated `name=value` pairs, read at every call:
+//   split=0|1   trailing updates of >= 3 matrices on streams of their own (default) or all on the caller's stream
+//   tail=N      switch to single-stream rounds at N trailing columns (default 10 240; 0: no rounds)
+//   late=1      no finishing passes beside the schedule: everything after the last panel, on the caller's stream
+//   delay=0     every trailing update applies ONE panel (K = 256)
+//   sync=1      the host waits for the device after every outer step (serialises the streams: no overlap at all)
+struct CholDebug {
+    int split = -1, late = 0, delay = 1, sync = 0;
+    int64_t tail = -1;
+};
+inline CholDebug chol_debug() {
+    CholDebug d;
+    const char *e = getenv("SSA_CHOL_DEBUG");
+    if (e == nullptr) return d;
+    std::string str(e);
+    size_t pos = 0;
+    while (pos < str.size()) {
+        size_t end = str.find(',', pos);
+        if (end == std::string::npos) end = str.size();
+        const std::string item = str.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq != std::string::npos) {
+            const std::string key = item.substr(0, eq);
+            const long long val = atoll(item.c_str() + eq + 1);
+            if (key == "split") d.split = static_cast<int>(val);
+            else if (key == "tail") d.tail = val;
+            else if (key == "late") d.late = static_cast<int>(val);
+            else if (key == "delay") d.delay = static_cast<int>(val);
+            else if (key == "sync") d.sync = static_cast<int>(val);
+        }
+        pos = end + 1;
+    }
+    return d;
+}
+
 // Factor `count` independent matrices (the films of a device) in one interleaved schedule.
 //
 // Every MFMA trailing update (SYRK) of every matrix goes to the caller's stream, round-robin over
@@ -542,7 +579,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // the next update of another matrix, and a matrix' chain no longer waits behind the updates of all the
     // others (4 x 30 301-vertex stack: 350 -> 317 ms; two matrices: no gain, 156.6 vs 158.7 ms, so they keep the
     // single stream).
-    const bool split_updates = count >= 3;
+    const CholDebug dbg = chol_debug();
+    const bool split_updates = dbg.split < 0 ? count >= 3 : (dbg.split != 0 && count >= 2);
     // Once the trailing matrix of EVERY film is at most this order the schedule is bound by the panel chains (a
     // round of a chain takes 0.3-0.5 ms beside running updates, an update of that size less): the rest of the
     // factorization runs as single-stream rounds of batched launches (see the loop below).
@@ -550,7 +588,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // 10240 / 12288 / 16384 / all columns, float32 57.7 -> 52.6, K = 81 60.8 -> 54.8, one film K = 64 18.0 -> 15.1,
     // K = 129 407 -> 405, four films 361 -> 350 ms.  Larger: the rounds' panel and strip launches are not hidden
     // behind an update the way the chains' are)
-    constexpr int64_t tail_round_cols = 10240;
+    const int64_t tail_round_cols = dbg.tail >= 0 ? dbg.tail : 10240;
     // a round launch with at most this many update tiles asks for a CU per workgroup (chain-bound rounds: the
     // diagonal-block workgroups then run alone on their CUs, 175 us instead of 220-300; 0 / 2500: + 0.5 ms)
     constexpr int64_t tail_excl_tiles = 1024;
@@ -587,7 +625,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
     // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' products
-    constexpr int kDelayDepth = 2;            // (3 / 4 panels: 107 / 108 against 101.5-102.8 ms in round 3; with the rounds
+    const int kDelayDepth = dbg.delay ? 2 : 1;            // (3 / 4 panels: 107 / 108 against 101.5-102.8 ms in round 3; with the rounds
                                               // behind the stream part, round 4: 96.4 / 100.4 against 94.6 ms)
     constexpr int64_t kDelayMinCols = 8192;   // (2048 ... 16384: flat within 1 %, rounds 2 and 3)
     hipStream_t cur_us[kMaxLanes];
@@ -595,12 +633,13 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     bool in_rounds = false;
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
         const int64_t c = k0 + CNB;   // first column of the next panel
+        if (dbg.sync && hipDeviceSynchronize() != hipSuccess) return SSA_ERR_HIP;
         // ---- films that have run out of panels while others still have some: their remaining finishing steps go to
         // their own low-priority stream, behind their last panel and behind what their update stream holds for them
         for (int i = 0; i < count; ++i) {
             const CholJob<T> &J = jobs[i];
             CholLane &ln = lanes[i];
-            if (c < J.n || detached[i]) continue;
+            if (c < J.n || detached[i] || dbg.late) continue;
             detached[i] = true;
             if (hipEventRecord(ln.ev_fork, cur_us[i]) != hipSuccess || hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess ||
                 hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess)
@@ -681,7 +720,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             // the finishing passes of a film's blocks that are final (all their columns lie left of c) fill the chip
             // beside the chain-bound rounds from the film's low-priority stream: in slices, so that no launch of theirs
             // holds more than a quarter of the chip's workgroup slots or a slot for longer than a round takes
-            if (tiles <= fill_tiles) {
+            if (tiles <= fill_tiles && !dbg.late) {
                 for (int i = 0; i < count; ++i) {
                     FinishPlan<T> &fp = plans[i];
                     CholLane &ln = lanes[i];
@@ -743,7 +782,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             // the solve-phase data of the SNB blocks that have become final (all their columns lie left of c): whole
             // launches on the matrix' low-priority stream, behind the chain (beside the rounds they go out in slices)
             FinishPlan<T> &fp = plans[i];
-            if (c / SNB > fp.done && fp.done < fp.nfull()) {
+            if (!dbg.late && c / SNB > fp.done && fp.done < fp.nfull()) {
                 if (hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
                 rc = fp.run_blocks(c / SNB, false, ln.finish);
                 if (rc != SSA_OK) return rc;

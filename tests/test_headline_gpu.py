@@ -335,7 +335,39 @@ def test_configH_full_size_vs_oracle(sc):
             assert relerr(fs.self_field, ref[nm].self_field) < 1e-9, (it, nm)
             if it:
                 assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < 1e-9, (it, nm)
-    print(f"config H vs oracle: stream max-rel-error {worst:.2e} over {iters + 1} iterates")
+    # Fluxoids at this size (north_star: "stream functions AND fluxoids"; solution.py:484-563, 565-609): a ring
+    # between the washer's hole and its rim (the hole's fluxoid), the same ring on the shield disk (a simply connected
+    # region), flux part and supercurrent part of every iterate against the oracle, < 1e-9 of the larger part.
+    worst_fluxoid = _fluxoid_parity(sc, device, K, sols, films, trace, tol=1e-9)
+    print(f"config H vs oracle: stream max-rel-error {worst:.2e}, fluxoid parts {worst_fluxoid:.2e} "
+          f"over {iters + 1} iterates")
+
+
+def _fluxoid_parity(sc, device, K, sols, films, trace, tol):
+    from superscreen_amd import synthetic
+
+    _, _, dr = synthetic.ring_disk_mesh(K)
+    Kf = synthetic.film_rings(K)
+    outline = synthetic.circle_points((Kf + 0.5) * dr)
+    ring = sc.Polygon(points=synthetic.circle_points((Kf // 3 + 0.5 + 0.5 * (Kf - Kf // 3)) * dr, 301)).points
+    worst = 0.0
+    for it, (sol, ref) in enumerate(zip(sols, trace)):
+        for film, nm in zip(films, device.films):
+            got = sol.polygon_fluxoid(ring, film=nm, units="mT * um**2", with_units=False)
+            want = orc.polygon_fluxoid_mT_um2(film, ref[film.name], ring, outline)
+            scale = max(abs(want[0]), abs(want[1]))
+            err = max(abs(got.flux_part - want[0]), abs(got.supercurrent_part - want[1])) / scale
+            worst = max(worst, err)
+            assert err < tol, (it, nm, tuple(got), want)
+    # the hole's own entry point, in Phi_0 (solution.py:565-609), last iterate
+    hole = next(iter(device.holes))
+    film_of_hole = next(f for f, nm in zip(films, device.films) if nm == list(device.films)[0])
+    fq = sols[-1].hole_fluxoid(hole, points=ring)
+    want = [v * 1e-3 * 1e-12 / orc.PHI_0 for v in     # mT um^2 -> Wb -> Phi_0
+            orc.polygon_fluxoid_mT_um2(film_of_hole, trace[-1][film_of_hole.name], ring, outline)]
+    assert abs(float(fq.flux_part.magnitude) - want[0]) < tol * abs(want[0])
+    assert abs(float(fq.supercurrent_part.magnitude) - want[1]) < tol * max(abs(want[0]), abs(want[1]))
+    return worst
 
 
 def test_configH_float32_no_worse_than_the_reference_in_float32(sc):
