@@ -29,7 +29,10 @@
 
 #include <algorithm>
 #include <mutex>
+#include <stdio.h>
+
 #include <string>
+#include <vector>
 #include <utility>
 
 #include "chain_streams.hpp"
@@ -503,8 +506,12 @@ struct FinishPlan {
 //   late=1      no finishing passes beside the schedule: everything after the last panel, on the caller's stream
 //   delay=0     every trailing update applies ONE panel (K = 256)
 //   sync=1      the host waits for the device after every outer step (serialises the streams: no overlap at all)
+//   excl=0      round launches never ask for a CU per workgroup
+//   trace=1     every diagonal-block workgroup of a round stores the block AS IT READ IT (register images, 272 KB);
+//               after the schedule the host waits and writes all of them to the file SSA_CHOL_TRACE_FILE:
+//               [matrix][panel][34 816] float64 (float64 matrices only)
 struct CholDebug {
-    int split = -1, late = 0, delay = 1, sync = 0;
+    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0;
     int64_t tail = -1;
 };
 inline CholDebug chol_debug() {
@@ -526,6 +533,8 @@ inline CholDebug chol_debug() {
             else if (key == "late") d.late = static_cast<int>(val);
             else if (key == "delay") d.delay = static_cast<int>(val);
             else if (key == "sync") d.sync = static_cast<int>(val);
+            else if (key == "excl") d.excl = static_cast<int>(val);
+            else if (key == "trace") d.trace = static_cast<int>(val);
         }
         pos = end + 1;
     }
@@ -598,6 +607,16 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     constexpr int64_t fill_tiles = 1500;
     FinishPlan<T> plans[kMaxLanes];
     int64_t nmax = 0;
+    // (debugging, trace=1: one slot of register images per matrix and panel, zero where no round ran)
+    double *trace_buf = nullptr;
+    int64_t trace_panels = 0;
+    if (dbg.trace && sizeof(T) == 8) {
+        for (int i = 0; i < count; ++i) trace_panels = std::max<int64_t>(trace_panels, jobs[i].n / CNB);
+        const size_t bytes = static_cast<size_t>(count) * trace_panels * cholk2::kScratchElems * sizeof(double);
+        if (hipMalloc(reinterpret_cast<void **>(&trace_buf), bytes) != hipSuccess ||
+            hipMemsetAsync(trace_buf, 0, bytes, st) != hipSuccess)
+            return SSA_ERR_HIP;
+    }
     for (int i = 0; i < count; ++i) {
         const CholJob<T> &J = jobs[i];
         CholLane &ln = lanes[i];
@@ -703,6 +722,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 r.ldc = J.lda;
                 r.M = below;
                 r.K = c - upd0;
+                if (trace_buf != nullptr)
+                    r.trace = trace_buf + (static_cast<int64_t>(i) * trace_panels + c / CNB) * cholk2::kScratchElems;
                 tiles += (below / 128) * (below / 128 + 1) / 2;
                 pending_from[i] = c;
                 if (below <= 0) continue;
@@ -711,7 +732,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 sj[np] = SmallNtJob{A21, A21, nullptr, A21 + CNB, J.lda, J.lda, J.lda, below, CNB, CNB, -1.0, 1.0, 0};
                 ++np;
             }
-            rc = tail_round_t(static_cast<const T *>(nullptr), nr, rj, tiles <= tail_excl_tiles ? 1 : 0, st);
+            rc = tail_round_t(static_cast<const T *>(nullptr), nr, rj, (dbg.excl && tiles <= tail_excl_tiles) ? 1 : 0, st);
             if (rc != SSA_OK) return rc;
             rc = small_batch_t(static_cast<const T *>(nullptr), np, pj, st);
             if (rc != SSA_OK) return rc;
@@ -802,6 +823,21 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (plans[i].finished()) continue;
         rc = plans[i].run_rest(false, st);
         if (rc != SSA_OK) return rc;
+    }
+    if (trace_buf != nullptr) {   // (debugging: the host waits here)
+        const size_t elems = static_cast<size_t>(count) * trace_panels * cholk2::kScratchElems;
+        std::vector<double> host(elems);
+        const bool ok = hipStreamSynchronize(st) == hipSuccess &&
+                        hipMemcpy(host.data(), trace_buf, elems * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(trace_buf);
+        const char *path = getenv("SSA_CHOL_TRACE_FILE");
+        if (ok && path != nullptr) {
+            if (FILE *f = fopen(path, "wb")) {
+                fwrite(host.data(), sizeof(double), elems, f);
+                fclose(f);
+            }
+        }
+        if (!ok) return SSA_ERR_HIP;
     }
     return SSA_OK;
 }

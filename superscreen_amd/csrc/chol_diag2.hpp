@@ -309,7 +309,7 @@ __device__ __forceinline__ void chol16inv(Tile<T> &d, Tile<T> &w, bool &bad, int
 // inside the diagonal blocks is); the kernel is latency-bound, so it costs little time.
 template <typename T, typename IO = T>
 __device__ __forceinline__ void chol_diag256_v2_body(IO *D, int lda, IO *W, int ldw, T *scratch, int32_t *info, int col1,
-                                                     char *cholk2_smem_raw CHOLK2_TIMING_ARG) {
+                                                     char *cholk2_smem_raw CHOLK2_TIMING_ARG, T *trace = nullptr) {
     Smem<T> &sm = *reinterpret_cast<Smem<T> *>(cholk2_smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __builtin_amdgcn_s_setprio(3);
@@ -331,6 +331,11 @@ __device__ __forceinline__ void chol_diag256_v2_body(IO *D, int lda, IO *W, int 
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (K + q <= row) image_store<T>(scratch + img_of(row, K + q), t[q], lane);
+            if (trace != nullptr) {   // (debugging: what this launch read, kept apart from the working copy)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (K + q <= row) image_store<T>(trace + img_of(row, K + q), t[q], lane);
+            }
         }
     }
     // (a wave reads back only images it wrote itself until the first barrier below)

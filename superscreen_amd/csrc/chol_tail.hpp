@@ -42,6 +42,7 @@ struct TailRoundJob {
     void *C;
     const void *P;
     int64_t ldc, M, K;
+    void *trace = nullptr;   // debugging (chol.hip, CholDebug::trace): the block as the kernel READ it, as register images
 };
 // exclusive: the launch asks for so much LDS that no second workgroup of an MFMA tile kernel fits on a CU beside one
 // of its own: the diagonal-block workgroups then have their CUs to themselves (chain-bound rounds: few tiles);

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void chol_tail_round_kernel(TailRo
         const TailRoundJob &F = a.f[a.diag_film[blockIdx.x]];
         cholk2::chol_diag256_v2_body<cholk2::factor_t<T>, T>(static_cast<T *>(F.D), F.lda, static_cast<T *>(F.W), F.ldw,
                                                              static_cast<cholk2::factor_t<T> *>(F.scratch), F.info, F.col1,
-                                                             smem_raw);
+                                                             smem_raw, static_cast<cholk2::factor_t<T> *>(F.trace));
         return;
     }
     // (equal blockIdx.x % 8 = equal XCD holds for the shifted ids as well)

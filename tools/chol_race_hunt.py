@@ -66,10 +66,39 @@ def locate(a, b, what):
 
 print(f"SSA_CHOL_DEBUG={os.environ.get('SSA_CHOL_DEBUG', '')!r} poison={poison.mode() or 'off'} K={K} films={nfilms} "
       f"unknowns={[ni[nm] for nm in names]} reps={reps}", flush=True)
+tracing = "trace=1" in os.environ.get("SSA_CHOL_DEBUG", "")
+TRACE_FILE = "/tmp/chol_trace.bin"
+if tracing:
+    os.environ["SSA_CHOL_TRACE_FILE"] = TRACE_FILE
+
+
+def read_trace():
+    """[film][panel][tile (I, K), K <= I, 136 of them][256]: the diagonal block of every ROUND as its workgroup read it."""
+    t = np.fromfile(TRACE_FILE, dtype=np.float64)
+    return t.reshape(nfilms, -1, 136, 256)
+
+
+def trace_report(t, t0):
+    lines = []
+    for i in range(nfilms):
+        for p in range(t.shape[1]):
+            d = (t[i, p] != t0[i, p]).any(axis=1)
+            if d.any():
+                tiles = []
+                for tid in np.flatnonzero(d):
+                    I = int((np.sqrt(8 * tid + 1) - 1) // 2)
+                    tiles.append((I, int(tid - I * (I + 1) // 2)))
+                diff = np.abs(t[i, p] - t0[i, p]).max()
+                lines.append(f"   trace: film {i} panel {p} (column {256 * p}): INPUT block differs in {len(tiles)} tiles, "
+                             f"first (row, col) tiles {tiles[:8]}, max |diff| {diff:.3e}")
+    return lines or ["   trace: every diagonal block was READ with the reference's bits"]
+
+
 ref = factor_all()
 torch.cuda.synchronize()
 assert all(f.info == 0 for f in ref)
 refs = [(f.L.clone(), f.aux.clone()) for f in ref]
+trace0 = read_trace() if tracing else None
 del ref
 bad = 0
 t0 = time.perf_counter()
@@ -91,6 +120,8 @@ for rep in range(reps):
                 print("   " + locate(f.L[:n, :n], L0[:n, :n], "factor"), flush=True)
             if not same_aux:
                 print("   " + locate(f.aux[:used], aux0[:used], "aux (inverse blocks)"), flush=True)
+            if tracing:
+                print("\n".join(trace_report(read_trace(), trace0)[:12]), flush=True)
     del fs
 print(f"{bad} differing factorizations in {reps} x {nfilms}; {1e3 * (time.perf_counter() - t0) / reps:.0f} ms per repetition",
       flush=True)
