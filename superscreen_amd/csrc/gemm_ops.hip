@@ -344,7 +344,14 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
                     }
                 }
         }
-        __builtin_amdgcn_s_barrier();   // every wave is done reading slot `cur` before it is refilled
+        // Every wave is done reading slot `cur` before it is refilled (the next iteration's issue() writes it): the
+        // reads must have COMPLETED, not just been issued, when a wave arrives here.  s_barrier alone does not wait for
+        // them -- the compiler placed it in front of the `s_waitcnt lgkmcnt(0)` of the last k-step's fragments, and
+        // beside LDS-heavy workgroups of another stream (the finishing passes' transposes next to the rounds) a DMA of
+        // the next stage landed in the slot before a slow wave's read of it had executed: about one factorization in a
+        // hundred of the four-film stack came out different in the 10th digit (round 5, tools/chol_race_hunt.py).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
