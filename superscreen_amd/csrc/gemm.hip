@@ -525,7 +525,11 @@ int gemm_batched_f32(int64_t M, int64_t N, int64_t K, double alpha, const float 
 // ---- a batched product in SLICES: the same tiles as gemm_kernel's two-level batch, launched as many small grids
 // (at most `max_wgs` workgroups each) and with the K range cut into chunks of `kchunk` (a later chunk accumulates
 // onto the earlier ones: the launches of one stream are ordered, and the sum over k runs in the same order as in
-// the unsliced product, so the result is bit-identical).  For work that fills the chip beside latency-critical
+// the unsliced product).  float64: BIT-IDENTICAL to the unsliced product when alpha = +-1 (the tile accumulates onto
+// C in k order, and scaling by +-1 is exact).  float32: NOT bit-identical -- that tile sums its products from zero and
+// adds C once in the epilogue (gemm_tile_full_f32), so every chunk boundary adds one rounding at the magnitude of C:
+// the float32 block inverses depend, to rounding, on whether a finishing pass ran sliced (beside the rounds) or whole
+// (tests/test_kernels_gpu.py::test_cholesky_finishing_passes_sliced_or_whole).  For work that fills the chip beside latency-critical
 // launches of another stream (the finishing passes of the Cholesky schedule beside its single-stream rounds,
 // chol.hip): no launch holds more than max_wgs workgroup slots, and no workgroup lives longer than kchunk / 16
 // LDS stages.  Aligned full tiles only (M, N multiples of 128, K ranges multiples of 32).

@@ -456,6 +456,58 @@ def test_cholesky_schedule_parts_batch_equals_single(K, dtype, tol):
         assert float((got - x).abs().max() / x.abs().max()) < tol
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cholesky_finishing_passes_sliced_or_whole(K, dtype, monkeypatch):
+    """The finishing passes (block inverses, their transposes) go out in SLICES beside the single-stream rounds
+    (gemm.hip: gemm_batched_sliced, K in chunks of 512 accumulated in order) or as whole launches after the last
+    round (chol.hip, CholDebug late=1).  float64: the same bits either way; float32: equal to rounding only (its
+    tile adds C once per launch, so every chunk boundary rounds once more)."""
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sizes = [9000, 8500]        # rounds from the first panel on, two full 4096-blocks final while rounds still run
+
+    def make(n):
+        U = torch.randn(n, 24, dtype=torch.float64, device="cuda", generator=g)
+        S = U @ U.T / 24
+        S.diagonal().add_(2.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
+        return S.to(tdt)
+
+    mats = [make(n) for n in sizes]
+
+    def run():
+        bufs = []
+        for S in mats:
+            n = S.shape[0]
+            npad = K.chol_padded_n(n)
+            t = torch.zeros((npad, K.padded_ld(npad, dtype)), dtype=tdt, device="cuda")
+            t[:n, :n] = torch.tril(S)
+            bufs.append((t, n))
+        out = K.chol_factor_batch(bufs)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.delenv("SSA_CHOL_DEBUG", raising=False)
+    sliced = run()
+    monkeypatch.setenv("SSA_CHOL_DEBUG", "late=1")
+    whole = run()
+    monkeypatch.delenv("SSA_CHOL_DEBUG", raising=False)
+    for S, a, b in zip(mats, sliced, whole):
+        n = S.shape[0]
+        assert a.info == 0 and b.info == 0
+        used = 2 * ((K.chol_padded_n(n) + 4095) // 4096) * 4096 * 4096       # inverse blocks and their transposes
+        assert torch.equal(a.L[:n, :n], b.L[:n, :n])                          # the factor itself never depends on it
+        if dtype == "float64":
+            assert torch.equal(a.aux[:used], b.aux[:used])
+        else:
+            scale = float(b.aux[:used].abs().max())
+            assert float((a.aux[:used] - b.aux[:used]).abs().max()) < 1e-5 * scale
+        x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        rhs = (S.double() @ x).to(tdt)
+        for f in (a, b):
+            got = K.chol_solve(f, rhs.clone()).double()
+            assert float((got - x).abs().max() / x.abs().max()) < (1e-11 if dtype == "float64" else 2e-3)
+
+
 def test_cholesky_full_size_residual(K):
     """BASELINE.json size (n_i = 20 419): S x = b to rounding, by a residual check that needs no
     O(n^3) host work (S = D + U U^T built on the GPU)."""
