@@ -62,7 +62,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # HIP multiplexes a process' streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level; the
 # factorization schedules use two high-priority chain streams per film, so the 4-film stack of config 5 wants 8
-# (DESIGN.md section 9).  An application-level choice: set here, before the HIP runtime starts, not by the package.
+# (DESIGN_HISTORY.md, round 4).  An application-level choice: set here, before the HIP runtime starts, not by the package.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)

@@ -11,7 +11,7 @@ gfx950 behind the C ABI declared in ``include/superscreen_hip.h``.  See DESIGN.m
 # (csrc/chol.hip, lu.hip); a four-film stack factors 3 % faster with GPU_MAX_HW_QUEUES=8 set BEFORE the HIP
 # runtime starts (bench.py does that).  Do NOT go above 8: with 16 or 32 the streams of a four-film factorization
 # take more hardware queues than the chip has queue slots, and every later kernel of the process -- on any stream --
-# runs 20-40 % slower (measured).
+# runs 20-40 % slower (measured, DESIGN_HISTORY.md, round 4).
 
 from .version import __version__  # noqa: F401
 

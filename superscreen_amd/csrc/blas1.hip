@@ -74,13 +74,11 @@ __device__ __forceinline__ void gemv_wave_rows(const T *__restrict__ M, int64_t 
             }
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
-#ifdef SSA_GEMV_NT   // (experiment: the matrix is read once per product -- non-temporal loads)
+                // The matrix is read exactly once per product: non-temporal loads (the lines are not kept for a second use
+                // that never comes).  Same-box A/B, round 5: the 11 passes of a warm config-H solve 20.1-20.3 -> 19.0-19.1 ms.
                 typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
                 const u32x4_nt raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt *>(rowp[r] + c));
                 const V mv = __builtin_bit_cast(V, raw);
-#else
-                const V mv = *reinterpret_cast<const V *>(rowp[r] + c);
-#endif
                 const T *mp = reinterpret_cast<const T *>(&mv);
 #pragma unroll
                 for (int k = 0; k < VN; ++k) acc[r] = fma_t(mp[k], xv[k], acc[r]);

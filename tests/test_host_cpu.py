@@ -165,6 +165,23 @@ def test_no_barrier_with_lds_operations_in_flight():
     assert len(list(isa_lint.lint_disassembly(bad))) == 1 and not list(isa_lint.lint_disassembly(good))
 
 
+def test_final_gate_log_belongs_to_this_tree():
+    """``profiles/r05_final_gate.txt`` is the log of the last full GPU run of the round (``tools/final_gate.sh``: the
+    suite as the driver runs it, smoke(), a driver-style bench).  It records a digest of everything that run
+    depended on; a tree that has moved on since (a kernel edited after the last GPU run -- how round 4 ended red) is
+    reported here as a SKIP with the reason, a log whose run failed as a failure."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import final_gate
+
+    path = os.path.join(ROOT, "profiles", "r05_final_gate.txt")
+    if not os.path.exists(path):
+        pytest.skip("no gate log yet")
+    fields = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+    assert [fields.get(k, "?").strip() for k in ("pytest_gpu_rc", "smoke_rc", "bench_rc")] == ["0", "0", "0"]
+    if fields.get("tree_digest", "").strip() != final_gate.tree_digest():
+        pytest.skip("sources changed since the last full GPU run: run tools/final_gate.sh through gpurun before the round ends")
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
 
