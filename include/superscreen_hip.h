@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 6
+#define SSA_ABI_VERSION 5
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);
@@ -69,14 +69,9 @@ int ssa_device_info(int *num_cus, size_t *hbm_bytes, char *arch_name, int arch_n
  *   C     [n]   f64   edge vector (MeshOperators.C_vector, device/mesh.py:401-432)
  *   Q     [n,ldq] dtype  out (may be NULL: only the diagonal is produced)
  *   qdiag [n]   f64   out, Q_ii in float64 (may be NULL)
- *   workspace   ssa_q_assemble_workspace_bytes(n, dtype) bytes when Q != NULL (one partial row sum per 4 KiB
- *               piece of a row: the dense matrix is written as one-shot pieces, assemble.hip); unused (may be
- *               NULL) when Q == NULL
  */
-size_t ssa_q_assemble_workspace_bytes(int64_t n, int dtype);
 int ssa_q_assemble(const double *xy, const double *w, const double *C, int64_t n, void *Q,
-                   int64_t ldq, int dtype, double *qdiag, void *workspace, size_t workspace_bytes,
-                   void *stream);
+                   int64_t ldq, int dtype, double *qdiag, void *stream);
 
 /*
  * Replaces  _build_system_2d / _build_system_1d  solver/solve_film.py:285-305 together with

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SSA_LIB_PATH") or os.path.join(_PKG, "lib", "libsuper
 
 SSA_F32 = 0
 SSA_F64 = 1
-ABI_VERSION = 6   # SSA_ABI_VERSION of include/superscreen_hip.h
+ABI_VERSION = 5   # SSA_ABI_VERSION of include/superscreen_hip.h
 
 
 class HipLibraryError(RuntimeError):
@@ -32,8 +32,7 @@ SIGNATURES = {
     "ssa_abi_version": (c_int, []),
     "ssa_error_string": (c_char_p, [c_int]),
     "ssa_device_info": (c_int, [P, P, P, c_int]),
-    "ssa_q_assemble_workspace_bytes": (c_size_t, [I64, c_int]),
-    "ssa_q_assemble": (c_int, [P, P, P, I64, P, I64, c_int, P, P, c_size_t, P]),
+    "ssa_q_assemble": (c_int, [P, P, P, I64, P, I64, c_int, P, P]),
     "ssa_system_assemble_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "ssa_system_assemble": (c_int, [P, P, P, P, I64, P, P, P, P, I64, P, I64, c_double, P, c_int,
                                     P, I64, c_int, P, c_size_t, P]),

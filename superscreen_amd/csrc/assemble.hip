@@ -11,10 +11,6 @@
 // diagonal stay in registers (TR per lane) and are reduced once per strip (wave shuffle + one
 // LDS hop), so the diagonal costs no extra pass over memory.  Optional row scaling and
 // lower-tiles-only output serve the Cholesky route (S = diag(w) A, chol.hip).
-#include <stdlib.h>
-
-#include <algorithm>
-
 #include "common.hpp"
 
 namespace ssa {
@@ -134,92 +130,6 @@ __global__ __launch_bounds__(kAsmThreads) void q_assemble_kernel(
         if (qdiag != nullptr) qdiag[i] = d;
         if (WANT_Q) Q[i * ldq + i] = static_cast<OutT>(d);
     }
-}
-
-// ---- Q in ONE-SHOT pieces (round 5) ----------------------------------------------------------------------------
-// The store stream that fills HBM fastest on this chip is neither a persistent grid nor row strips: it is a launch of
-// very many workgroups that each store ONE contiguous 4 KiB piece (one 16-byte store per lane) and retire -- the
-// dispatcher hands the pieces out in address order, every wave's single store is the last thing it does, nothing
-// waits behind a store (tools/probes/store_probe.hip: 6.9 TB/s against 6.4 for hipMemsetAsync, 5.4-5.7 for the
-// strips' shape, same box).  So: workgroup b = piece p of row i (grid: x = piece, y = row; x runs fastest, so
-// consecutive workgroups continue the same row), lane <-> kPieceElems / 256 adjacent columns.  The price is that
-// the column data (x, y, w: 24 B per column) is loaded for every piece instead of once per 24 rows -- from L2, where
-// the 0.6-1.2 MB of vertex data stay -- and that the row sums need a hand-over: every workgroup leaves the sum of its
-// piece in `partial[row][piece]` (summed over lanes, then waves, in a fixed order) and q_diag_from_partials_kernel
-// adds a row's pieces in order and writes Q_ii.  Same arithmetic per entry as the strips.
-template <typename OutT>
-struct Piece {
-    static constexpr int kPerLane = 16 / sizeof(OutT);          // one 16-byte store per lane
-    static constexpr int kElems = kAsmThreads * kPerLane;       // 512 (float64) / 1 024 (float32) columns = 4 KiB
-};
-
-template <typename OutT>
-__global__ __launch_bounds__(kAsmThreads) void q_oneshot_kernel(
-    const double *__restrict__ xy, const double *__restrict__ w, int64_t n, OutT *__restrict__ Q, int64_t ldq,
-    double *__restrict__ partial, int64_t row_base) {
-    constexpr int PL = Piece<OutT>::kPerLane;
-    __shared__ double s_part[kAsmThreads / kWave];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t i = row_base + blockIdx.y;                         // row (workgroup-uniform: scalar loads)
-    const int64_t j0 = static_cast<int64_t>(blockIdx.x) * Piece<OutT>::kElems + static_cast<int64_t>(tid) * PL;
-    const double xi = xy[2 * i], yi = xy[2 * i + 1];
-    double acc = 0.0;
-    OutT out[PL];
-    if (j0 + PL <= n) {                                              // whole lanes: vector loads
-        double xj[PL], yj[PL], wj[PL];
-#pragma unroll
-        for (int k = 0; k < PL; k += 2) {
-            const double2 a = *reinterpret_cast<const double2 *>(xy + 2 * (j0 + k));
-            const double2 b = *reinterpret_cast<const double2 *>(xy + 2 * (j0 + k) + 2);
-            const double2 ww = *reinterpret_cast<const double2 *>(w + j0 + k);
-            xj[k] = a.x; yj[k] = a.y; xj[k + 1] = b.x; yj[k + 1] = b.y;
-            wj[k] = ww.x; wj[k + 1] = ww.y;
-        }
-#pragma unroll
-        for (int k = 0; k < PL; ++k) {
-            const double dx = xi - xj[k], dy = yi - yj[k];
-            double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
-            q = (j0 + k == i) ? 0.0 : q;                             // distance.py:104-105
-            acc = __builtin_fma(q, wj[k], acc);
-            out[k] = static_cast<OutT>(-q);
-        }
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<u32x4 *>(Q + i * ldq + j0) = *reinterpret_cast<const u32x4 *>(out);
-    } else {                                                         // the ragged end of a row
-#pragma unroll
-        for (int k = 0; k < PL; ++k) {
-            const int64_t j = j0 + k;
-            if (j < n) {
-                const double dx = xi - xy[2 * j], dy = yi - xy[2 * j + 1];
-                double q = inv_r3_over_4pi(__builtin_fma(dx, dx, dy * dy));
-                q = (j == i) ? 0.0 : q;
-                acc = __builtin_fma(q, w[j], acc);
-                Q[i * ldq + j] = static_cast<OutT>(-q);
-            }
-        }
-    }
-    const double s = wave_sum(acc);
-    if (lane == 0) s_part[wave] = s;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int v = 0; v < kAsmThreads / kWave; ++v) t += s_part[v];
-        partial[i * gridDim.x + blockIdx.x] = t;
-    }
-}
-
-// Q_ii = (C_i + sum of the row's pieces, in piece order) / w_i   (device/mesh.py:455-457)
-template <typename OutT>
-__global__ void q_diag_from_partials_kernel(const double *__restrict__ partial, int64_t pieces, const double *__restrict__ w,
-                                            const double *__restrict__ C, int64_t n, OutT *__restrict__ Q, int64_t ldq,
-                                            double *__restrict__ qdiag) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double s = sum_strided(partial + i * pieces, static_cast<int>(pieces), int64_t(1));
-    const double d = (C[i] + s) / w[i];
-    if (qdiag != nullptr) qdiag[i] = d;
-    Q[i * ldq + i] = static_cast<OutT>(d);
 }
 
 // Number of workgroups for n rows: a whole number of rounds of kQGroupsPerCu workgroups per CU (every CU then holds
@@ -367,55 +277,13 @@ __global__ __launch_bounds__(kAsmThreads) void system_assemble_kernel(
 
 using namespace ssa;
 
-namespace ssa {
-namespace {
-template <typename OutT>
-int64_t q_pieces(int64_t n) { return ceil_div(n, static_cast<int64_t>(Piece<OutT>::kElems)); }
-
-template <typename OutT>
-int q_assemble_oneshot(const double *xy, const double *w, const double *C, int64_t n, OutT *Q, int64_t ldq, double *qdiag,
-                       double *partial, hipStream_t st) {
-    const int64_t pieces = q_pieces<OutT>(n);
-    for (int64_t r0 = 0; r0 < n; r0 += 65535) {   // (grid y is a 16-bit count)
-        const int64_t rows = std::min<int64_t>(65535, n - r0);
-        hipLaunchKernelGGL((q_oneshot_kernel<OutT>), dim3(static_cast<unsigned>(pieces), static_cast<unsigned>(rows)),
-                           dim3(kAsmThreads), 0, st, xy, w, n, Q, ldq, partial, r0);
-        SSA_RETURN_IF_LAUNCH_FAILED();
-    }
-    hipLaunchKernelGGL((q_diag_from_partials_kernel<OutT>), dim3(static_cast<unsigned>(ceil_div(n, 256))), dim3(256), 0, st,
-                       partial, pieces, w, C, n, Q, ldq, qdiag);
-    SSA_RETURN_IF_LAUNCH_FAILED();
-    return SSA_OK;
-}
-}  // namespace
-}  // namespace ssa
-
-// Workspace of ssa_q_assemble when Q is wanted: one partial row sum per (row, 4 KiB piece of the row).
-extern "C" size_t ssa_q_assemble_workspace_bytes(int64_t n, int dtype) {
-    if (n <= 0) return 0;
-    const int64_t pieces = (dtype == SSA_F64) ? q_pieces<double>(n) : q_pieces<float>(n);
-    return static_cast<size_t>(n) * static_cast<size_t>(pieces) * sizeof(double) + 256;
-}
-
 extern "C" int ssa_q_assemble(const double *xy, const double *w, const double *C, int64_t n,
-                              void *Q, int64_t ldq, int dtype, double *qdiag, void *workspace, size_t workspace_bytes,
-                              void *stream) {
+                              void *Q, int64_t ldq, int dtype, double *qdiag, void *stream) {
     if (n <= 0 || !xy || !w || !C) return SSA_ERR_INVALID_ARGUMENT;
     if (Q && (ldq < n || (ldq & 1))) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
-    hipStream_t st = as_stream(stream);
-    // The dense matrix: one-shot pieces (16-byte stores need a 16-byte aligned leading dimension; the host layer pads
-    // to 128 bytes).  SSA_Q_FORM=strips keeps the strip form for comparisons (tools/q_form_timing.py).
-    const char *form = getenv("SSA_Q_FORM");
-    const bool strips = (form != nullptr && form[0] == 's') || (ldq * (dtype == SSA_F64 ? 8 : 4)) % 16 != 0 ||
-                        reinterpret_cast<uintptr_t>(Q) % 16 != 0;
-    if (Q && !strips) {
-        if (!workspace || workspace_bytes < ssa_q_assemble_workspace_bytes(n, dtype)) return SSA_ERR_WORKSPACE_TOO_SMALL;
-        double *partial = static_cast<double *>(workspace);
-        if (dtype == SSA_F64) return q_assemble_oneshot<double>(xy, w, C, n, static_cast<double *>(Q), ldq, qdiag, partial, st);
-        return q_assemble_oneshot<float>(xy, w, C, n, static_cast<float *>(Q), ldq, qdiag, partial, st);
-    }
     const dim3 grid(static_cast<unsigned>(balanced_groups(n, kQStripRows)));
+    hipStream_t st = as_stream(stream);
     // (the row-sum-only form -- Q == nullptr: the factorizations need only the diagonal -- is its own instantiation:
     // no store code in the sweep)
     if (dtype == SSA_F64) {

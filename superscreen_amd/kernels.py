@@ -54,10 +54,8 @@ def q_assemble(xy: torch.Tensor, w: torch.Tensor, C: torch.Tensor, dtype, *,
     if want_Q:
         ldq = ld or padded_ld(n, dtype)
         Q = out if out is not None else torch.empty((n, ldq), dtype=_tdtype(dtype), device=xy.device)
-    nbytes = lib.ssa_q_assemble_workspace_bytes(n, dtype_code(dtype)) if want_Q else 0
-    ws = _ws(nbytes, xy.device) if want_Q else None
     check(lib.ssa_q_assemble(ptr(xy), ptr(w), ptr(C), n, ptr(Q), ldq, dtype_code(dtype),
-                             ptr(qdiag), ptr(ws), nbytes, current_stream()), "ssa_q_assemble")
+                             ptr(qdiag), current_stream()), "ssa_q_assemble")
     return Q, qdiag
 
 

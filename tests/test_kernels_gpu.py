@@ -598,9 +598,9 @@ def test_c_abi_error_codes():
     st = torch.cuda.current_stream().cuda_stream
     INVALID, TOO_SMALL = -1, -3
     # null pointer, non-positive size, bad dtype
-    assert lib.ssa_q_assemble(None, P(w), P(w), n, None, 0, 1, P(out), None, 0, st) == INVALID
-    assert lib.ssa_q_assemble(P(xy), P(w), P(w), 0, None, 0, 1, P(out), None, 0, st) == INVALID
-    assert lib.ssa_q_assemble(P(xy), P(w), P(w), n, None, 0, 7, P(out), None, 0, st) == INVALID
+    assert lib.ssa_q_assemble(None, P(w), P(w), n, None, 0, 1, P(out), st) == INVALID
+    assert lib.ssa_q_assemble(P(xy), P(w), P(w), 0, None, 0, 1, P(out), st) == INVALID
+    assert lib.ssa_q_assemble(P(xy), P(w), P(w), n, None, 0, 7, P(out), st) == INVALID
     assert lib.ssa_gemv(None, n, n, n, P(w), None, None, P(out), 1.0, 0.0, 1, st) == INVALID
     assert lib.ssa_gemm(n, n, n, 1.0, P(xy), 1, P(xy), n, 0.0, P(out), n, 1, st) == INVALID      # lda < K
     # factor / solve entry points

@@ -355,18 +355,12 @@ int main(int argc, char **argv) {
     const double fill = time_ms([&] { hipMemsetAsync(Q, 0, static_cast<size_t>(n) * ld * 8, 0); });
     printf("hipMemsetAsync: %.3f ms %.0f GB/s\n", fill, static_cast<double>(n) * ld * 8 / 1e9 / fill * 1e3);
     // the library's own kernel through the C ABI, on the same buffers
-    typedef int (*q_fn)(const double *, const double *, const double *, int64_t, void *, int64_t, int, double *, void *,
-                        size_t, void *);
-    typedef size_t (*ws_fn)(int64_t, int);
+    typedef int (*q_fn)(const double *, const double *, const double *, int64_t, void *, int64_t, int, double *, void *);
     void *lib = dlopen("superscreen_amd/lib/libsuperscreen_hip.so", RTLD_NOW);
     q_fn q_assemble = lib ? reinterpret_cast<q_fn>(dlsym(lib, "ssa_q_assemble")) : nullptr;
-    ws_fn q_ws = lib ? reinterpret_cast<ws_fn>(dlsym(lib, "ssa_q_assemble_workspace_bytes")) : nullptr;
-    if (q_assemble && q_ws) {
-        const size_t ws_bytes = q_ws(n, 1);
-        void *ws = nullptr;
-        hipMalloc(&ws, ws_bytes);
+    if (q_assemble) {
         for (int rep = 0; rep < 3; ++rep) {
-            const double ms = time_ms([&] { q_assemble(xy, w, w, n, Q, ld, 1, rs, ws, ws_bytes, nullptr); });
+            const double ms = time_ms([&] { q_assemble(xy, w, w, n, Q, ld, 1, rs, nullptr); });
             printf("library ssa_q_assemble (float64, ld=%lld): %7.3f ms  %6.0f GB/s\n", static_cast<long long>(ld), ms,
                    static_cast<double>(n) * n * 8 / 1e9 / ms * 1e3);
             run<FULL, 24, 2, true, 1>("probe copy of it", xy, w, n, Q, ld, rs, 5, 0);
