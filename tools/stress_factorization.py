@@ -132,4 +132,5 @@ if "mix" in wanted:
     print(f"mix: {nmix} x (cholesky f64, cholesky f32, lu f64, lu f32) interleaved: "
           f"{'ALL bit-identical' if not bad else str(bad) + ' DIFFERENT'}", flush=True)
 print(f"{failed} differing runs in all", flush=True)
-sys.exit(1 if failed else 0)
+sys.stdout.flush()
+os._exit(1 if failed else 0)   # (not sys.exit: the disturber thread is still launching work)
