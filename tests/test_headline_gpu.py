@@ -267,6 +267,8 @@ def test_four_film_stack_vs_oracle(sc):
             assert relerr(fs.self_field, ref[nm].self_field) < 1e-9, (it, nm)
             if it:
                 assert relerr(fs.field_from_other_films, ref[nm].field_from_other_films) < 1e-9, (it, nm)
+    # fluxoids of every film and iterate (washers: around their hole with its circulating current)
+    assert _fluxoid_parity(sc, device, K, sols, films, trace, tol=1e-9, hole_entry=False) < 1e-9
 
 
 # ------------------------------------------------------------------------------------------------
@@ -343,7 +345,7 @@ def test_configH_full_size_vs_oracle(sc):
           f"over {iters + 1} iterates")
 
 
-def _fluxoid_parity(sc, device, K, sols, films, trace, tol):
+def _fluxoid_parity(sc, device, K, sols, films, trace, tol, hole_entry=True):
     from superscreen_amd import synthetic
 
     _, _, dr = synthetic.ring_disk_mesh(K)
@@ -359,7 +361,9 @@ def _fluxoid_parity(sc, device, K, sols, films, trace, tol):
             err = max(abs(got.flux_part - want[0]), abs(got.supercurrent_part - want[1])) / scale
             worst = max(worst, err)
             assert err < tol, (it, nm, tuple(got), want)
-    # the hole's own entry point, in Phi_0 (solution.py:565-609), last iterate
+    if not hole_entry:
+        return worst
+    # the hole's own entry point, in Phi_0 (solution.py:565-609), last iterate (first film = the washer with the hole)
     hole = next(iter(device.holes))
     film_of_hole = next(f for f, nm in zip(films, device.films) if nm == list(device.films)[0])
     fq = sols[-1].hole_fluxoid(hole, points=ring)
