@@ -31,7 +31,8 @@ def pytest_configure(config):
 #   2  oracle comparisons at headline sizes (configs 3/H, config 4's 64-field sweep, the 4-film stack)
 #   3  full-size properties (configs 2, 3, H, 5)
 _FULL_SIZE_PROPERTIES = ("test_full_size_london_system", "test_full_size_float32_and_lu_routes_agree_with_float64",
-                         "test_system_assemble_sampled_rows_at_full_size")
+                         "test_system_assemble_sampled_rows_at_full_size",
+                         "test_cold_factorizations_bit_identical_beside_other_work")
 
 
 # BASELINE config 1 (the 2 107-vertex disk) and config 4 (64 applied fields) are cheap: they go first of all

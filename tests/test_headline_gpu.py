@@ -271,6 +271,71 @@ def test_four_film_stack_vs_oracle(sc):
     assert _fluxoid_parity(sc, device, K, sols, films, trace, tol=1e-9, hole_entry=False) < 1e-9
 
 
+def test_cold_factorizations_bit_identical_beside_other_work(sc):
+    """Config 5's stack (4 x 24 571 unknowns: the only benchmark device whose schedule runs update streams of its own,
+    rounds and sliced finishing passes all in one factorization), factored cold a dozen times WHILE a second stream
+    keeps the chip's LDS and memory pipes busy with transposes: every factor buffer and every block inverse must come
+    out with the first run's bits.  (Round 4 ended on a result that depended on such company: an LDS read still in
+    flight at a hand-rolled barrier, 1.5 % of these factorizations.  The static check is
+    tests/test_host_cpu.py::test_no_barrier_with_lds_operations_in_flight; this is the run-time side,
+    tools/chol_race_hunt.py the tool that locates a difference.)"""
+    import threading
+
+    from superscreen_amd import kernels, synthetic
+    from superscreen_amd.solver import FilmDeviceData, make_film_info
+
+    device = synthetic.make_stack_device(100, ("disk",) * 4, z_spacing=0.5, solve_dtype="float64")
+    names = list(device.films)
+    info = make_film_info(device=device, vortices=[], circulating_currents={}, terminal_currents={})
+    fds = {nm: FilmDeviceData(info[nm], device.meshes[nm], device.solve_dtype, False) for nm in names}
+    ix = {nm: torch.from_numpy(info[nm].interior_indices.astype(np.int64)).cuda() for nm in names}
+
+    def factor_all():
+        systems = []
+        for nm in names:
+            fd, ni = fds[nm], len(info[nm].interior_indices)
+            npad = kernels.chol_padded_n(ni)
+            S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix[nm], ix[nm], sign=1.0,
+                                        dtype="float64", row_scale=fd.w, lower_only=True,
+                                        ld=kernels.padded_ld(npad, "float64"), alloc_rows=npad)
+            systems.append((S, ni))
+        out = kernels.chol_factor_batch(systems)
+        torch.cuda.synchronize()
+        return out
+
+    stop = threading.Event()
+
+    def disturb():
+        torch.cuda.set_device(0)
+        side = torch.cuda.Stream()
+        x = torch.randn(8192, 8192, dtype=torch.float64, device="cuda")
+        pending = []
+        while not stop.is_set():
+            with torch.cuda.stream(side):
+                y = x.t().contiguous()   # noqa: F841
+                e = torch.cuda.Event()
+                e.record(side)
+            pending.append(e)
+            if len(pending) > 3:
+                pending.pop(0).synchronize()
+        side.synchronize()
+
+    ref = factor_all()
+    assert all(f.info == 0 for f in ref)
+    thread = threading.Thread(target=disturb, daemon=True)
+    thread.start()
+    try:
+        for rep in range(12):
+            for i, (f, r) in enumerate(zip(factor_all(), ref)):
+                n = f.n
+                used = 2 * ((kernels.chol_padded_n(n) + 4095) // 4096) * 4096 * 4096      # inverse blocks + transposes
+                assert torch.equal(f.L[:n, :n], r.L[:n, :n]), (rep, names[i], "factor")
+                assert torch.equal(f.aux[:used], r.aux[:used]), (rep, names[i], "block inverses")
+    finally:
+        stop.set()
+        thread.join(timeout=30)
+
+
 # ------------------------------------------------------------------------------------------------
 # (e) the north_star's acceptance number at its own size: config H against the oracle
 # ------------------------------------------------------------------------------------------------
