@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void transpose_lower_kernel(const T *src, int6
 struct CholLane {
     hipStream_t side = nullptr, finish = nullptr, upd = nullptr;
     hipEvent_t ev_strip = nullptr, ev_panel = nullptr, ev_fork = nullptr, ev_finish = nullptr, ev_syrk = nullptr,
-               ev_upd = nullptr;
+               ev_syrk2 = nullptr, ev_upd = nullptr;   // ev_syrk / ev_syrk2: the last two trailing updates, alternating
 };
 constexpr int kMaxLanes = 16;
 
@@ -299,6 +299,7 @@ inline int get_lanes(int count, hipStream_t st, LaneSet **out) {
             hipEventCreateWithFlags(&lanes[i].ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_syrk, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&lanes[i].ev_syrk2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&lanes[i].ev_finish, hipEventDisableTiming) != hipSuccess)
             return SSA_ERR_HIP;
     }
@@ -325,7 +326,7 @@ inline int destroy_lanes() {
         for (CholLane &ln : set.lanes) {
             if (ln.finish == nullptr) continue;
             if (hipStreamSynchronize(ln.finish) != hipSuccess || hipStreamSynchronize(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
-            hipEvent_t evs[6] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk, ln.ev_upd};
+            hipEvent_t evs[7] = {ln.ev_strip, ln.ev_panel, ln.ev_fork, ln.ev_finish, ln.ev_syrk, ln.ev_syrk2, ln.ev_upd};
             for (hipEvent_t e : evs)
                 if (e != nullptr && hipEventDestroy(e) != hipSuccess) rc = SSA_ERR_HIP;
             if (hipStreamDestroy(ln.finish) != hipSuccess || hipStreamDestroy(ln.upd) != hipSuccess) rc = SSA_ERR_HIP;
@@ -507,11 +508,12 @@ struct FinishPlan {
 //   delay=0     every trailing update applies ONE panel (K = 256)
 //   sync=1      the host waits for the device after every outer step (serialises the streams: no overlap at all)
 //   excl=0      round launches never ask for a CU per workgroup
+//   look=D      look-ahead depth of the stream part in block columns (default: 3 for a single matrix, else 1)
 //   trace=1     every diagonal-block workgroup of a round stores the block AS IT READ IT (register images, 272 KB);
 //               after the schedule the host waits and writes all of them to the file SSA_CHOL_TRACE_FILE:
 //               [matrix][panel][34 816] float64 (float64 matrices only)
 struct CholDebug {
-    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0;
+    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0;
     int64_t tail = -1;
 };
 inline CholDebug chol_debug() {
@@ -534,6 +536,7 @@ inline CholDebug chol_debug() {
             else if (key == "delay") d.delay = static_cast<int>(val);
             else if (key == "sync") d.sync = static_cast<int>(val);
             else if (key == "excl") d.excl = static_cast<int>(val);
+            else if (key == "look") d.look = static_cast<int>(val);
             else if (key == "trace") d.trace = static_cast<int>(val);
         }
         pos = end + 1;
@@ -638,9 +641,28 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (hipEventRecord(ln.ev_panel, ln.side) != hipSuccess) return SSA_ERR_HIP;
     }
     bool detached[kMaxLanes] = {};
-    bool updated[kMaxLanes] = {};      // a trailing update of this matrix has been issued (ev_syrk is recorded)
     bool on_finish[kMaxLanes] = {};    // finishing steps of this matrix have gone to its low-priority stream
+    // State of the stream part, per matrix.  The trailing updates maintain the region T = A[tstart:, tstart:]: every
+    // panel before pending_from has been applied to it.  Block columns between the panel being factored and tstart are
+    // LOOK-AHEAD columns: they left T when an update was issued that no longer covered them, with the panels before
+    // col_from[] applied, and take the rest from the chain's block-column product when their turn comes.
+    //   look = 1: an update covers everything right of the panel being factored; the chain's next block-column
+    //             product waits for the update issued a step earlier (two or more matrices fill that wait with each
+    //             other's updates);
+    //   look = 3: an update leaves the next TWO block columns to the chain (K = 768 / 1 024 products there instead
+    //             of 256 / 512): the chain's products then wait for the update BEFORE the running one, i.e. never,
+    //             and a single matrix' updates follow each other without the gap of two chain steps (round 5).
+    // In float64 the factor does not depend on `look`, bit for bit: every tile still takes its panels in ascending order.
+    const int look = dbg.look > 0 ? dbg.look : (count == 1 ? 3 : 1);
+    constexpr int kColRing = 8;
     int64_t pending_from[kMaxLanes] = {};
+    int64_t tstart[kMaxLanes];
+    int64_t col_from[kMaxLanes][kColRing] = {};
+    int col_writer[kMaxLanes][kColRing] = {};   // index of the last trailing update that covered the column (-1: none)
+    int n_syrk[kMaxLanes] = {};                 // trailing updates issued so far; update k records ev_syrk / ev_syrk2 by k & 1
+    for (int i = 0; i < count; ++i) tstart[i] = CNB;
+    auto slot = [](int64_t col) { return static_cast<int>((col / CNB) % kColRing); };
+    auto syrk_event = [&](int i, int k) { return (k & 1) ? lanes[i].ev_syrk2 : lanes[i].ev_syrk; };
     // trailing updates of a large trailing matrix are applied two panels at a time (K = 512): the C tiles
     // are then read and written once per 32 LDS stages instead of 16 (50 -> 63 TFLOP/s per launch,
     // tools/probes/syrk_k_probe.py); deeper (K = 768, 1024) leaves too little between the chains' products
@@ -682,10 +704,22 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                                         hipStreamWaitEvent(st, ln.ev_upd, 0) != hipSuccess))
                     return SSA_ERR_HIP;
                 cur_us[i] = st;
-                const int64_t upd0 = pending_from[i], right = J.n - c;
+                const int64_t right = J.n - c;
+                const int64_t upd0 = (c >= tstart[i]) ? pending_from[i] : col_from[i][slot(c)];
                 const T *P = J.A + c * J.lda + upd0;
                 strips[ns++] = SmallNtJob{P, P, nullptr, J.A + c * J.lda + c, J.lda, J.lda, J.lda, right, CNB, c - upd0,
                                           -1.0, 1.0, 0};
+                // look-ahead columns right of c catch up with the region the updates maintained: from here on
+                // A[c + 256:, c + 256:] is one trailing matrix again, every panel before pending_from applied
+                for (int64_t b = c + CNB; b < tstart[i] && b < J.n; b += CNB) {
+                    const int64_t f = col_from[i][slot(b)];
+                    if (f >= pending_from[i]) continue;
+                    const T *Pb = J.A + b * J.lda + f;
+                    const SmallNtJob job{Pb, Pb, nullptr, J.A + b * J.lda + b, J.lda, J.lda, J.lda, J.n - b, CNB,
+                                         pending_from[i] - f, -1.0, 1.0, 0};
+                    rc = small_batch_t(static_cast<const T *>(nullptr), 1, &job, st);
+                    if (rc != SSA_OK) return rc;
+                }
             }
             rc = small_batch_t(static_cast<const T *>(nullptr), ns, strips, st);
             if (rc != SSA_OK) return rc;
@@ -766,9 +800,13 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             hipStream_t us = cur_us[i];                       // where this matrix' trailing updates run
             hipStream_t cs = ln.side;                         // the matrix' panel chain
             const int64_t nw = (right < CNB) ? right : CNB;   // width of the next panel
-            // panels that the trailing matrix has not seen yet: everything after the last trailing update
+            // panels that the trailing region has not seen yet: everything after the last trailing update; the block
+            // column of this step may have left that region earlier (look-ahead column) and then needs more
             const int64_t upd0 = pending_from[i], kp = c - upd0;
-            const T *P = J.A + c * J.lda + upd0;              // those panels, from the next diagonal block down
+            const bool in_T = c >= tstart[i];
+            const int64_t col0 = in_T ? upd0 : col_from[i][slot(c)];
+            const int writer = in_T ? n_syrk[i] - 1 : col_writer[i][slot(c)];   // the last update that wrote this column
+            const T *P = J.A + c * J.lda + col0;              // the column's pending panels, from its diagonal block down
             T *C = J.A + c * J.lda + c;
             // every other panel of a large trailing matrix keeps its update pending: the next one then
             // runs with K = 512, i.e. half the C-tile traffic per flop (50 -> 63 TFLOP/s per launch)
@@ -779,10 +817,11 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             const bool delay = kp < kDelayDepth * CNB && right > kDelayMinCols &&
                                ((k0 + J.n) / CNB) % kDelayDepth != kDelayDepth - 1;
             if (hipStreamWaitEvent(us, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;  // panel k done
-            // the chain: pending panels onto the next block column (behind the last trailing update of THIS matrix,
-            // which wrote that column), diagonal-block kernel, the panel below it
-            if (updated[i] && hipStreamWaitEvent(cs, ln.ev_syrk, 0) != hipSuccess) return SSA_ERR_HIP;
-            rc = gemm_op_t(0, 1, 0, right, nw, kp, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, cs);
+            // the chain: pending panels onto the next block column (behind the last trailing update of THIS matrix
+            // that wrote that column; updates of one matrix run in order on one stream, so waiting for a later one
+            // than necessary is safe), diagonal-block kernel, the panel below it
+            if (writer >= 0 && hipStreamWaitEvent(cs, syrk_event(i, writer), 0) != hipSuccess) return SSA_ERR_HIP;
+            rc = gemm_op_t(0, 1, 0, right, nw, c - col0, -1.0, P, J.lda, P, J.lda, 1.0, C, J.lda, cs);
             if (rc != SSA_OK) return rc;
             rc = chol_panel_diag(J, c, cs);
             if (rc != SSA_OK) return rc;
@@ -791,15 +830,27 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 if (rc != SSA_OK) return rc;
             }
             if (hipEventRecord(ln.ev_panel, cs) != hipSuccess) return SSA_ERR_HIP;
-            if (right > nw && !delay) {  // rest of the trailing update: lower tiles behind the next panel's block column
-                const int64_t rstart = c + nw, M = J.n - rstart;
-                const T *P2 = J.A + rstart * J.lda + upd0;
-                rc = gemm_op_t(0, 1, 1, M, M, kp, -1.0, P2, J.lda, P2, J.lda, 1.0, J.A + rstart * (J.lda + 1), J.lda, us);
-                if (rc != SSA_OK) return rc;
-                if (hipEventRecord(ln.ev_syrk, us) != hipSuccess) return SSA_ERR_HIP;
-                updated[i] = true;
+            if (tstart[i] < c + nw) tstart[i] = c + nw;       // (this column is no longer part of the trailing region)
+            if (right > nw && !delay) {
+                // rest of the trailing update: the lower tiles behind the look-ahead columns.  Columns that leave the
+                // region now have seen the panels before upd0, written last by the update before this one.
+                const int64_t rstart = std::max(tstart[i], std::min(J.n, c + static_cast<int64_t>(look) * CNB));
+                for (int64_t b = tstart[i]; b < rstart; b += CNB) {
+                    col_from[i][slot(b)] = upd0;
+                    col_writer[i][slot(b)] = n_syrk[i] - 1;
+                }
+                tstart[i] = rstart;
+                const int64_t M = J.n - rstart;
+                if (M > 0) {
+                    const T *P2 = J.A + rstart * J.lda + upd0;
+                    rc = gemm_op_t(0, 1, 1, M, M, kp, -1.0, P2, J.lda, P2, J.lda, 1.0, J.A + rstart * (J.lda + 1), J.lda, us);
+                    if (rc != SSA_OK) return rc;
+                    if (hipEventRecord(syrk_event(i, n_syrk[i]), us) != hipSuccess) return SSA_ERR_HIP;
+                    ++n_syrk[i];
+                    pending_from[i] = c;
+                }
+                // (M == 0: nothing is left behind the look-ahead columns; they take their panels from the chain alone)
             }
-            if (!delay) pending_from[i] = c;
             // the solve-phase data of the SNB blocks that have become final (all their columns lie left of c): whole
             // launches on the matrix' low-priority stream, behind the chain (beside the rounds they go out in slices)
             FinishPlan<T> &fp = plans[i];

@@ -508,6 +508,51 @@ def test_cholesky_finishing_passes_sliced_or_whole(K, dtype, monkeypatch):
             assert float((got - x).abs().max() / x.abs().max()) < (1e-11 if dtype == "float64" else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cholesky_lookahead_depth_does_not_change_the_factor(K, dtype, monkeypatch):
+    """A single matrix is factored with a look-ahead of three block columns in the stream part of the schedule (the
+    trailing updates leave the next two block columns to the panel chain, chol.hip ``look``), several matrices with
+    one.  Every tile still takes its panels in ascending order, so in float64 the factor and the block inverses are
+    the same bits for every depth -- with rounds (the look-ahead columns catch up at the switch) and without (the
+    trailing region runs out before the columns do); float32 to rounding."""
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = 17000
+    U = torch.randn(n, 24, dtype=torch.float64, device="cuda", generator=g)
+    S = U @ U.T / 24
+    S.diagonal().add_(2.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
+    S = S.to(tdt)
+
+    def run(debug):
+        if debug:
+            monkeypatch.setenv("SSA_CHOL_DEBUG", debug)
+        else:
+            monkeypatch.delenv("SSA_CHOL_DEBUG", raising=False)
+        npad = K.chol_padded_n(n)
+        t = torch.zeros((npad, K.padded_ld(npad, dtype)), dtype=tdt, device="cuda")
+        t[:n, :n] = torch.tril(S)
+        f = K.chol_factor(t, n)
+        torch.cuda.synchronize()
+        assert f.info == 0
+        return f
+
+    used = 2 * ((K.chol_padded_n(n) + 4095) // 4096) * 4096 * 4096
+    for tail in ("", "tail=0"):
+        ref = run(",".join(x for x in ("look=1", tail) if x))
+        for look in ("", "look=2", "look=3", "look=5"):          # ("" = the default: 3 for a single matrix)
+            f = run(",".join(x for x in (look, tail) if x))
+            if dtype == "float64":
+                assert torch.equal(f.L[:n, :n], ref.L[:n, :n]), (tail, look)
+                assert torch.equal(f.aux[:used], ref.aux[:used]), (tail, look)
+            else:
+                scale = float(ref.L[:n, :n].abs().max())
+                assert float((f.L[:n, :n] - ref.L[:n, :n]).abs().max()) < 1e-5 * scale, (tail, look)
+    monkeypatch.delenv("SSA_CHOL_DEBUG", raising=False)
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    got = K.chol_solve(run(""), (S.double() @ x).to(tdt)).double()
+    assert float((got - x).abs().max() / x.abs().max()) < (1e-11 if dtype == "float64" else 2e-3)
+
+
 def test_cholesky_full_size_residual(K):
     """BASELINE.json size (n_i = 20 419): S x = b to rounding, by a residual check that needs no
     O(n^3) host work (S = D + U U^T built on the GPU)."""
