@@ -79,7 +79,10 @@ def main():
 
     from superscreen_amd import kernels as K
 
+    # both profiler passes first: they are child processes, and a process that has initialised the GPU must not start
+    # other programs on this pool
     d1, line1 = rocprof("trace", ["--kernel-trace"])
+    d2, _ = rocprof("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace"])
     rows = last_factorization(find(d1, "kernel_trace.csv"))
     syrk = [r for r in rows if NEEDLE in r["Kernel_Name"]]
     t0 = rows[0]["s"]
@@ -127,7 +130,6 @@ def main():
         f"alone {tal / 1e3:.2f} ms = {fl / tal / 1e6:.1f} TFLOP/s = {fl / tal / 1e6 / PEAK_F32:.3f}; ratio {tin / tal:.3f}")
     say(f"the rest of the factorization (chains not hidden, rounds, finishing): {(t1 - t0) / 1e6 - tin / 1e3:.2f} ms of {(t1 - t0) / 1e6:.2f}")
 
-    d2, _ = rocprof("mfma", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace"])
     per = {}
     for r in csv.DictReader(open(find(d2, "counter_collection.csv"))):
         if NEEDLE in r["Kernel_Name"]:
