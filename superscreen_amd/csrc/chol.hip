@@ -508,12 +508,13 @@ struct FinishPlan {
 //   delay=0     every trailing update applies ONE panel (K = 256)
 //   sync=1      the host waits for the device after every outer step (serialises the streams: no overlap at all)
 //   excl=0      round launches never ask for a CU per workgroup
+//   early=0     no finishing passes during the STREAM part (the blocks that become final there wait for the rounds)
 //   look=D      look-ahead depth of the stream part in block columns (default: 3 for a single matrix, else 1)
 //   trace=1     every diagonal-block workgroup of a round stores the block AS IT READ IT (register images, 272 KB);
 //               after the schedule the host waits and writes all of them to the file SSA_CHOL_TRACE_FILE:
 //               [matrix][panel][34 816] float64 (float64 matrices only)
 struct CholDebug {
-    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0;
+    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0, early = 1;
     int64_t tail = -1;
 };
 inline CholDebug chol_debug() {
@@ -537,6 +538,7 @@ inline CholDebug chol_debug() {
             else if (key == "sync") d.sync = static_cast<int>(val);
             else if (key == "excl") d.excl = static_cast<int>(val);
             else if (key == "look") d.look = static_cast<int>(val);
+            else if (key == "early") d.early = static_cast<int>(val);
             else if (key == "trace") d.trace = static_cast<int>(val);
         }
         pos = end + 1;
@@ -854,7 +856,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             // the solve-phase data of the SNB blocks that have become final (all their columns lie left of c): whole
             // launches on the matrix' low-priority stream, behind the chain (beside the rounds they go out in slices)
             FinishPlan<T> &fp = plans[i];
-            if (!dbg.late && c / SNB > fp.done && fp.done < fp.nfull()) {
+            if (!dbg.late && dbg.early && c / SNB > fp.done && fp.done < fp.nfull()) {
                 if (hipStreamWaitEvent(ln.finish, ln.ev_panel, 0) != hipSuccess) return SSA_ERR_HIP;
                 rc = fp.run_blocks(c / SNB, false, ln.finish);
                 if (rc != SSA_OK) return rc;
