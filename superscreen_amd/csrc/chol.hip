@@ -171,13 +171,11 @@ inline int gemm_sliced_t(int64_t M, int64_t N, int64_t K, double alpha, const fl
     return gemm_batched_sliced_f32(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, b1, b2, strides, tri, kSliceK, kSliceWgs, st);
 }
 
-inline int small_batch_t(const double *, int n, const SmallNtJob *jobs, hipStream_t st, int nt = 0,
-                         const TailTileJob *tiles = nullptr) {
-    return gemm_nt_small_batch_f64(n, jobs, st, nt, tiles);
+inline int small_batch_t(const double *, int n, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch_f64(n, jobs, st);
 }
-inline int small_batch_t(const float *, int n, const SmallNtJob *jobs, hipStream_t st, int nt = 0,
-                         const TailTileJob *tiles = nullptr) {
-    return gemm_nt_small_batch_f32(n, jobs, st, nt, tiles);
+inline int small_batch_t(const float *, int n, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch_f32(n, jobs, st);
 }
 inline int tail_round_t(const double *, int n, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
     return chol_tail_round_f64(n, jobs, exclusive, st);
@@ -511,13 +509,12 @@ struct FinishPlan {
 //   sync=1      the host waits for the device after every outer step (serialises the streams: no overlap at all)
 //   excl=0      round launches never ask for a CU per workgroup
 //   early=0     no finishing passes during the STREAM part (the blocks that become final there wait for the rounds)
-//   spread=N    update-bound rounds: N update tiles ride in the panel launch and N in the strip launch (default 512; 0: none)
 //   look=D      look-ahead depth of the stream part in block columns (default: 3 for a single matrix, else 1)
 //   trace=1     every diagonal-block workgroup of a round stores the block AS IT READ IT (register images, 272 KB);
 //               after the schedule the host waits and writes all of them to the file SSA_CHOL_TRACE_FILE:
 //               [matrix][panel][34 816] float64 (float64 matrices only)
 struct CholDebug {
-    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0, early = 1, spread = -1;
+    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0, early = 1;
     int64_t tail = -1;
 };
 inline CholDebug chol_debug() {
@@ -542,7 +539,6 @@ inline CholDebug chol_debug() {
             else if (key == "excl") d.excl = static_cast<int>(val);
             else if (key == "look") d.look = static_cast<int>(val);
             else if (key == "early") d.early = static_cast<int>(val);
-            else if (key == "spread") d.spread = static_cast<int>(val);
             else if (key == "trace") d.trace = static_cast<int>(val);
         }
         pos = end + 1;
@@ -772,35 +768,11 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 sj[np] = SmallNtJob{A21, A21, nullptr, A21 + CNB, J.lda, J.lda, J.lda, below, CNB, CNB, -1.0, 1.0, 0};
                 ++np;
             }
-            // Update-bound rounds: the panel and strip launches are short (40-60 us each) and would leave the chip to
-            // themselves.  Part of the update's tiles rides in them instead of in the round launch: any tile but those
-            // of the two leftmost tile columns (the next panel's block column, which the strip launch updates again:
-            // they stay in the round launch, first in its order).  A tile still takes its panels in the same order.
-            TailTileJob tp[kMaxLanes], ts[kMaxLanes];
-            int nt = 0;
-            {
-                const int64_t per_launch = dbg.spread >= 0 ? dbg.spread : 512;
-                int64_t rest_total = 0;
-                for (int q = 0; q < nr; ++q) rest_total += round_tiles_total(rj[q].M) - round_tiles_first_columns(rj[q].M);
-                if (per_launch > 0 && rest_total >= 3 * per_launch) {
-                    for (int q = 0; q < nr; ++q) {
-                        TailRoundJob &r = rj[q];
-                        const int64_t all = round_tiles_total(r.M), rest = all - round_tiles_first_columns(r.M);
-                        const int64_t share = per_launch * rest / rest_total;
-                        if (share <= 0) continue;
-                        r.tile_first = 0;
-                        r.tile_count = all - 2 * share;
-                        tp[nt] = TailTileJob{r.C, r.P, r.ldc, r.M, r.K, all - 2 * share, share};
-                        ts[nt] = TailTileJob{r.C, r.P, r.ldc, r.M, r.K, all - share, share};
-                        ++nt;
-                    }
-                }
-            }
             rc = tail_round_t(static_cast<const T *>(nullptr), nr, rj, (dbg.excl && tiles <= tail_excl_tiles) ? 1 : 0, st);
             if (rc != SSA_OK) return rc;
-            rc = small_batch_t(static_cast<const T *>(nullptr), np, pj, st, nt, tp);
+            rc = small_batch_t(static_cast<const T *>(nullptr), np, pj, st);
             if (rc != SSA_OK) return rc;
-            rc = small_batch_t(static_cast<const T *>(nullptr), np, sj, st, nt, ts);
+            rc = small_batch_t(static_cast<const T *>(nullptr), np, sj, st);
             if (rc != SSA_OK) return rc;
             // the finishing passes of a film's blocks that are final (all their columns lie left of c) fill the chip
             // beside the chain-bound rounds from the film's low-priority stream: in slices, so that no launch of theirs

@@ -29,19 +29,8 @@ struct SmallNtJob {
     double alpha, beta;
     int pair;
 };
-// The tiles of a film's update that ride in the PANEL or STRIP launch of a round (update-bound rounds: those two
-// launches are short and would leave the chip idle): same operands as TailRoundJob's update part.
-struct TailTileJob {
-    void *C;
-    const void *P;
-    int64_t ldc, M, K, tile_first, tile_count;
-};
-// ntiles > 0: after the small-tile workgroups of `jobs` (dispatched first) the launch also runs the update tiles `tiles`.
-int gemm_nt_small_batch_f64(int njobs, const SmallNtJob *jobs, hipStream_t st, int ntiles = 0, const TailTileJob *tiles = nullptr);
-int gemm_nt_small_batch_f32(int njobs, const SmallNtJob *jobs, hipStream_t st, int ntiles = 0, const TailTileJob *tiles = nullptr);
-// number of tiles of an update of order M, and how many of them belong to the two leftmost tile columns
-inline int64_t round_tiles_total(int64_t M) { const int64_t t = M / 128; return t * (t + 1) / 2; }
-inline int64_t round_tiles_first_columns(int64_t M) { const int64_t t = M / 128; return t <= 1 ? t : 2 * t - 1; }
+int gemm_nt_small_batch_f64(int njobs, const SmallNtJob *jobs, hipStream_t st);
+int gemm_nt_small_batch_f32(int njobs, const SmallNtJob *jobs, hipStream_t st);
 
 // One film in a round launch.  diag: factor and invert the 256 x 256 block at D (leading dimension lda), inverse to
 // W (leading dimension ldw), `scratch` and `info` as for the stand-alone kernel; col1: 1-based column of D[0][0].
@@ -54,10 +43,6 @@ struct TailRoundJob {
     const void *P;
     int64_t ldc, M, K;
     void *trace = nullptr;   // debugging (chol.hip, CholDebug::trace): the block as the kernel READ it, as register images
-    // The update's tiles are numbered in ROUND ORDER (round_tile, gemm_ops.hip): first the tiles of the two leftmost
-    // tile columns -- the next panel's block column, which the strip launch of the same round updates again --, then
-    // the rest in band order.  A launch runs the tiles [tile_first, tile_first + tile_count) (-1: all from tile_first).
-    int64_t tile_first = 0, tile_count = -1;
 };
 // exclusive: the launch asks for so much LDS that no second workgroup of an MFMA tile kernel fits on a CU beside one
 // of its own: the diagonal-block workgroups then have their CUs to themselves (chain-bound rounds: few tiles);

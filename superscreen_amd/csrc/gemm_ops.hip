@@ -497,23 +497,6 @@ __device__ __forceinline__ void lower_band_tile(int64_t id, int64_t ntm, int64_t
     }
 }
 
-// ROUND ORDER of the lower tiles of an update of ntm tile rows (chol_tail.hpp): ids 0 .. ntm - 1 = tile column 0 top
-// to bottom, ntm .. 2 ntm - 2 = tile column 1 (rows 1 .. ntm - 1), the rest = the triangle behind those two columns in
-// band order.
-__device__ __forceinline__ void round_tile(int64_t id, int64_t ntm, int64_t &tm, int64_t &tn) {
-    if (id < ntm) {
-        tm = id;
-        tn = 0;
-    } else if (id < 2 * ntm - 1) {
-        tm = id - ntm + 1;
-        tn = 1;
-    } else {
-        lower_band_tile(id - (2 * ntm - 1), ntm - 2, tm, tn);
-        tm += 2;
-        tn += 2;
-    }
-}
-
 // LOWER is a template parameter so that the SYRK-shaped launches carry their own symbol in
 // rocprofv3's kernel statistics (profiles/), apart from the skinny in-panel updates.
 template <typename T, int TA, int TB, bool LOWER>
@@ -618,9 +601,6 @@ int gemm_op(int opA, int opB, int lower, int64_t M, int64_t N, int64_t K, double
 // ---- batched launches of the single-stream rounds of the Cholesky schedule (chol_tail.hpp) --------------------
 struct SmallBatchArgs {
     int njobs;
-    int ntiles;                            // update-tile jobs behind the small-tile workgroups (0: none)
-    int64_t tile_begin[kTailMaxFilms + 1]; // first tile workgroup (counted from the end of the small-tile ones) of each
-    TailTileJob t[kTailMaxFilms];
     int64_t wg_begin[kTailMaxFilms + 1];   // first workgroup of each job
     struct Job {
         const double *A, *B, *B2;          // 8-byte views
@@ -634,23 +614,8 @@ struct SmallBatchArgs {
 template <typename T>
 __global__ __launch_bounds__(kGemmThreads) void gemm_nt_small_batch_kernel(SmallBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int64_t nsmall = a.wg_begin[a.njobs];
-    if (static_cast<int64_t>(blockIdx.x) >= nsmall) {   // an update tile riding in this launch (update-bound rounds)
-        const int64_t id = xcd_contiguous(static_cast<int64_t>(blockIdx.x) - nsmall, static_cast<int64_t>(gridDim.x) - nsmall);
-        int ft = 0;
-        while (ft + 1 < a.ntiles && id >= a.tile_begin[ft + 1]) ++ft;
-        const TailTileJob &F = a.t[ft];
-        int64_t tm, tn;
-        round_tile(F.tile_first + id - a.tile_begin[ft], F.M / BM, tm, tn);
-        const T *P = static_cast<const T *>(F.P);
-        if constexpr (sizeof(T) == 8)
-            tile_full_f64<OP_N, OP_T>(F.K, -1.0, P, F.ldc, P, F.ldc, 1.0, static_cast<T *>(F.C), F.ldc, tm * BM, tn * BN, smem_raw);
-        else
-            tile_full_f32_nt(F.K, -1.0f, P, F.ldc, P, F.ldc, 1.0f, static_cast<T *>(F.C), F.ldc, tm * BM, tn * BN, smem_raw);
-        return;
-    }
     __builtin_amdgcn_s_setprio(3);   // beside the finishing passes' tiles on their low-priority stream (see gemm_nt_small_kernel)
-    const int64_t wg = xcd_contiguous(blockIdx.x, nsmall);
+    const int64_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
     int f = 0;
     while (f + 1 < a.njobs && wg >= a.wg_begin[f + 1]) ++f;
     const SmallBatchArgs::Job &J = a.j[f];
@@ -667,8 +632,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_small_batch_kernel(Small
 }
 
 template <typename T>
-int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st, int ntiles, const TailTileJob *tiles) {
-    if (njobs < 0 || njobs > kTailMaxFilms || ntiles < 0 || ntiles > kTailMaxFilms) return SSA_ERR_INVALID_ARGUMENT;
+int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st) {
+    if (njobs < 0 || njobs > kTailMaxFilms) return SSA_ERR_INVALID_ARGUMENT;
     constexpr int64_t per8 = 8 / sizeof(T);
     constexpr int64_t kStage = (sizeof(T) == 8) ? KC : 2 * KC;
     SmallBatchArgs a{};
@@ -701,37 +666,23 @@ int gemm_nt_small_batch(int njobs, const SmallNtJob *jobs, hipStream_t st, int n
         flops += (s.pair ? 1.5 : 2.0) * static_cast<double>(s.M) * static_cast<double>(s.N) * static_cast<double>(s.K);
         ++a.njobs;
     }
-    int64_t tile_total = 0;
-    for (int i = 0; i < ntiles; ++i) {
-        const TailTileJob &J = tiles[i];
-        if (J.tile_count <= 0) continue;
-        if (J.M <= 0 || J.M % BM != 0 || J.K <= 0 || J.K % kStage != 0 || reinterpret_cast<uintptr_t>(J.P) % 16 != 0 ||
-            (J.ldc * sizeof(T)) % 16 != 0 || J.tile_first < 0 || J.tile_first + J.tile_count > round_tiles_total(J.M))
-            return SSA_ERR_INVALID_ARGUMENT;
-        a.t[a.ntiles] = J;
-        a.tile_begin[a.ntiles] = tile_total;
-        tile_total += J.tile_count;
-        flops += 2.0 * static_cast<double>(J.K) * BM * BN * static_cast<double>(J.tile_count);
-        ++a.ntiles;
-    }
-    a.tile_begin[a.ntiles] = tile_total;
-    if (total + tile_total == 0) return SSA_OK;
+    if (total == 0) return SSA_OK;
     a.wg_begin[a.njobs] = total;
-    constexpr size_t lds = sizeof(SmallSmem) > sizeof(OpSmemF64) ? sizeof(SmallSmem) : sizeof(OpSmemF64);
     static DeviceFlags flags;
-    if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&gemm_nt_small_batch_kernel<T>), lds}}) != SSA_OK)
+    if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&gemm_nt_small_batch_kernel<T>), sizeof(SmallSmem)}}) !=
+        SSA_OK)
         return SSA_ERR_HIP;
     ProfileScope scope(sizeof(T) == 8, kProfileSmallBatch, flops, st);
-    hipLaunchKernelGGL((gemm_nt_small_batch_kernel<T>), dim3(static_cast<unsigned>(total + tile_total)), dim3(kGemmThreads),
-                       lds, st, a);
+    hipLaunchKernelGGL((gemm_nt_small_batch_kernel<T>), dim3(static_cast<unsigned>(total)), dim3(kGemmThreads),
+                       sizeof(SmallSmem), st, a);
     SSA_RETURN_IF_LAUNCH_FAILED();
     return SSA_OK;
 }
-int gemm_nt_small_batch_f64(int njobs, const SmallNtJob *jobs, hipStream_t st, int ntiles, const TailTileJob *tiles) {
-    return gemm_nt_small_batch<double>(njobs, jobs, st, ntiles, tiles);
+int gemm_nt_small_batch_f64(int njobs, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch<double>(njobs, jobs, st);
 }
-int gemm_nt_small_batch_f32(int njobs, const SmallNtJob *jobs, hipStream_t st, int ntiles, const TailTileJob *tiles) {
-    return gemm_nt_small_batch<float>(njobs, jobs, st, ntiles, tiles);
+int gemm_nt_small_batch_f32(int njobs, const SmallNtJob *jobs, hipStream_t st) {
+    return gemm_nt_small_batch<float>(njobs, jobs, st);
 }
 
 // The round launch: workgroups [0, ndiag) run the diagonal-block kernel of one film each (the lowest block ids of a
@@ -763,7 +714,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void chol_tail_round_kernel(TailRo
     while (f + 1 < a.nfilms && id >= a.tile_begin[f + 1]) ++f;
     const TailRoundJob &F = a.f[f];
     int64_t tm, tn;
-    round_tile(F.tile_first + id - a.tile_begin[f], F.M / BM, tm, tn);
+    lower_band_tile(id - a.tile_begin[f], F.M / BM, tm, tn);
     const T *P = static_cast<const T *>(F.P);
     if constexpr (sizeof(T) == 8)
         tile_full_f64<OP_N, OP_T>(F.K, -1.0, P, F.ldc, P, F.ldc, 1.0, static_cast<T *>(F.C), F.ldc, tm * BM, tn * BN, smem_raw);
@@ -785,13 +736,11 @@ int chol_tail_round(int nfilms, const TailRoundJob *jobs, int exclusive, hipStre
         if (J.M > 0 && (reinterpret_cast<uintptr_t>(J.P) % 16 != 0 || (J.ldc * sizeof(T)) % 16 != 0))
             return SSA_ERR_INVALID_ARGUMENT;
         if (J.has_diag) a.diag_film[a.ndiag++] = i;
-        const int64_t all = round_tiles_total(J.M);
-        if (J.tile_first < 0 || J.tile_first > all) return SSA_ERR_INVALID_ARGUMENT;
-        if (J.tile_count < 0 || J.tile_first + J.tile_count > all) J.tile_count = all - J.tile_first;
         a.f[i] = J;
         a.tile_begin[i] = tiles;
-        tiles += J.tile_count;
-        flops += 2.0 * static_cast<double>(J.K) * BM * BN * static_cast<double>(J.tile_count);
+        const int64_t ntm = J.M / BM;
+        tiles += ntm * (ntm + 1) / 2;
+        flops += static_cast<double>(J.K) * static_cast<double>(J.M) * static_cast<double>(J.M + 1);
     }
     a.tile_begin[nfilms] = tiles;
     if (a.ndiag + tiles == 0) return SSA_OK;
