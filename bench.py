@@ -623,6 +623,44 @@ def configH_alt_2x50k(sc, torch, iterations):
             "configH_alt_2x50k_TFLOPs_factorization_flops_only": sum(u ** 3 / 3.0 for u in unknowns) / t / 1e12}
 
 
+def configH_own_meshes(sc, torch, iterations):
+    """Config H's shape on films that share NOTHING: a washer on a K = 91 mesh (25 117 vertices) below a smaller
+    disk on a K = 85 mesh (21 931 vertices, radius 4.5 um) that sits off the axis, different Lambda per layer -- the
+    reference's general case (every film its own mesh, ``solver/solve.py:495-515``); parity of this device class:
+    ``tests/test_solve_gpu.py::test_films_with_their_own_meshes_*`` (reference fixture + oracle)."""
+    from superscreen_amd import synthetic
+
+    Ka = int(os.environ.get("BENCH_OWN_MESHES_K", "91"))          # testing aid: smaller meshes
+    spec = dict(layers=[dict(name="layer0", z0=0.0, Lambda=0.1), dict(name="layer1", z0=0.5, Lambda=0.05)],
+                films=[dict(name="washer", kind="washer", K=Ka, layer="layer0", film_radius=5.0),
+                       dict(name="shield", kind="disk", K=max(3, Ka - 6), layer="layer1", film_radius=4.5,
+                            center=(0.4, -0.3))])
+    device = synthetic.make_device(spec["films"], spec["layers"])
+    field = sc.Parameter(synthetic.tilted_field, B0=1.0)
+
+    def cold():
+        model = sc.factorize_model(device=device, current_units="uA")
+        return [int(len(s_.indices)) for s_ in model.film_systems.values()], \
+            sc.solve(model=model, applied_field=field, field_units="mT", iterations=iterations, progress_bar=False)
+
+    cold()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        unknowns, sols = cold()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t1)
+        assert len(sols) == iterations + 1
+        del sols
+    t = float(np.median(ts))
+    torch.cuda.empty_cache()
+    return {"configH_own_meshes_vertices": [len(device.meshes[f].sites) for f in device.films],
+            "configH_own_meshes_unknowns": unknowns, "configH_own_meshes_ms_per_solve": t * 1e3,
+            "configH_own_meshes_solves_per_s": 1.0 / t,
+            "configH_own_meshes_TFLOPs_factorization_flops_only": sum(u ** 3 / 3.0 for u in unknowns) / t / 1e12}
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE configs 4 and 5 on N ranks
 # ---------------------------------------------------------------------------------------------------
@@ -1138,6 +1176,7 @@ def main():
         extras.update(guarded("pipelined", lambda: pipelined_cold_solves(sc, torch, device, args.iterations)))
         extras.update(guarded("configH_float32", lambda: configH_float32(sc, torch, args.K, args.iterations)))
         extras.update(guarded("configH_alt_2x50k", lambda: configH_alt_2x50k(sc, torch, args.iterations)))
+        extras.update(guarded("configH_own_meshes", lambda: configH_own_meshes(sc, torch, args.iterations)))
 
     def emit_line():
         if rank == 0:

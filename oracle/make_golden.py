@@ -641,10 +641,143 @@ def mutual_fixture(K, kinds, z0s, Lambda, iterations, fname, I_circ=1000.0):
     print("wrote", fname, "n =", n, "holes", hole_names)
 
 
+def _mixed_setup(spec, circ_by_hole):
+    """Reference-side objects of a device whose films have their own meshes (superscreen_amd.synthetic.make_device
+    builds the same device for the GPU path): one reference ``Mesh`` per film, ``FilmInfo`` per film with ITS layer's
+    Lambda and ITS polygons."""
+    layer = {l["name"]: l for l in spec["layers"]}
+    names = [f["name"] for f in spec["films"]]
+    geos, meshes, infos, z0 = {}, {}, {}, {}
+    for f in spec["films"]:
+        geo = synthetic.film_geometry(f["kind"], f["K"], film_radius=f.get("film_radius", 5.0),
+                                      center=f.get("center", (0.0, 0.0)))
+        geos[f["name"]] = geo
+        meshes[f["name"]] = Mesh.from_triangulation(geo["sites"], geo["elements"])
+    for f in spec["films"]:
+        nm = f["name"]
+        holes = {} if geos[nm]["hole_polygon"] is None else {"hole_" + nm: geos[nm]["hole_polygon"]}
+        infos[nm] = make_film_info(nm, f["layer"], meshes[nm], geos[nm]["film_polygon"], holes,
+                                   layer[f["layer"]]["Lambda"], circ_by_hole, "float64")
+        z0[nm] = layer[f["layer"]]["z0"]
+    return names, geos, meshes, infos, z0
+
+
+def _mixed_trace(names, meshes, infos, z0, applied, iterations):
+    """solver/solve.py:459-547 around the reference's ``solve_film`` / ``biot_savart_film_to_film`` -- source and
+    target sites are those of the two films' OWN meshes (:508-515)."""
+    device_like = SimpleNamespace(terminals={}, meshes=meshes)
+    film_systems, hole_systems, _ = factorize_linear_systems(device_like, infos)
+
+    def run(other):
+        return {
+            nm: solve_film(
+                device=device_like, applied_field=applied[nm], film_info=infos[nm],
+                film_system=film_systems[nm], hole_systems=hole_systems[nm],
+                field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX,
+                field_from_other_films=None if other is None else other[nm],
+            )
+            for nm in names
+        }
+
+    sols = run(None)
+    trace = [sols]
+    for it in range(iterations):
+        other = {nm: np.zeros(len(meshes[nm].sites)) for nm in names}
+        for src, tgt in itertools.product(names, repeat=2):
+            if src == tgt:
+                continue
+            other[tgt] += biot_savart_film_to_film(
+                film1_sites=meshes[src].sites, film1_z0=z0[src], film1_areas=infos[src].weights,
+                film1_J=sols[src].current_density, film2_sites=meshes[tgt].sites, film2_z0=z0[tgt],
+            )
+        sols = run(other)
+        trace.append(sols)
+    return trace
+
+
+def _fluxoid_raw(geo, mesh, sol, Lambda):
+    """The two raw parts of ``polygon_fluxoid`` (solution.py:535-559) of the film's fluxoid polygon."""
+    from matplotlib.tri import LinearTriInterpolator, Triangulation
+
+    poly = geo["fluxoid_polygon"]
+    total = sol.applied_field + sol.self_field
+    if sol.field_from_other_films is not None:
+        total = total + sol.field_from_other_films
+    ix = contains(poly, mesh.sites)
+    flux_part = np.einsum("i, i ->", total[ix], mesh.vertex_areas[ix])
+    tri = Triangulation(mesh.sites[:, 0], mesh.sites[:, 1], mesh.elements)
+    J = sol.current_density
+    Jp = np.array([LinearTriInterpolator(tri, J[:, 0])(poly[:, 0], poly[:, 1]).data,
+                   LinearTriInterpolator(tri, J[:, 1])(poly[:, 0], poly[:, 1]).data]).T
+    Jp[~contains(geo["film_polygon"], poly)] = 0
+    Jp[~np.isfinite(Jp).all(axis=1)] = 0
+    dl = np.diff(poly, axis=0)
+    int_J = np.trapezoid(Lambda * np.ones(len(poly))[:-1] * np.sum(Jp[:-1] * dl, axis=1))
+    return flux_part, int_J
+
+
+def mixed_mesh_fixture(spec, iterations, fname, circ, field_mT):
+    """Coupled films with DIFFERENT meshes (different vertex counts, a lateral offset, per-layer Lambda including 0,
+    two films in one layer): every Jacobi iterate and the fluxoid parts of every washer -- the general case of
+    solver/solve.py:495-515 that the coaxial shared-mesh stacks above never reach."""
+    names, geos, meshes, infos, z0 = _mixed_setup(spec, circ)
+    layer = {l["name"]: l for l in spec["layers"]}
+    applied = {}
+    for nm in names:
+        xy = meshes[nm].sites
+        applied[nm] = synthetic.tilted_field(xy[:, 0], xy[:, 1], z0[nm] * np.ones(len(xy)), field_mT) * FIELD_CONV
+    trace = _mixed_trace(names, meshes, infos, z0, applied, iterations)
+    out = dict(names=np.array(names), iterations=iterations, field_mT=field_mT, field_conversion=FIELD_CONV,
+               circ_holes=np.array(list(circ)), circ_values=np.array([circ[h] for h in circ], dtype=float))
+    for nm in names:
+        out[f"n_{nm}"] = len(meshes[nm].sites)
+        out[f"film_indices_{nm}"] = np.setdiff1d(infos[nm].interior_indices, np.where(infos[nm].in_hole)[0])
+    for it, s in enumerate(trace):
+        for nm in names:
+            out[f"g_{nm}_it{it}"] = s[nm].stream
+            out[f"J_{nm}_it{it}"] = s[nm].current_density
+            out[f"self_field_{nm}_it{it}"] = s[nm].self_field
+            if s[nm].field_from_other_films is not None:
+                out[f"other_{nm}_it{it}"] = s[nm].field_from_other_films
+            if geos[nm]["hole_polygon"] is not None:
+                Lam = layer[infos[nm].layer]["Lambda"]
+                out[f"flux_part_raw_{nm}_it{it}"], out[f"int_J_raw_{nm}_it{it}"] = \
+                    _fluxoid_raw(geos[nm], meshes[nm], s[nm], Lam)
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "films", {nm: len(meshes[nm].sites) for nm in names})
+
+
+def mixed_mutual_fixture(spec, iterations, fname, I_circ=1000.0):
+    """``mutual_fixture`` for films with their own meshes: raw fluxoid parts [iterate, hole i, source hole j]."""
+    layer = {l["name"]: l for l in spec["layers"]}
+    hole_films = [f["name"] for f in spec["films"] if f["kind"] == "washer"]
+    hole_names = ["hole_" + nm for nm in hole_films]
+    flux_raw = np.zeros((iterations + 1, len(hole_names), len(hole_names)))
+    intJ_raw = np.zeros_like(flux_raw)
+    for j, src_hole in enumerate(hole_names):
+        names, geos, meshes, infos, z0 = _mixed_setup(spec, {h: (I_circ if h == src_hole else 0.0)
+                                                             for h in hole_names})
+        applied = {nm: np.zeros(len(meshes[nm].sites)) for nm in names}
+        trace = _mixed_trace(names, meshes, infos, z0, applied, iterations)
+        for it, s_all in enumerate(trace):
+            for i, nm in enumerate(hole_films):
+                flux_raw[it, i, j], intJ_raw[it, i, j] = _fluxoid_raw(
+                    geos[nm], meshes[nm], s_all[nm], layer[infos[nm].layer]["Lambda"])
+    np.savez_compressed(os.path.join(GOLDEN, fname), iterations=iterations, I_circ_uA=I_circ,
+                        hole_names=np.array(hole_names), flux_part_raw=flux_raw, int_J_raw=intJ_raw,
+                        field_conversion=FIELD_CONV)
+    print("wrote", fname, "holes", hole_names)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     if "--only-mutual" in sys.argv:
         mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
+        sys.exit(0)
+    if "--only-mixed" in sys.argv:
+        mixed_mesh_fixture(synthetic.RINGS_MIXED, 4, "rings_mixed.npz",
+                           {"hole_big_ring": 3.0, "hole_little_ring": -1.5}, 0.8)
+        mixed_mutual_fixture(synthetic.RINGS_MIXED, 3, "mutual_rings_mixed.npz")
         sys.exit(0)
     if "--only-vortex" in sys.argv:
         vortex_fixture(13, False, "vortex_disk_K13.npz")
@@ -671,6 +804,9 @@ if __name__ == "__main__":
                   circ=2.0, field_mT=0.5)
     biot_savart_fixture("biot_savart.npz")
     mutual_fixture(12, ("washer", "washer"), (0.0, 0.4), 0.1, 3, "mutual_K12.npz")
+    mixed_mesh_fixture(synthetic.RINGS_MIXED, 4, "rings_mixed.npz",
+                       {"hole_big_ring": 3.0, "hole_little_ring": -1.5}, 0.8)
+    mixed_mutual_fixture(synthetic.RINGS_MIXED, 3, "mutual_rings_mixed.npz")
     sheet_field_fixture("sheet_field.npz")
     potential_and_flux_fixture("potential_flux.npz")
     vortex_fixture(13, False, "vortex_disk_K13.npz")

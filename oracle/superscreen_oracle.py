@@ -365,6 +365,31 @@ def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.nda
     return film
 
 
+def make_films(layers: Sequence[dict], films: Sequence[dict], geometries: Dict[str, dict],
+               dtype="float64", meshes: Optional[Dict[str, OracleMesh]] = None) -> List[OracleFilm]:
+    """The films of a device in which EVERY film has its own mesh (the general case of ``make_film_info``,
+    solver/utils.py:244-246: ``mesh = device.meshes[name]``, ``layer = device.layers[film.layer]``).
+
+    ``layers``: ``dict(name=, z0=, Lambda=)``; ``films``: ``dict(name=, layer=, ...)``; ``geometries[name]``:
+    ``dict(sites=, elements=, film_polygon=, hole_polygon= | None)`` (what
+    ``superscreen_amd.synthetic.film_geometry`` returns -- data only).  A film's hole is ``"hole_" + name``; hole
+    membership is ``Polygon.contains_points`` = matplotlib ``Path.contains_points`` (device/polygon.py:159)."""
+    from matplotlib.path import Path
+
+    layer = {l["name"]: l for l in layers}
+    out = []
+    for f in films:
+        geo = geometries[f["name"]]
+        mesh = meshes[f["name"]] if meshes is not None else make_mesh(geo["sites"], geo["elements"])
+        holes = {}
+        if geo.get("hole_polygon") is not None:
+            holes["hole_" + f["name"]] = Path(geo["hole_polygon"], closed=True).contains_points(mesh.sites)
+        out.append(make_film(f["name"], mesh, z0=layer[f["layer"]]["z0"], Lambda=layer[f["layer"]]["Lambda"],
+                             in_film=Path(geo["film_polygon"], closed=True).contains_points(mesh.sites),
+                             holes_mask=holes, dtype=dtype))
+    return out
+
+
 @dataclass
 class OracleFilmSolution:
     """``FilmSolution`` (solution.py:95-130)."""

@@ -71,11 +71,15 @@ def make_stack_device(
     film_radius: float = 5.0,
     solve_dtype: str = "float64",
     name: Optional[str] = None,
+    share_mesh: bool = False,
 ):
     """Builds a :class:`superscreen_amd.Device` made of ``len(kinds)`` coaxial films, one per
-    layer at ``z0 = i*z_spacing``, every film meshed with the same ``K``-ring disk mesh.
+    layer at ``z0 = i*z_spacing``, every film meshed with the same ``K``-ring disk triangulation.
 
-    ``kinds[i]`` is ``"disk"`` or ``"washer"`` (disk with a concentric hole).
+    ``kinds[i]`` is ``"disk"`` or ``"washer"`` (disk with a concentric hole).  Every film gets its OWN
+    :class:`Mesh` object, as in the reference, where ``Device.make_mesh`` meshes film by film
+    (``device/device.py:383-470``); ``share_mesh=True`` hands one object to all films (what rounds 1-5 did: one
+    geometry upload and one host-side cache entry then serve every film).
     """
     from .device import Device, Layer, Polygon
     from .mesh import Mesh
@@ -103,9 +107,78 @@ def make_stack_device(
         length_units="um",
         solve_dtype=solve_dtype,
     )
-    mesh = Mesh.from_triangulation(sites, elements)  # one mesh object shared by all films
-    device.meshes = {film.name: mesh for film in films}
+    if share_mesh:
+        mesh = Mesh.from_triangulation(sites, elements)
+        device.meshes = {film.name: mesh for film in films}
+    else:
+        device.meshes = {film.name: Mesh.from_triangulation(sites.copy(), elements.copy()) for film in films}
     return device
+
+
+def film_geometry(kind: str, K: int, *, film_radius: float = 5.0, center=(0.0, 0.0)) -> dict:
+    """One synthetic film ON ITS OWN MESH: the ``K``-ring disk mesh scaled to ``film_radius`` and moved to
+    ``center``.  Returns ``sites, elements, dr, film_polygon, hole_polygon`` (``None`` for a disk) and
+    ``fluxoid_polygon`` (a circle half way between hole and rim -- for a disk: at the same radius)."""
+    if kind not in ("disk", "washer"):
+        raise ValueError(f"Unknown film kind {kind!r}.")
+    sites, elements, dr = ring_disk_mesh(K, film_radius)
+    center = np.asarray(center, dtype=np.float64)
+    Kf = film_rings(K)
+    Kh = Kf // 3
+    return dict(
+        kind=kind, K=int(K), dr=dr, center=center,
+        sites=sites + center, elements=elements,
+        film_polygon=circle_points((Kf + 0.5) * dr, center=center),
+        hole_polygon=circle_points((Kh + 0.5) * dr, 201, center=center) if kind == "washer" else None,
+        fluxoid_polygon=circle_points((Kh + (Kf - Kh) / 2 + 0.25) * dr, 101, center=center),
+    )
+
+
+def make_device(films: Sequence[dict], layers: Sequence[dict], *, solve_dtype: str = "float64",
+                name: Optional[str] = None):
+    """A device whose films are meshed SEPARATELY (the reference's general case, ``solver/solve.py:495-515``:
+    ``meshes[source_film].sites`` -> ``meshes[film].sites``; its own multi-film test device is two rings of
+    different size, ``test/test_solve.py:40-93``): every film gets its own :class:`Mesh` object, vertex count,
+    position and radius, and the layers their own ``Lambda`` and ``z0``; several films may share a layer.
+
+    ``layers``: ``dict(name=, z0=, Lambda=)`` each; ``films``: ``dict(name=, kind=, K=, layer=, film_radius=5.0,
+    center=(0, 0))`` each (the keyword arguments of :func:`film_geometry` plus ``name`` and ``layer``).  A washer's
+    hole is called ``"hole_" + name``.
+    """
+    from .device import Device, Layer, Polygon
+    from .mesh import Mesh
+
+    lays = [Layer(l["name"], Lambda=l["Lambda"], z0=l["z0"]) for l in layers]
+    polys, holes, meshes = [], [], {}
+    for spec in films:
+        geo = film_geometry(spec["kind"], spec["K"], film_radius=spec.get("film_radius", 5.0),
+                            center=spec.get("center", (0.0, 0.0)))
+        polys.append(Polygon(spec["name"], layer=spec["layer"], points=geo["film_polygon"]))
+        if geo["hole_polygon"] is not None:
+            holes.append(Polygon("hole_" + spec["name"], layer=spec["layer"], points=geo["hole_polygon"]))
+        meshes[spec["name"]] = Mesh.from_triangulation(geo["sites"], geo["elements"])
+    device = Device(name or "synthetic_" + "_".join(s["name"] for s in films), layers=lays, films=polys,
+                    holes=holes, length_units="um", solve_dtype=solve_dtype)
+    device.meshes = meshes
+    return device
+
+
+# The device of tests/golden/rings_mixed.npz (recorded from the reference by oracle/make_golden.py): the shape of
+# the reference's ``two_rings`` test device (a big and a little ring in two layers, the lower one with Lambda = 0)
+# with the little ring moved off the axis and a third, disjoint film in the lower ring's layer (dz = 0 coupling).
+RINGS_MIXED = dict(
+    layers=[dict(name="layer0", z0=0.0, Lambda=0.0), dict(name="layer1", z0=1.0, Lambda=0.2)],
+    films=[
+        dict(name="big_ring", kind="washer", K=13, layer="layer0", film_radius=7.5, center=(0.0, 0.0)),
+        dict(name="little_ring", kind="washer", K=9, layer="layer1", film_radius=5.0, center=(0.8, -0.5)),
+        dict(name="side_disk", kind="disk", K=7, layer="layer0", film_radius=2.0, center=(12.0, 3.0)),
+    ],
+)
+
+
+def tilted_field(x, y, z, B0: float = 1.0):
+    """The applied field of the mixed-mesh fixtures: not uniform, so that a film's position matters."""
+    return B0 * (1.0 + 0.04 * np.asarray(x) - 0.03 * np.asarray(y) + 0.1 * np.asarray(z))
 
 
 def strip_mesh(nx: int, ny: int, length: float = 10.0, width: float = 4.0) -> Tuple[np.ndarray, np.ndarray]:

@@ -122,6 +122,157 @@ def test_coupled_films_jacobi_trace_and_fluxoid(sc, golden, name, kinds):
     assert relerr(short[-1].film_solutions[names[0]].stream, d[f"g_{names[0]}_it{len(short) - 1}"]) < TOL
 
 
+def _mixed_device(sc, spec=None, dtype="float64"):
+    from superscreen_amd import synthetic
+
+    spec = spec or synthetic.RINGS_MIXED
+    device = synthetic.make_device(spec["films"], spec["layers"], solve_dtype=dtype)
+    meshes = list(device.meshes.values())
+    assert all(a is not b for i, a in enumerate(meshes) for b in meshes[i + 1:])   # NOT one shared Mesh object
+    geos = {f["name"]: synthetic.film_geometry(f["kind"], f["K"], film_radius=f.get("film_radius", 5.0),
+                                               center=f.get("center", (0.0, 0.0))) for f in spec["films"]}
+    return device, geos
+
+
+def _mixed_circ(d):
+    return dict(zip((str(h) for h in d["circ_holes"]), (float(v) for v in d["circ_values"])))
+
+
+@pytest.mark.parametrize("method", ["auto", "lu"])
+def test_films_with_their_own_meshes_vs_reference_fixture(sc, golden, method):
+    """The general case of the reference's coupling loop (solver/solve.py:495-515: ``meshes[source_film].sites``
+    -> ``meshes[film].sites``) and the shape of its own multi-film test device (test/test_solve.py:40-93): three
+    films on three DIFFERENT meshes (547 / 271 / 169 vertices), the little ring off the axis, Lambda = 0 below and
+    0.2 above, a third film in the lower ring's layer (dz = 0), a field that is not uniform.  Every iterate, the
+    fluxoid parts of both rings in every iterate, against what the reference produced
+    (tests/golden/rings_mixed.npz)."""
+    from superscreen_amd import synthetic
+
+    d = golden("rings_mixed.npz")
+    device, geos = _mixed_device(sc)
+    names = [str(s) for s in d["names"]]
+    assert list(device.films) == names
+    assert [len(device.meshes[nm].sites) for nm in names] == [int(d[f"n_{nm}"]) for nm in names] == [547, 271, 169]
+    iters = int(d["iterations"])
+    field = sc.Parameter(synthetic.tilted_field, B0=float(d["field_mT"]))
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents=_mixed_circ(d), method=method)
+    for nm in names:
+        assert np.array_equal(model.film_systems[nm].indices, d[f"film_indices_{nm}"])
+    sols = sc.solve(model=model, applied_field=field, field_units="mT", iterations=iters)
+    assert len(sols) == iters + 1
+    raw_units = "mT * um**2"
+    for it, sol in enumerate(sols):
+        for nm in names:
+            fs = sol.film_solutions[nm]
+            assert fs.stream.shape == (int(d[f"n_{nm}"]),)
+            assert relerr(fs.stream, d[f"g_{nm}_it{it}"]) < TOL
+            assert relerr(fs.current_density, d[f"J_{nm}_it{it}"]) < TOL
+            assert relerr(fs.self_field, d[f"self_field_{nm}_it{it}"]) < TOL
+            if it == 0:
+                assert fs.field_from_other_films is None
+            else:
+                assert relerr(fs.field_from_other_films, d[f"other_{nm}_it{it}"]) < TOL
+            if geos[nm]["hole_polygon"] is not None:
+                fl = sol.polygon_fluxoid(geos[nm]["fluxoid_polygon"], film=nm, units=raw_units, with_units=False)
+                ref_flux = float(d[f"flux_part_raw_{nm}_it{it}"])
+                ref_sc = orc.MU_0 * float(d[f"int_J_raw_{nm}_it{it}"]) * 1e-12 / (1e-3 * 1e-12)
+                assert abs(fl.flux_part - ref_flux) < 1e-9 * abs(ref_flux)
+                assert abs(fl.supercurrent_part - ref_sc) <= 1e-9 * abs(ref_sc)
+    # the device form of solve() (factorization inside) gives the same iterates
+    again = sc.solve(device, applied_field=field, field_units="mT", current_units="uA",
+                     circulating_currents=_mixed_circ(d), iterations=iters)
+    for a, b in zip(again, sols):
+        for nm in names:
+            assert relerr(a.film_solutions[nm].stream, b.film_solutions[nm].stream) < (0 if method == "auto" else TOL) + 1e-300
+
+
+def test_solve_sweep_films_with_their_own_meshes(sc, golden):
+    """solve_sweep (n x nvec operands per film, pair kernels between films of different size) on the mixed-mesh
+    device: the column that carries the fixture's field reproduces the reference's iterates, every column equals
+    the looped solve()."""
+    from superscreen_amd import synthetic
+
+    d = golden("rings_mixed.npz")
+    device, _ = _mixed_device(sc)
+    names = list(device.films)
+    iters = int(d["iterations"])
+    B0 = float(d["field_mT"])
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents=_mixed_circ(d))
+    fields = [sc.Parameter(synthetic.tilted_field, B0=b) for b in (0.3, B0, -1.2)] + [0.5, sc.ConstantField(0.0)]
+    fields += [sc.Parameter(synthetic.tilted_field, B0=0.1 * k) for k in range(1, 15)]   # 19 columns
+    sweep = sc.solve_sweep(model, fields, field_units="mT", iterations=iters)
+    assert len(sweep) == 19 and all(len(s) == iters + 1 for s in sweep)
+    for it, sol in enumerate(sweep[1]):
+        for nm in names:
+            fs = sol.film_solutions[nm]
+            assert relerr(fs.stream, d[f"g_{nm}_it{it}"]) < TOL
+            assert relerr(fs.current_density, d[f"J_{nm}_it{it}"]) < TOL
+            assert relerr(fs.self_field, d[f"self_field_{nm}_it{it}"]) < TOL
+            if it > 0:
+                assert relerr(fs.field_from_other_films, d[f"other_{nm}_it{it}"]) < TOL
+    for f, sols in zip(fields, sweep):
+        ref = sc.solve(model=model, applied_field=f if callable(f) else sc.ConstantField(f), field_units="mT",
+                       iterations=iters)
+        for a, b in zip(sols, ref):
+            for nm in names:
+                fa, fb = a.film_solutions[nm], b.film_solutions[nm]
+                scale = max(float(np.abs(fb.stream).max()), 1e-300)
+                assert float(np.abs(fa.stream - fb.stream).max()) / scale < 1e-11
+                assert np.array_equal(fa.applied_field, fb.applied_field)
+    final = sc.solve_sweep(model, fields[:3], field_units="mT", iterations=iters, all_iterations=False)
+    for (last,), sols in zip(final, sweep[:3]):
+        for nm in names:
+            assert relerr(last.film_solutions[nm].stream, sols[-1].film_solutions[nm].stream) < 1e-10
+            assert relerr(last.film_solutions[nm].field_from_other_films,
+                          sols[-1].film_solutions[nm].field_from_other_films) < 1e-10
+
+
+def test_mutual_inductance_matrix_films_with_their_own_meshes(sc, golden):
+    """Device.mutual_inductance_matrix (device/device.py:538-648) of the two rings of the mixed-mesh device (different
+    meshes and Lambda, the side disk coupling to both) against the reference's raw fluxoid parts."""
+    from superscreen_amd.units import MU_0
+
+    d = golden("mutual_rings_mixed.npz")
+    device, geos = _mixed_device(sc)
+    hole_names = [str(h) for h in d["hole_names"]]
+    mapping = {h: geos[h[len("hole_"):]]["fluxoid_polygon"] for h in hole_names}
+    iterations = int(d["iterations"])
+    I_A = float(d["I_circ_uA"]) * 1e-6
+    M_ref = (d["flux_part_raw"] * 1e-3 * 1e-12 + MU_0 * d["int_J_raw"] * 1e-6 * 1e-6) / I_A / 1e-12
+    Ms = device.mutual_inductance_matrix(hole_polygon_mapping=mapping, units="pH", all_iterations=True,
+                                         iterations=iterations)
+    assert len(Ms) == iterations + 1
+    for it, M in enumerate(Ms):
+        assert np.max(np.abs(np.asarray(M.magnitude) - M_ref[it])) < 1e-9 * np.max(np.abs(M_ref[it]))
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 5e-4)])
+def test_films_with_their_own_meshes_vs_oracle_medium(sc, dtype, tol):
+    """Two rings of 1 951 (K = 25) and 2 977 (K = 31) vertices -- sizes the reference under stubs does not reach
+    -- the smaller one off the axis above the larger, different Lambda: every iterate against the oracle."""
+    from superscreen_amd import synthetic
+
+    spec = dict(layers=[dict(name="bottom", z0=0.0, Lambda=0.05), dict(name="top", z0=0.7, Lambda=0.3)],
+                films=[dict(name="wide", kind="washer", K=31, layer="bottom", film_radius=6.0, center=(0.0, 0.0)),
+                       dict(name="narrow", kind="washer", K=25, layer="top", film_radius=4.0, center=(-1.1, 0.6))])
+    device, geos = _mixed_device(sc, spec, dtype)
+    circ = {"hole_wide": 2.0}
+    field = sc.Parameter(synthetic.tilted_field, B0=0.6)
+    sols = sc.solve(device, applied_field=field, field_units="mT", current_units="uA", circulating_currents=circ,
+                    iterations=4)
+    films = orc.make_films(spec["layers"], spec["films"], geos, dtype=dtype)
+    assert [len(f.mesh.sites) for f in films] == [2977, 1951]
+    trace = orc.solve(films, lambda x, y, z: synthetic.tilted_field(x, y, z, 0.6), iterations=4,
+                      circulating_currents=circ)
+    for sol, ref in zip(sols, trace):
+        for nm in device.films:
+            assert relerr(sol.film_solutions[nm].stream, ref[nm].stream) < tol
+            assert relerr(sol.film_solutions[nm].self_field, ref[nm].self_field) < tol
+            assert relerr(sol.film_solutions[nm].current_density, ref[nm].current_density) < tol * 10
+            if ref[nm].field_from_other_films is not None:
+                assert relerr(sol.film_solutions[nm].field_from_other_films, ref[nm].field_from_other_films) < tol * 10
+
+
 def _oracle_stack(K, kinds, z_spacing, Lambda, dtype):
     from matplotlib.path import Path
 
@@ -528,9 +679,12 @@ def test_vector_potential_and_polygon_flux_vs_reference(golden):
         assert abs(b - float(d[f"flux_{poly}_T_m2"])) < 1e-12 * abs(float(d[f"flux_{poly}_T_m2"]))
 
 
-def test_film_placement_two_ranks():
+@pytest.mark.parametrize("which", ["stack", "mixed"])
+def test_film_placement_two_ranks(which):
     """parallel.FilmPlacement (owner-computes films, broadcast of the O(n) result vectors): two
-    ranks share this GPU, gloo carries the broadcasts, results equal the single-process solve."""
+    ranks share this GPU, gloo carries the broadcasts, results equal the single-process solve.
+    ``mixed``: the three films have their own meshes of different size (and the iterates are also held against
+    the reference's, tests/golden/rings_mixed.npz)."""
     import subprocess
     import sys
 
@@ -543,7 +697,7 @@ def test_film_placement_two_ranks():
         port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker] + (["mixed"] if which == "mixed" else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("owner-computes == single process") == 2
