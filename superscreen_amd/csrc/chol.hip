@@ -184,6 +184,15 @@ inline int tail_round_t(const float *, int n, const TailRoundJob *jobs, int excl
     return chol_tail_round_f32(n, jobs, exclusive, st);
 }
 
+inline int fused_round_t(const double *, int n, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big, hipStream_t st,
+                         unsigned long long *wg_times, int64_t cap) {
+    return chol_fused_round_f64(n, jobs, exclusive, chain_pos, big, st, wg_times, cap);
+}
+inline int fused_round_t(const float *, int n, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big, hipStream_t st,
+                         unsigned long long *wg_times, int64_t cap) {
+    return chol_fused_round_f32(n, jobs, exclusive, chain_pos, big, st, wg_times, cap);
+}
+
 #ifndef SSA_SNB
 #define SSA_SNB 4096
 #endif
@@ -191,7 +200,7 @@ constexpr int64_t SNB = SSA_SNB;  // block size of the triangular solves (pre-in
 
 // aux layout (elements):  inv [nblk][SNB][SNB] | invT [nblk][SNB][SNB] | tmp | scratch
 struct AuxLayout {
-    int64_t nblk, nfull, inv, invT, tmp, scratch, total;
+    int64_t nblk, nfull, inv, invT, tmp, scratch, flags, total;
 };
 inline AuxLayout aux_layout(int64_t n) {
     AuxLayout a;
@@ -204,7 +213,9 @@ inline AuxLayout aux_layout(int64_t n) {
     // scratch of the diagonal-block kernel: one register image per lower 16 x 16 tile of the 256 x 256 block
     // (chol_diag2.hpp: 34 816 elements of the type the block is factored in -- float64 for both routes, so twice as
     // many elements of a float32 matrix)
-    a.total = a.scratch + 2 * cholk2::kScratchElems;
+    // the words the workgroups of a fused round launch synchronise through (chol_tail.hpp, kRoundFlagWords)
+    a.flags = a.scratch + 2 * cholk2::kScratchElems;
+    a.total = a.flags + 64;
     return a;
 }
 
@@ -443,6 +454,7 @@ template <typename T>
 struct FinishPlan {
     const CholJob<T> *job = nullptr;
     int64_t done = 0;   // full SNB blocks whose solve-phase data have been issued
+    bool skip_all = false, skip_mirror = false;   // timing experiments only (SSA_CHOL_DEBUG finish=0 / mirror=0)
 
     void init(const CholJob<T> *j) {
         job = j;
@@ -455,6 +467,10 @@ struct FinishPlan {
         const CholJob<T> &J = *job;
         if (upto > nfull()) upto = nfull();
         if (upto <= done) return SSA_OK;
+        if (skip_all) {
+            done = upto;
+            return SSA_OK;
+        }
         int rc = SSA_OK;
         for (int64_t h = 256; h < SNB; h *= 2) {
             rc = inverse_level(J, h, false, done, upto, st, sliced);
@@ -465,11 +481,11 @@ struct FinishPlan {
         // (beside the rounds these two go out in pieces as well: a transpose launch of a whole block is 4 096 / 20 000
         // short workgroups that take every free slot for 0.2-0.7 ms -- the rounds' panel and strip launches waited
         // behind them for up to 0.9 ms)
-        for (int64_t j = done; j < upto && rc == SSA_OK; j += (sliced ? 1 : upto - done))
+        for (int64_t j = done; j < upto && rc == SSA_OK && !skip_mirror; j += (sliced ? 1 : upto - done))
             rc = inverse_transposes(J, j, sliced ? j + 1 : upto, st);
         if (rc != SSA_OK) return rc;
         const int64_t piece = sliced ? 512 : (upto - done) * SNB;
-        for (int64_t c0 = done * SNB; c0 < upto * SNB && rc == SSA_OK; c0 += piece)
+        for (int64_t c0 = done * SNB; c0 < upto * SNB && rc == SSA_OK && !skip_mirror; c0 += piece)
             rc = mirror_columns(J, c0, std::min(c0 + piece, upto * SNB), st);
         if (rc != SSA_OK) return rc;
         done = upto;
@@ -480,6 +496,10 @@ struct FinishPlan {
         const AuxLayout al = aux_layout(J.n);
         const int64_t first = done;
         int rc = SSA_OK;
+        if (skip_all) {
+            done = -1;
+            return SSA_OK;
+        }
         for (int64_t h = 256; h < SNB; h *= 2) {
             rc = inverse_level(J, h, false, first, al.nfull, st, sliced);
             if (rc != SSA_OK) return rc;
@@ -492,9 +512,11 @@ struct FinishPlan {
                                      J.aux + al.tmp + al.nfull * (SNB * SNB / 4), st);
             if (rc != SSA_OK) return rc;
         }
-        rc = inverse_transposes(J, first, al.nblk, st);
-        if (rc != SSA_OK) return rc;
-        rc = mirror_columns(J, first * SNB, J.n, st);
+        if (!skip_mirror) {
+            rc = inverse_transposes(J, first, al.nblk, st);
+            if (rc != SSA_OK) return rc;
+            rc = mirror_columns(J, first * SNB, J.n, st);
+        }
         done = -1;
         return rc;
     }
@@ -513,15 +535,37 @@ struct FinishPlan {
 //   trace=1     every diagonal-block workgroup of a round stores the block AS IT READ IT (register images, 272 KB);
 //               after the schedule the host waits and writes all of them to the file SSA_CHOL_TRACE_FILE:
 //               [matrix][panel][34 816] float64 (float64 matrices only)
+//   fuse=0      rounds as three launches (round / panel / strip: the form of rounds 4 and 5) instead of ONE launch whose
+//               workgroups hand over through device-side flags (chol_tail.hpp, "Fused rounds")
+//   kdepth=D    fused rounds: a block column behind the next two is served when D panels are pending for it (default 2:
+//               every other round with K = 512; 1: every round with K = 256)
+//   cpos=N      fused rounds: N tile workgroups in front of the chain workgroups in the grid (default 2048)
+//   wgtime=R    fused rounds: every workgroup of round R (0-based) records {role, start, end}; after the schedule the host
+//               waits and writes them to SSA_CHOL_TRACE_FILE as uint64 triples (wall_clock64 ticks of 10 ns)
+//   big=N       fused rounds: rounds with at least N update tiles run the chain in its big-strip form (default 1536)
+//   finish=0    TIMING EXPERIMENT, WRONG SOLVES: no finishing passes at all (what do they cost the schedule?)
+//   mirror=0    TIMING EXPERIMENT, WRONG SOLVES: finishing passes without the L^T mirror and the inverse transposes
+// A value that is set is reported once per distinct string on stderr: a stray variable must not change a production
+// schedule silently.
 struct CholDebug {
-    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0, early = 1;
-    int64_t tail = -1;
+    int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0, early = 1, finish = 1, mirror = 1;
+    int fuse = -1, kdepth = -1;
+    int64_t tail = -1, cpos = -1, big = -1, wgtime = -1;
 };
 inline CholDebug chol_debug() {
     CholDebug d;
     const char *e = getenv("SSA_CHOL_DEBUG");
-    if (e == nullptr) return d;
+    if (e == nullptr || *e == 0) return d;
     std::string str(e);
+    {
+        static std::mutex seen_mutex;
+        static std::vector<std::string> seen;
+        std::lock_guard<std::mutex> lock(seen_mutex);
+        if (std::find(seen.begin(), seen.end(), str) == seen.end()) {
+            seen.push_back(str);
+            fprintf(stderr, "superscreen_hip: SSA_CHOL_DEBUG=%s changes the Cholesky schedule (debugging aid)\n", e);
+        }
+    }
     size_t pos = 0;
     while (pos < str.size()) {
         size_t end = str.find(',', pos);
@@ -540,6 +584,13 @@ inline CholDebug chol_debug() {
             else if (key == "look") d.look = static_cast<int>(val);
             else if (key == "early") d.early = static_cast<int>(val);
             else if (key == "trace") d.trace = static_cast<int>(val);
+            else if (key == "finish") d.finish = static_cast<int>(val);
+            else if (key == "mirror") d.mirror = static_cast<int>(val);
+            else if (key == "fuse") d.fuse = static_cast<int>(val);
+            else if (key == "kdepth") d.kdepth = static_cast<int>(val);
+            else if (key == "cpos") d.cpos = val;
+            else if (key == "big") d.big = val;
+            else if (key == "wgtime") d.wgtime = val;
         }
         pos = end + 1;
     }
@@ -614,6 +665,32 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     int64_t nmax = 0;
     // (debugging, trace=1: one slot of register images per matrix and panel, zero where no round ran)
     double *trace_buf = nullptr;
+    struct TraceGuard {   // (every early return below frees the trace buffer; the device may still be writing it, so wait)
+        double *&p;
+        ~TraceGuard() {
+            if (p != nullptr) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(p);
+                p = nullptr;
+            }
+        }
+    } trace_guard{trace_buf};
+    constexpr int64_t kWgTimeCap = 16384;
+    unsigned long long *wg_times = nullptr;
+    struct WgTimeGuard {
+        unsigned long long *&p;
+        ~WgTimeGuard() {
+            if (p != nullptr) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(p);
+                p = nullptr;
+            }
+        }
+    } wg_time_guard{wg_times};
+    if (dbg.wgtime >= 0 && (hipMalloc(reinterpret_cast<void **>(&wg_times), kWgTimeCap * 3 * sizeof(unsigned long long)) != hipSuccess ||
+                            hipMemsetAsync(wg_times, 0, kWgTimeCap * 3 * sizeof(unsigned long long), st) != hipSuccess))
+        return SSA_ERR_HIP;
+    int64_t fused_round_index = 0;
     int64_t trace_panels = 0;
     if (dbg.trace && sizeof(T) == 8) {
         for (int i = 0; i < count; ++i) trace_panels = std::max<int64_t>(trace_panels, jobs[i].n / CNB);
@@ -626,6 +703,8 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         const CholJob<T> &J = jobs[i];
         CholLane &ln = lanes[i];
         plans[i].init(&jobs[i]);
+        plans[i].skip_all = dbg.finish == 0;
+        plans[i].skip_mirror = dbg.mirror == 0;
         if (J.n % CNB != 0) return SSA_ERR_INVALID_ARGUMENT;  // callers pad (potrf_padded_batch)
         if (J.lda > (int64_t(1) << 22)) return SSA_ERR_INVALID_ARGUMENT;  // 32-bit offsets inside a diagonal block
         if (J.n > nmax) nmax = J.n;
@@ -655,12 +734,14 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     //             of 256 / 512): the chain's products then wait for the update BEFORE the running one, i.e. never,
     //             and a single matrix' updates follow each other without the gap of two chain steps (round 5).
     // In float64 the factor does not depend on `look`, bit for bit: every tile still takes its panels in ascending order.
-    const int look = dbg.look > 0 ? dbg.look : (count == 1 ? 3 : 1);
     constexpr int kColRing = 8;
+    if (dbg.look > kColRing) return SSA_ERR_INVALID_ARGUMENT;   // (two outstanding look-ahead columns would share a ring slot)
+    const int look = dbg.look > 0 ? dbg.look : (count == 1 ? 3 : 1);
     int64_t pending_from[kMaxLanes] = {};
     int64_t tstart[kMaxLanes];
     int64_t col_from[kMaxLanes][kColRing] = {};
-    int col_writer[kMaxLanes][kColRing] = {};   // index of the last trailing update that covered the column (-1: none)
+    int col_writer[kMaxLanes][kColRing] = {};   // index of the last trailing update that covered the column (a slot is
+                                                // only read after the update that retires its column has set it)
     int n_syrk[kMaxLanes] = {};                 // trailing updates issued so far; update k records ev_syrk / ev_syrk2 by k & 1
     for (int i = 0; i < count; ++i) tstart[i] = CNB;
     auto slot = [](int64_t col) { return static_cast<int>((col / CNB) % kColRing); };
@@ -674,6 +755,21 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
     bool in_rounds = false;
+    // Fused rounds (chol_tail.hpp): ONE launch per round; per film and 256-wide block column the LEVEL = the column
+    // before which every panel has been applied to it.  A round's tile workgroups bring block columns from their level
+    // to c (the panels finished before the launch); its chain workgroups bring block column c + 256 to c + 256.
+    const bool fuse = dbg.fuse != 0 && nmax <= 255 * CNB;
+    const int kdepth = dbg.kdepth > 0 ? dbg.kdepth : 2;
+    // tile workgroups in front of a round's chain workgroups: what the chip starts while a diagonal block is factored
+    // beside running tiles (~ 0.28 ms: four waves of 512 tiles of K = 256), so that the chain workgroups find W ready
+    const int64_t chain_pos = dbg.cpos >= 0 ? dbg.cpos : 2048;
+    uint32_t panel_total[kMaxLanes] = {}, head_total[kMaxLanes] = {};
+    std::vector<int64_t> level[kMaxLanes];
+    uint32_t round_no[kMaxLanes] = {};
+    auto col_tiles = [](int64_t n, int64_t col) {   // 128 x 128 tiles on or below the diagonal in the block column at `col`
+        const int64_t ntm = n / 128, t = col / 128;
+        return (ntm - t) + (ntm - t - 1);
+    };
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
         const int64_t c = k0 + CNB;   // first column of the next panel
         if (dbg.sync && hipDeviceSynchronize() != hipSuccess) return SSA_ERR_HIP;
@@ -711,6 +807,16 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 const T *P = J.A + c * J.lda + upd0;
                 strips[ns++] = SmallNtJob{P, P, nullptr, J.A + c * J.lda + c, J.lda, J.lda, J.lda, right, CNB, c - upd0,
                                           -1.0, 1.0, 0};
+                if (fuse) {
+                    // the levels the stream part leaves behind: the trailing region has every panel before pending_from,
+                    // a look-ahead column what it had when it left that region
+                    level[i].assign(static_cast<size_t>(J.n / CNB), 0);
+                    for (int64_t b = c + CNB; b < J.n; b += CNB)
+                        level[i][b / CNB] = (b >= tstart[i]) ? pending_from[i] : col_from[i][slot(b)];
+                    uint32_t *flags = reinterpret_cast<uint32_t *>(J.aux + aux_layout(J.n).flags);
+                    if (hipMemsetAsync(flags, 0, kRoundFlagWords * sizeof(uint32_t), st) != hipSuccess) return SSA_ERR_HIP;
+                    continue;
+                }
                 // look-ahead columns right of c catch up with the region the updates maintained: from here on
                 // A[c + 256:, c + 256:] is one trailing matrix again, every panel before pending_from applied
                 for (int64_t b = c + CNB; b < tstart[i] && b < J.n; b += CNB) {
@@ -726,6 +832,83 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             rc = small_batch_t(static_cast<const T *>(nullptr), ns, strips, st);
             if (rc != SSA_OK) return rc;
             in_rounds = true;
+        }
+        if (in_rounds && fuse) {
+            // ---- one round of every film as ONE launch (chol_tail.hpp, "Fused rounds")
+            FusedRoundJob fj[kMaxLanes];
+            int nf = 0;
+            int64_t tiles = 0;
+            for (int i = 0; i < count; ++i) {
+                const CholJob<T> &J = jobs[i];
+                if (c >= J.n) continue;
+                FusedRoundJob &r = fj[nf++];
+                r = FusedRoundJob{};
+                r.A = J.A;
+                r.lda = J.lda;
+                r.n = J.n;
+                r.c = c;
+                r.W = chol_leaf(J, c);
+                r.scratch = J.aux + aux_layout(J.n).scratch;
+                r.info = J.info;
+                r.ldw = static_cast<int>(SNB);
+                r.flags = reinterpret_cast<uint32_t *>(J.aux + aux_layout(J.n).flags);
+                r.round_no = ++round_no[i];
+                if (trace_buf != nullptr)
+                    r.trace = trace_buf + (static_cast<int64_t>(i) * trace_panels + c / CNB) * cholk2::kScratchElems;
+                r.strip_from = c;
+                if (c + CNB < J.n) {
+                    r.strip_from = level[i][(c + CNB) / CNB];
+                    level[i][(c + CNB) / CNB] = c + CNB;
+                }
+                // Tiles: the block column two ahead takes everything that is pending for it (the next round's strip then
+                // runs with K = 512); a column further right is served every `kdepth`-th round, i.e. with K = 512 --
+                // one pass over its C tiles per two panels --, columns of even and odd index taking turns.
+                int64_t end = c + 2 * CNB;
+                for (int64_t b = c + 2 * CNB, q = 0; b < J.n && q < kRoundMaxBlockCols; b += CNB, ++q) {
+                    const int64_t avail = c - level[i][b / CNB];
+                    const bool serve = avail > 0 && (q == 0 || ((b + c) / CNB) % kdepth == 0);
+                    r.level[q] = serve ? level[i][b / CNB] : c;
+                    if (serve) {
+                        level[i][b / CNB] = c;
+                        tiles += col_tiles(J.n, b);
+                    }
+                    end = b + CNB;
+                }
+                r.tile_cols_end = std::min(end, J.n);
+            }
+            const bool exclusive = dbg.excl && tiles <= tail_excl_tiles;
+            const bool big = tiles >= (dbg.big >= 0 ? dbg.big : 1536);
+            {   // (the panel workgroups of a big-strip round count themselves in FLAG_PANEL, the heads of a small-form
+                // round in FLAG_HEAD: running totals per film)
+                int k = 0;
+                for (int i = 0; i < count; ++i) {
+                    if (c >= jobs[i].n) continue;
+                    const uint32_t rows32 = static_cast<uint32_t>(std::max<int64_t>(0, jobs[i].n - c - CNB) / 32);
+                    if (big) panel_total[i] += rows32;
+                    else head_total[i] += std::min<uint32_t>(8u, rows32);
+                    fj[k].panel_target = panel_total[i];
+                    fj[k++].head_target = head_total[i];
+                }
+            }
+            rc = fused_round_t(static_cast<const T *>(nullptr), nf, fj, exclusive ? 1 : 0, chain_pos, big ? 1 : 0, st,
+                               (fused_round_index == dbg.wgtime) ? wg_times : nullptr, kWgTimeCap);
+            ++fused_round_index;
+            if (rc != SSA_OK) return rc;
+            if (tiles <= fill_tiles && !dbg.late) {
+                for (int i = 0; i < count; ++i) {
+                    FinishPlan<T> &fp = plans[i];
+                    CholLane &ln = lanes[i];
+                    const int64_t ready = c / SNB;
+                    if (detached[i] || fp.finished() || ready <= fp.done || fp.done >= fp.nfull()) continue;
+                    if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess)
+                        return SSA_ERR_HIP;
+                    rc = fp.run_blocks(ready, true, ln.finish);
+                    if (rc != SSA_OK) return rc;
+                    if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
+                    on_finish[i] = true;
+                }
+            }
+            continue;
         }
         if (in_rounds) {
             // ---- one round of every film on the caller's stream.  State of a film at this point: block column c has
@@ -877,12 +1060,26 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         rc = plans[i].run_rest(false, st);
         if (rc != SSA_OK) return rc;
     }
+    if (wg_times != nullptr) {   // (debugging: the host waits here)
+        std::vector<unsigned long long> host(static_cast<size_t>(kWgTimeCap) * 3);
+        const bool ok = hipStreamSynchronize(st) == hipSuccess &&
+                        hipMemcpy(host.data(), wg_times, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+        const char *path = getenv("SSA_CHOL_TRACE_FILE");
+        if (ok && path != nullptr) {
+            if (FILE *f = fopen(path, "wb")) {
+                fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+                fclose(f);
+            }
+        }
+        if (!ok) return SSA_ERR_HIP;
+    }
     if (trace_buf != nullptr) {   // (debugging: the host waits here)
         const size_t elems = static_cast<size_t>(count) * trace_panels * cholk2::kScratchElems;
         std::vector<double> host(elems);
         const bool ok = hipStreamSynchronize(st) == hipSuccess &&
                         hipMemcpy(host.data(), trace_buf, elems * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
         (void)hipFree(trace_buf);
+        trace_buf = nullptr;
         const char *path = getenv("SSA_CHOL_TRACE_FILE");
         if (ok && path != nullptr) {
             if (FILE *f = fopen(path, "wb")) {

@@ -14,6 +14,9 @@
 #   hunt:<reps>      tools/chol_race_hunt.py <reps>: cold factorizations of the 4-film stack, bit-compared
 #   repeat:<reps>    tools/config5_repeat.py <reps>: config 5 in both self-field modes, bit-compared
 #   qform            tools/q_form_timing.py: Q assembly, one-shot pieces against strips
+#   timeline:<kind>  rocprofv3 kernel trace of tools/fact_timeline.py run <kind> (float64|float32|stack4|single), then its
+#                    `table` (SYRK launches in situ / alone / beside) and `rounds` listings
+#   ab:<args>        tools/ab_knobs.py <args> (SSA_CHOL_DEBUG variants taking turns in one process)
 #   py:<script and args>   any tool, e.g. "py:tools/fact_single.py 129"
 #   env:<NAME=VALUE>       exported for the steps that follow (e.g. env:SSA_CHOL_DEBUG=late=1)
 tag=$1; shift
@@ -40,6 +43,16 @@ for step in "$@"; do
               echo "repeat rc=$? $(tail -1 $out/config5_repeat.txt)" >> $sum ;;
     qform)    timeout 900 python -X faulthandler tools/q_form_timing.py $arg > $out/q_form_timing.txt 2>&1
               echo "qform rc=$?" >> $sum ;;
+    timeline) kind=${arg:-float64}; td=/tmp/ssa_ft_${tag}_${kind}; rm -rf $td
+              here=$PWD; (cd /tmp && TMPDIR=/tmp timeout 900 rocprofv3 --kernel-trace --output-format csv -d $td -- python3 $here/tools/fact_timeline.py run $kind) > $out/timeline_$kind.log 2>&1
+              echo "timeline[$kind] trace rc=$?" >> $sum
+              nf=2; unk=""; [ "$kind" = stack4 ] && { nf=4; unk="24571 24571 24571 24571"; }; [ "$kind" = single ] && { nf=1; unk="41419"; }
+              timeout 600 python tools/fact_timeline.py rounds $td $nf > $out/round_timeline_$kind.txt 2>&1
+              [ "$kind" != float32 ] && timeout 900 python tools/fact_timeline.py table $td $unk > $out/syrk_launch_table_$kind.txt 2>&1
+              echo "timeline[$kind] $(tail -2 $out/syrk_launch_table_$kind.txt 2>/dev/null | head -1)" >> $sum ;;
+    ab)       log=$out/ab_$(echo "$arg" | tr ' /="' '____' | cut -c1-60).log
+              eval "timeout 1500 python -X faulthandler tools/ab_knobs.py $arg" > $log 2>&1
+              echo "ab[$arg] rc=$?" >> $sum; cat $log >> $sum ;;
     py)       log=$out/$(echo "$arg" | tr ' /' '__').log
               timeout 1200 python -X faulthandler $arg > $log 2>&1
               echo "py[$arg] rc=$? $(tail -1 $log)" >> $sum ;;
