@@ -184,15 +184,6 @@ inline int tail_round_t(const float *, int n, const TailRoundJob *jobs, int excl
     return chol_tail_round_f32(n, jobs, exclusive, st);
 }
 
-inline int fused_round_t(const double *, int n, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big, hipStream_t st,
-                         unsigned long long *wg_times, int64_t cap) {
-    return chol_fused_round_f64(n, jobs, exclusive, chain_pos, big, st, wg_times, cap);
-}
-inline int fused_round_t(const float *, int n, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big, hipStream_t st,
-                         unsigned long long *wg_times, int64_t cap) {
-    return chol_fused_round_f32(n, jobs, exclusive, chain_pos, big, st, wg_times, cap);
-}
-
 #ifndef SSA_SNB
 #define SSA_SNB 4096
 #endif
@@ -200,7 +191,7 @@ constexpr int64_t SNB = SSA_SNB;  // block size of the triangular solves (pre-in
 
 // aux layout (elements):  inv [nblk][SNB][SNB] | invT [nblk][SNB][SNB] | tmp | scratch
 struct AuxLayout {
-    int64_t nblk, nfull, inv, invT, tmp, scratch, flags, total;
+    int64_t nblk, nfull, inv, invT, tmp, scratch, total;
 };
 inline AuxLayout aux_layout(int64_t n) {
     AuxLayout a;
@@ -213,9 +204,7 @@ inline AuxLayout aux_layout(int64_t n) {
     // scratch of the diagonal-block kernel: one register image per lower 16 x 16 tile of the 256 x 256 block
     // (chol_diag2.hpp: 34 816 elements of the type the block is factored in -- float64 for both routes, so twice as
     // many elements of a float32 matrix)
-    // the words the workgroups of a fused round launch synchronise through (chol_tail.hpp, kRoundFlagWords)
-    a.flags = a.scratch + 2 * cholk2::kScratchElems;
-    a.total = a.flags + 64;
+    a.total = a.scratch + 2 * cholk2::kScratchElems;
     return a;
 }
 
@@ -535,22 +524,13 @@ struct FinishPlan {
 //   trace=1     every diagonal-block workgroup of a round stores the block AS IT READ IT (register images, 272 KB);
 //               after the schedule the host waits and writes all of them to the file SSA_CHOL_TRACE_FILE:
 //               [matrix][panel][34 816] float64 (float64 matrices only)
-//   fuse=0      rounds as three launches (round / panel / strip: the form of rounds 4 and 5) instead of ONE launch whose
-//               workgroups hand over through device-side flags (chol_tail.hpp, "Fused rounds")
-//   kdepth=D    fused rounds: a block column behind the next two is served when D panels are pending for it (default 2:
-//               every other round with K = 512; 1: every round with K = 256)
-//   cpos=N      fused rounds: N tile workgroups in front of the chain workgroups in the grid (default 2048)
-//   wgtime=R    fused rounds: every workgroup of round R (0-based) records {role, start, end}; after the schedule the host
-//               waits and writes them to SSA_CHOL_TRACE_FILE as uint64 triples (wall_clock64 ticks of 10 ns)
-//   big=N       fused rounds: rounds with at least N update tiles run the chain in its big-strip form (default 1536)
 //   finish=0    TIMING EXPERIMENT, WRONG SOLVES: no finishing passes at all (what do they cost the schedule?)
 //   mirror=0    TIMING EXPERIMENT, WRONG SOLVES: finishing passes without the L^T mirror and the inverse transposes
 // A value that is set is reported once per distinct string on stderr: a stray variable must not change a production
 // schedule silently.
 struct CholDebug {
     int split = -1, late = 0, delay = 1, sync = 0, excl = 1, trace = 0, look = 0, early = 1, finish = 1, mirror = 1;
-    int fuse = -1, kdepth = -1;
-    int64_t tail = -1, cpos = -1, big = -1, wgtime = -1;
+    int64_t tail = -1;
 };
 inline CholDebug chol_debug() {
     CholDebug d;
@@ -586,11 +566,6 @@ inline CholDebug chol_debug() {
             else if (key == "trace") d.trace = static_cast<int>(val);
             else if (key == "finish") d.finish = static_cast<int>(val);
             else if (key == "mirror") d.mirror = static_cast<int>(val);
-            else if (key == "fuse") d.fuse = static_cast<int>(val);
-            else if (key == "kdepth") d.kdepth = static_cast<int>(val);
-            else if (key == "cpos") d.cpos = val;
-            else if (key == "big") d.big = val;
-            else if (key == "wgtime") d.wgtime = val;
         }
         pos = end + 1;
     }
@@ -675,22 +650,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             }
         }
     } trace_guard{trace_buf};
-    constexpr int64_t kWgTimeCap = 16384;
-    unsigned long long *wg_times = nullptr;
-    struct WgTimeGuard {
-        unsigned long long *&p;
-        ~WgTimeGuard() {
-            if (p != nullptr) {
-                (void)hipDeviceSynchronize();
-                (void)hipFree(p);
-                p = nullptr;
-            }
-        }
-    } wg_time_guard{wg_times};
-    if (dbg.wgtime >= 0 && (hipMalloc(reinterpret_cast<void **>(&wg_times), kWgTimeCap * 3 * sizeof(unsigned long long)) != hipSuccess ||
-                            hipMemsetAsync(wg_times, 0, kWgTimeCap * 3 * sizeof(unsigned long long), st) != hipSuccess))
-        return SSA_ERR_HIP;
-    int64_t fused_round_index = 0;
     int64_t trace_panels = 0;
     if (dbg.trace && sizeof(T) == 8) {
         for (int i = 0; i < count; ++i) trace_panels = std::max<int64_t>(trace_panels, jobs[i].n / CNB);
@@ -755,21 +714,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
     hipStream_t cur_us[kMaxLanes];
     for (int i = 0; i < count; ++i) cur_us[i] = split_updates ? lanes[i].upd : st;
     bool in_rounds = false;
-    // Fused rounds (chol_tail.hpp): ONE launch per round; per film and 256-wide block column the LEVEL = the column
-    // before which every panel has been applied to it.  A round's tile workgroups bring block columns from their level
-    // to c (the panels finished before the launch); its chain workgroups bring block column c + 256 to c + 256.
-    const bool fuse = dbg.fuse != 0 && nmax <= 255 * CNB;
-    const int kdepth = dbg.kdepth > 0 ? dbg.kdepth : 2;
-    // tile workgroups in front of a round's chain workgroups: what the chip starts while a diagonal block is factored
-    // beside running tiles (~ 0.28 ms: four waves of 512 tiles of K = 256), so that the chain workgroups find W ready
-    const int64_t chain_pos = dbg.cpos >= 0 ? dbg.cpos : 2048;
-    uint32_t panel_total[kMaxLanes] = {}, head_total[kMaxLanes] = {};
-    std::vector<int64_t> level[kMaxLanes];
-    uint32_t round_no[kMaxLanes] = {};
-    auto col_tiles = [](int64_t n, int64_t col) {   // 128 x 128 tiles on or below the diagonal in the block column at `col`
-        const int64_t ntm = n / 128, t = col / 128;
-        return (ntm - t) + (ntm - t - 1);
-    };
     for (int64_t k0 = 0; k0 + CNB < nmax; k0 += CNB) {
         const int64_t c = k0 + CNB;   // first column of the next panel
         if (dbg.sync && hipDeviceSynchronize() != hipSuccess) return SSA_ERR_HIP;
@@ -807,16 +751,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
                 const T *P = J.A + c * J.lda + upd0;
                 strips[ns++] = SmallNtJob{P, P, nullptr, J.A + c * J.lda + c, J.lda, J.lda, J.lda, right, CNB, c - upd0,
                                           -1.0, 1.0, 0};
-                if (fuse) {
-                    // the levels the stream part leaves behind: the trailing region has every panel before pending_from,
-                    // a look-ahead column what it had when it left that region
-                    level[i].assign(static_cast<size_t>(J.n / CNB), 0);
-                    for (int64_t b = c + CNB; b < J.n; b += CNB)
-                        level[i][b / CNB] = (b >= tstart[i]) ? pending_from[i] : col_from[i][slot(b)];
-                    uint32_t *flags = reinterpret_cast<uint32_t *>(J.aux + aux_layout(J.n).flags);
-                    if (hipMemsetAsync(flags, 0, kRoundFlagWords * sizeof(uint32_t), st) != hipSuccess) return SSA_ERR_HIP;
-                    continue;
-                }
                 // look-ahead columns right of c catch up with the region the updates maintained: from here on
                 // A[c + 256:, c + 256:] is one trailing matrix again, every panel before pending_from applied
                 for (int64_t b = c + CNB; b < tstart[i] && b < J.n; b += CNB) {
@@ -832,83 +766,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
             rc = small_batch_t(static_cast<const T *>(nullptr), ns, strips, st);
             if (rc != SSA_OK) return rc;
             in_rounds = true;
-        }
-        if (in_rounds && fuse) {
-            // ---- one round of every film as ONE launch (chol_tail.hpp, "Fused rounds")
-            FusedRoundJob fj[kMaxLanes];
-            int nf = 0;
-            int64_t tiles = 0;
-            for (int i = 0; i < count; ++i) {
-                const CholJob<T> &J = jobs[i];
-                if (c >= J.n) continue;
-                FusedRoundJob &r = fj[nf++];
-                r = FusedRoundJob{};
-                r.A = J.A;
-                r.lda = J.lda;
-                r.n = J.n;
-                r.c = c;
-                r.W = chol_leaf(J, c);
-                r.scratch = J.aux + aux_layout(J.n).scratch;
-                r.info = J.info;
-                r.ldw = static_cast<int>(SNB);
-                r.flags = reinterpret_cast<uint32_t *>(J.aux + aux_layout(J.n).flags);
-                r.round_no = ++round_no[i];
-                if (trace_buf != nullptr)
-                    r.trace = trace_buf + (static_cast<int64_t>(i) * trace_panels + c / CNB) * cholk2::kScratchElems;
-                r.strip_from = c;
-                if (c + CNB < J.n) {
-                    r.strip_from = level[i][(c + CNB) / CNB];
-                    level[i][(c + CNB) / CNB] = c + CNB;
-                }
-                // Tiles: the block column two ahead takes everything that is pending for it (the next round's strip then
-                // runs with K = 512); a column further right is served every `kdepth`-th round, i.e. with K = 512 --
-                // one pass over its C tiles per two panels --, columns of even and odd index taking turns.
-                int64_t end = c + 2 * CNB;
-                for (int64_t b = c + 2 * CNB, q = 0; b < J.n && q < kRoundMaxBlockCols; b += CNB, ++q) {
-                    const int64_t avail = c - level[i][b / CNB];
-                    const bool serve = avail > 0 && (q == 0 || ((b + c) / CNB) % kdepth == 0);
-                    r.level[q] = serve ? level[i][b / CNB] : c;
-                    if (serve) {
-                        level[i][b / CNB] = c;
-                        tiles += col_tiles(J.n, b);
-                    }
-                    end = b + CNB;
-                }
-                r.tile_cols_end = std::min(end, J.n);
-            }
-            const bool exclusive = dbg.excl && tiles <= tail_excl_tiles;
-            const bool big = tiles >= (dbg.big >= 0 ? dbg.big : 1536);
-            {   // (the panel workgroups of a big-strip round count themselves in FLAG_PANEL, the heads of a small-form
-                // round in FLAG_HEAD: running totals per film)
-                int k = 0;
-                for (int i = 0; i < count; ++i) {
-                    if (c >= jobs[i].n) continue;
-                    const uint32_t rows32 = static_cast<uint32_t>(std::max<int64_t>(0, jobs[i].n - c - CNB) / 32);
-                    if (big) panel_total[i] += rows32;
-                    else head_total[i] += std::min<uint32_t>(8u, rows32);
-                    fj[k].panel_target = panel_total[i];
-                    fj[k++].head_target = head_total[i];
-                }
-            }
-            rc = fused_round_t(static_cast<const T *>(nullptr), nf, fj, exclusive ? 1 : 0, chain_pos, big ? 1 : 0, st,
-                               (fused_round_index == dbg.wgtime) ? wg_times : nullptr, kWgTimeCap);
-            ++fused_round_index;
-            if (rc != SSA_OK) return rc;
-            if (tiles <= fill_tiles && !dbg.late) {
-                for (int i = 0; i < count; ++i) {
-                    FinishPlan<T> &fp = plans[i];
-                    CholLane &ln = lanes[i];
-                    const int64_t ready = c / SNB;
-                    if (detached[i] || fp.finished() || ready <= fp.done || fp.done >= fp.nfull()) continue;
-                    if (hipEventRecord(ln.ev_fork, st) != hipSuccess || hipStreamWaitEvent(ln.finish, ln.ev_fork, 0) != hipSuccess)
-                        return SSA_ERR_HIP;
-                    rc = fp.run_blocks(ready, true, ln.finish);
-                    if (rc != SSA_OK) return rc;
-                    if (hipEventRecord(ln.ev_finish, ln.finish) != hipSuccess) return SSA_ERR_HIP;
-                    on_finish[i] = true;
-                }
-            }
-            continue;
         }
         if (in_rounds) {
             // ---- one round of every film on the caller's stream.  State of a film at this point: block column c has
@@ -1059,19 +916,6 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         if (plans[i].finished()) continue;
         rc = plans[i].run_rest(false, st);
         if (rc != SSA_OK) return rc;
-    }
-    if (wg_times != nullptr) {   // (debugging: the host waits here)
-        std::vector<unsigned long long> host(static_cast<size_t>(kWgTimeCap) * 3);
-        const bool ok = hipStreamSynchronize(st) == hipSuccess &&
-                        hipMemcpy(host.data(), wg_times, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
-        const char *path = getenv("SSA_CHOL_TRACE_FILE");
-        if (ok && path != nullptr) {
-            if (FILE *f = fopen(path, "wb")) {
-                fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
-                fclose(f);
-            }
-        }
-        if (!ok) return SSA_ERR_HIP;
     }
     if (trace_buf != nullptr) {   // (debugging: the host waits here)
         const size_t elems = static_cast<size_t>(count) * trace_panels * cholk2::kScratchElems;

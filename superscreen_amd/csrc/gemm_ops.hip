@@ -237,15 +237,10 @@ constexpr int SBM = 32;
 constexpr int SNST = 4;   // LDS ring: with 16 MFMAs per wave and stage a stage computes in 0.5 us, a load takes 1-3 us:
                           // three stages are kept in flight (one-stage prefetch made the tile latency 16 x one memory
                           // round trip = 50 us whatever its size)
-template <int NST>
-struct SmallSmemN {
-    double a[NST][SBM * KC];
-    double b[NST][BN * KC];
+struct SmallSmem {
+    double a[SNST][SBM * KC];
+    double b[SNST][BN * KC];
 };
-using SmallSmem = SmallSmemN<SNST>;   // 80 KiB: one workgroup per CU (the stand-alone small launches)
-// the chain workgroups of a fused round launch (chol_tail.hpp) share their launch with 128 x 128 tiles, two workgroups
-// per CU: their ring has three stages (60 KiB, less than the tiles' 72 KiB)
-constexpr int kFusedChainStages = 3;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -255,15 +250,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
-template <typename T, int NST = SNST>
+template <typename T>
 __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double *__restrict__ A, int64_t lda8,
                                               const double *__restrict__ B, int64_t ldb8, T beta, T *__restrict__ C,
                                               int64_t ldc, int64_t m0, int64_t n0, char *smem_raw) {
     // A, B: 8-byte views (float32: pairs of consecutive k); K8, lda8, ldb8 in 8-byte units
     using MF = Mfma<T>;
     using acc_t = typename MF::acc_t;
-    static_assert(NST >= 2 && NST <= 4, "the waits below know up to three stages in flight");
-    SmallSmemN<NST> &sm = *reinterpret_cast<SmallSmemN<NST> *>(smem_raw);
+    SmallSmem &sm = *reinterpret_cast<SmallSmem *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int swz = 2 * ((li >> 1) & 7);
@@ -279,7 +273,7 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
         bsrc[u] = B + (n0 + row) * ldb8 + (kpos ^ (2 * ((row >> 1) & 7)));
     }
     auto issue = [&](int64_t kt) {
-        const int stage = static_cast<int>(kt % NST);
+        const int stage = static_cast<int>(kt % SNST);
         glds16(asrc + kt * KC, sm.a[stage] + 8 * wave * KC);
 #pragma unroll
         for (int u = 0; u < 4; ++u) glds16(bsrc[u] + kt * KC, sm.b[stage] + 8 * (wave + 4 * u) * KC);
@@ -308,12 +302,12 @@ __device__ __forceinline__ void tile_small_nt(int64_t K8, T alpha, const double 
         }
     const int64_t nk = K8 / KC;
 #pragma unroll
-    for (int p = 0; p < NST - 1; ++p)
+    for (int p = 0; p < SNST - 1; ++p)
         if (p < nk) issue(p);
     for (int64_t kt = 0; kt < nk; ++kt) {
-        const int cur = static_cast<int>(kt % NST);
-        if (kt + NST - 1 < nk) issue(kt + NST - 1);   // into the slot that was read at step kt - 1 (barrier below)
-        const int64_t ahead = (nk - 1 - kt < NST - 1) ? nk - 1 - kt : NST - 1;   // stages issued after stage kt
+        const int cur = static_cast<int>(kt % SNST);
+        if (kt + SNST - 1 < nk) issue(kt + SNST - 1);   // into the slot that was read at step kt - 1 (barrier below)
+        const int64_t ahead = nk - 1 - kt;               // stages issued after stage kt: min(SNST - 1, ahead)
         if (ahead >= 3) wait_vmcnt<15>();
         else if (ahead == 2) wait_vmcnt<10>();
         else if (ahead == 1) wait_vmcnt<5>();
@@ -766,315 +760,6 @@ int chol_tail_round_f64(int nfilms, const TailRoundJob *jobs, int exclusive, hip
 }
 int chol_tail_round_f32(int nfilms, const TailRoundJob *jobs, int exclusive, hipStream_t st) {
     return chol_tail_round<float>(nfilms, jobs, exclusive, st);
-}
-
-// ---- fused rounds (chol_tail.hpp, "Fused rounds") ------------------------------------------------------------------
-// Device-side hand-offs between the workgroups of ONE launch.  The forms are MI355X_MICROARCH.md's valid forms
-// ("Workgroup dispatch, XCD placement & inter-workgroup visibility"); tools/isa_lint.py checks in the built code that
-// every buffer_wbl2 is followed by an s_waitcnt vmcnt(0) before the next store or atomic (the compiler drops that wait
-// when it can prove the wave's counter empty; the inline asm below is what keeps it).
-constexpr int kSpinLimit = 1 << 21;   // polls of ~ 1 us: a wait gives up after ~ 2 s (info = -3)
-
-// Producer side, called by EVERY thread of the workgroup after its stores: the flag moves by `add`.
-__device__ __forceinline__ void publish_add(uint32_t *flag, uint32_t add) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(flag, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-// Consumer side, called by EVERY thread of the workgroup before its loads of the handed-off data: one lane polls.
-// Returns false after kSpinLimit polls (the caller reports it; it goes on so that the launch ends).
-__device__ __forceinline__ bool wait_at_least(uint32_t *flag, uint32_t target, int *lds_word) {
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > kSpinLimit) {
-                ok = false;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *lds_word = ok ? 1 : 0;
-    }
-    __syncthreads();
-    const bool ok = *lds_word != 0;
-    __syncthreads();   // (the word is reused by the next wait)
-    return ok;
-}
-
-// Tiles (tm, tn) of a film's round: tn runs over the SERVED tile columns col[0] < col[1] < ... (offsets from t0), tm over
-// tn .. ntm - 1; enumerated in bands of 8 tile rows (first band at row t0), column by column inside a band -- the order
-// of lower_band_tile: 64 consecutive ids touch 8 row blocks and about 8 column blocks of the panels.
-// The columns come in pairs (the two tile columns of a 256-wide block column): colq[] holds the block columns.
-__host__ __device__ inline int64_t served_col(int64_t t0, const uint8_t *colq, int k) { return t0 + 2 * colq[k >> 1] + (k & 1); }
-// Tiles of the band of rows r0 .. r0 + R - 1; `nfull` = served columns left of r0 (R rows each) on return.
-__host__ __device__ inline int64_t served_band_count(int64_t r0, int64_t R, int64_t t0, const uint8_t *colq, int ncols, int &nfull) {
-    int k = 0;
-    while (k < ncols && served_col(t0, colq, k) < r0) ++k;
-    nfull = k;
-    int64_t n = static_cast<int64_t>(k) * R;
-    for (; k < ncols && served_col(t0, colq, k) < r0 + R; ++k) n += r0 + R - served_col(t0, colq, k);   // rows col .. r0 + R - 1
-    return n;
-}
-__host__ __device__ inline int64_t served_tiles(int64_t ntm, int64_t t0, const uint8_t *col, int ncols) {
-    int64_t n = 0;
-    int nfull;
-    for (int64_t r0 = t0; r0 < ntm; r0 += 8) n += served_band_count(r0, (ntm - r0 < 8) ? ntm - r0 : 8, t0, col, ncols, nfull);
-    return n;
-}
-// id -> (tm, k): tile row and index into col[]
-__device__ __forceinline__ void served_band_tile(int64_t id, int64_t ntm, int64_t t0, const uint8_t *col, int ncols, int64_t &tm,
-                                                 int &k) {
-    int64_t r0 = t0, R = 8;
-    int nfull = 0;
-    for (;; r0 += 8) {
-        R = (ntm - r0 < 8) ? ntm - r0 : 8;
-        const int64_t cnt = served_band_count(r0, R, t0, col, ncols, nfull);
-        if (id < cnt || r0 + 8 >= ntm) break;
-        id -= cnt;
-    }
-    if (id < static_cast<int64_t>(nfull) * R) {
-        k = static_cast<int>(id / R);
-        tm = r0 + id % R;
-        return;
-    }
-    id -= static_cast<int64_t>(nfull) * R;
-    k = nfull;
-    while (k + 1 < ncols) {
-        const int64_t rows = r0 + R - served_col(t0, col, k);   // rows of this column inside the band
-        if (id < rows) break;
-        id -= rows;
-        ++k;
-    }
-    tm = served_col(t0, col, k) + id;
-}
-
-struct FusedRoundArgs {
-    int nfilms, ndiag;
-    int big_strips, pad_;                // chain form: 0 = one workgroup per 32 rows (panel rows, then their strip on small tiles);
-                                         // 1 = panel workgroups, then the strip as 128 x 128 tiles of their own workgroups
-    int64_t ntiles, nchain, chain_pos;   // chain_pos tile workgroups come before the chain workgroups, the rest after
-    unsigned long long *wg_times;        // debugging (CholDebug wgtime): per workgroup {role, start, end} in wall-clock ticks
-    struct Film {
-        void *A, *W, *scratch, *trace;
-        int32_t *info;
-        uint32_t *flags;
-        int64_t lda, tile_begin, chain_begin;
-        int ntm, c, ldw, strip_from, t0, ncols, nrow32;
-        uint32_t round_no, panel_target, head_target;   // what FLAG_DIAG / FLAG_PANEL / FLAG_HEAD reach in this round
-        uint8_t col[kRoundMaxBlockCols];   // the served block columns (two tile columns each), in units of 256 columns from t0, ascending
-        uint8_t lvl[kRoundMaxBlockCols];   // their level (every panel before it is applied) in units of 256 columns
-    } f[kTailMaxFilms];
-};
-
-template <typename T>
-__global__ __launch_bounds__(kGemmThreads, 2) void chol_fused_round_kernel(FusedRoundArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ int wait_word;
-    const int64_t bid = blockIdx.x;
-    struct WgClock {   // (debugging: when did this workgroup run, and as what)
-        unsigned long long *slot, t0;
-        int role = 0;
-        __device__ WgClock(unsigned long long *base, int64_t b) : slot(base ? base + 3 * b : nullptr), t0(base ? wall_clock64() : 0) {}
-        __device__ ~WgClock() {
-            if (slot != nullptr && threadIdx.x == 0) {
-                slot[0] = static_cast<unsigned long long>(role);
-                slot[1] = t0;
-                slot[2] = wall_clock64();
-            }
-        }
-    } wg_clock(a.wg_times, bid);
-    if (bid < a.ndiag) {
-        wg_clock.role = 1;
-        // ---- diagonal block of one film
-        const FusedRoundArgs::Film &F = a.f[bid];
-        cholk2::chol_diag256_v2_body<cholk2::factor_t<T>, T>(static_cast<T *>(F.A) + static_cast<int64_t>(F.c) * (F.lda + 1),
-                                                             static_cast<int>(F.lda), static_cast<T *>(F.W), F.ldw,
-                                                             static_cast<cholk2::factor_t<T> *>(F.scratch), F.info, F.c + 1,
-                                                             smem_raw, static_cast<cholk2::factor_t<T> *>(F.trace));
-        publish_add(F.flags + kFlagDiag, 1u);
-        return;
-    }
-    // block ids: [diag][chain_pos tiles][chain][the other tiles]
-    const int64_t after_diag = bid - a.ndiag;
-    const bool is_chain = after_diag >= a.chain_pos && after_diag < a.chain_pos + a.nchain;
-    if (!is_chain) {
-        wg_clock.role = 2;
-        // ---- one 128 x 128 tile of a film's pending updates
-        const int64_t id = xcd_contiguous(after_diag < a.chain_pos ? after_diag : after_diag - a.nchain, a.ntiles);
-        int f = 0;
-        while (f + 1 < a.nfilms && id >= a.f[f + 1].tile_begin) ++f;
-        const FusedRoundArgs::Film &F = a.f[f];
-        int64_t tm;
-        int k;
-        served_band_tile(id - F.tile_begin, F.ntm, F.t0, F.col, F.ncols, tm, k);
-        const int64_t tn = served_col(F.t0, F.col, k);
-        const int64_t from = 256 * static_cast<int64_t>(F.lvl[k >> 1]);
-        const int64_t K = F.c - from;
-        if (K <= 0) return;
-        T *A = static_cast<T *>(F.A);
-        const T *P = A + from;
-        if constexpr (sizeof(T) == 8)
-            tile_full_f64<OP_N, OP_T>(K, -1.0, P, F.lda, P, F.lda, 1.0, A, F.lda, tm * BM, tn * BN, smem_raw);
-        else
-            tile_full_f32_nt(K, -1.0f, P, F.lda, P, F.lda, 1.0f, A, F.lda, tm * BM, tn * BN, smem_raw);
-        return;
-    }
-    // ---- chain
-    const int64_t l = after_diag - a.chain_pos;
-    int f = 0;
-    while (f + 1 < a.nfilms && l >= a.f[f + 1].chain_begin) ++f;
-    const FusedRoundArgs::Film &F = a.f[f];
-    constexpr int64_t per8 = 8 / sizeof(T);
-    T *A = static_cast<T *>(F.A);
-    const int64_t c = F.c, lda = F.lda;
-    const int64_t lc = l - F.chain_begin;
-    wg_clock.role = (a.big_strips && lc >= F.nrow32) ? 4 : 3;
-    if (a.big_strips && lc >= F.nrow32) {
-        // strip as 128 x 128 tiles (update-bound rounds: their work hides among the other tiles): tile (tm, tn) of block
-        // column c + 256; the panels before c need no flag, the new one every panel workgroup of the film
-        const int64_t ts = (c + 2 * BN) / BM, ls = lc - F.nrow32, col0 = F.ntm - ts;   // tiles in the first tile column
-        const int64_t tn = (ls < col0) ? ts : ts + 1, tm = (ls < col0) ? ts + ls : ts + 1 + (ls - col0);
-        const int64_t K1 = c - F.strip_from;
-        const T *P1 = A + F.strip_from, *P2 = A + c;
-        if (K1 > 0) {
-            if constexpr (sizeof(T) == 8)
-                tile_full_f64<OP_N, OP_T>(K1, -1.0, P1, lda, P1, lda, 1.0, A, lda, tm * BM, tn * BN, smem_raw);
-            else
-                tile_full_f32_nt(K1, -1.0f, P1, lda, P1, lda, 1.0f, A, lda, tm * BM, tn * BN, smem_raw);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the C tile is read back below)
-        }
-        if (!wait_at_least(F.flags + kFlagPanel, F.panel_target, &wait_word) && threadIdx.x == 0) atomicMin(F.info, -3);
-        if constexpr (sizeof(T) == 8)
-            tile_full_f64<OP_N, OP_T>(2 * BN, -1.0, P2, lda, P2, lda, 1.0, A, lda, tm * BM, tn * BN, smem_raw);
-        else
-            tile_full_f32_nt(2 * BN, -1.0f, P2, lda, P2, lda, 1.0f, A, lda, tm * BM, tn * BN, smem_raw);
-        return;
-    }
-    // 32 rows of the panel below the diagonal block (and, in the small form, the same rows of block column c + 256)
-    __builtin_amdgcn_s_setprio(3);
-    const int64_t rb = lc;                                      // 0 .. nrow32 - 1; 0 .. 7 are the head
-    const int64_t r0 = c + 2 * BN + rb * SBM;
-    bool ok = wait_at_least(F.flags + kFlagDiag, F.round_no, &wait_word);
-    {   // L21 rows = A21 rows W^T, in place: columns 128 .. 255 from all 256, then 0 .. 127 from the first 128
-        const double *A21 = reinterpret_cast<const double *>(A + r0 * lda + c);
-        const double *W = reinterpret_cast<const double *>(F.W);
-        const int64_t ldw8 = F.ldw / per8, lda8 = lda / per8;
-        T *C = A + r0 * lda + c;
-        tile_small_nt<T, kFusedChainStages>(2 * BN / per8, T(1), A21, lda8, W + BN * ldw8, ldw8, T(0), C + BN, lda, 0, 0, smem_raw);
-        tile_small_nt<T, kFusedChainStages>(BN / per8, T(1), A21, lda8, W, ldw8, T(0), C, lda, 0, 0, smem_raw);
-    }
-    if (a.big_strips) {
-        publish_add(F.flags + kFlagPanel, 1u);
-        if (!ok && threadIdx.x == 0) atomicMin(F.info, -3);
-        return;
-    }
-    const int64_t heads = (F.nrow32 < 8) ? F.nrow32 : 8;
-    if (rb < heads) {
-        publish_add(F.flags + kFlagHead, 1u);
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its own rows: read back below through this CU's L1 / L2)
-        __syncthreads();
-    }
-    ok = wait_at_least(F.flags + kFlagHead, F.head_target, &wait_word) && ok;
-    if (!ok && threadIdx.x == 0) atomicMin(F.info, -3);
-    {   // block column c + 256, rows r0 .. r0 + 31:  C -= P[rows] P[head rows]^T with the panels [strip_from, c + 256)
-        const int64_t from = F.strip_from, K = c + 2 * BN - from;
-        const double *Prow = reinterpret_cast<const double *>(A + r0 * lda + from);
-        const double *Phead = reinterpret_cast<const double *>(A + (c + 2 * BN) * lda + from);
-        T *C = A + r0 * lda + c + 2 * BN;
-        const int64_t lda8 = lda / per8;
-        tile_small_nt<T, kFusedChainStages>(K / per8, T(-1), Prow, lda8, Phead, lda8, T(1), C, lda, 0, 0, smem_raw);
-        tile_small_nt<T, kFusedChainStages>(K / per8, T(-1), Prow, lda8, Phead, lda8, T(1), C, lda, 0, BN, smem_raw);
-    }
-}
-
-template <typename T>
-int chol_fused_round(int nfilms, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big_strips, hipStream_t st,
-                     unsigned long long *wg_times, int64_t wg_capacity) {
-    if (nfilms <= 0 || nfilms > kTailMaxFilms) return SSA_ERR_INVALID_ARGUMENT;
-    FusedRoundArgs a{};
-    a.big_strips = big_strips ? 1 : 0;
-    double flops = 0.0;
-    for (int i = 0; i < nfilms; ++i) {
-        const FusedRoundJob &J = jobs[i];
-        if (J.n % (2 * BN) != 0 || J.c % (2 * BN) != 0 || J.c < 0 || J.c >= J.n || J.n > 255 * 256 ||   // (levels travel as 8-bit panel indices)
-           
-            (J.lda * sizeof(T)) % 16 != 0 || reinterpret_cast<uintptr_t>(J.A) % 16 != 0 || J.flags == nullptr)
-            return SSA_ERR_INVALID_ARGUMENT;
-        FusedRoundArgs::Film &F = a.f[a.nfilms++];
-        F.A = J.A;
-        F.W = J.W;
-        F.scratch = J.scratch;
-        F.trace = J.trace;
-        F.info = J.info;
-        F.flags = J.flags;
-        F.lda = J.lda;
-        F.ntm = static_cast<int>(J.n / BM);
-        F.c = static_cast<int>(J.c);
-        F.ldw = J.ldw;
-        F.round_no = J.round_no;
-        F.panel_target = J.panel_target;
-        F.head_target = J.head_target;
-        const int64_t below = J.n - J.c - 2 * BN;
-        F.nrow32 = static_cast<int>(below > 0 ? below / SBM : 0);
-        F.strip_from = static_cast<int>(J.strip_from);
-        if (F.nrow32 > 0 && (J.strip_from < 0 || J.strip_from > J.c || J.strip_from % (2 * BN) != 0))
-            return SSA_ERR_INVALID_ARGUMENT;
-        const int64_t first = (J.c + 4 * BN < J.n) ? J.c + 4 * BN : J.n;   // first column the tiles may cover
-        F.t0 = static_cast<int>(first / BM);
-        int64_t end = J.tile_cols_end;
-        if (end < first) end = first;
-        if (end > J.n || end % (2 * BN) != 0 || (end - first) / (2 * BN) > kRoundMaxBlockCols) return SSA_ERR_INVALID_ARGUMENT;
-        for (int64_t q = 0; q < (end - first) / (2 * BN); ++q) {
-            const int64_t lv = J.level[q];
-            if (lv < 0 || lv > J.c || lv % (2 * BN) != 0) return SSA_ERR_INVALID_ARGUMENT;
-            if (lv == J.c) continue;   // nothing pending (or not served in this round)
-            F.col[F.ncols / 2] = static_cast<uint8_t>(q);
-            F.lvl[F.ncols / 2] = static_cast<uint8_t>(lv / (2 * BN));
-            F.ncols += 2;
-            const int64_t col0 = F.t0 + 2 * q;   // two tile columns of (ntm - col) and (ntm - col - 1) tiles
-            flops += 2.0 * static_cast<double>(J.c - lv) * BM * BN * static_cast<double>(2 * (F.ntm - col0) - 1);
-        }
-        F.tile_begin = a.ntiles;
-        a.ntiles += served_tiles(F.ntm, F.t0, F.col, F.ncols);
-        F.chain_begin = a.nchain;
-        a.nchain += F.nrow32;
-        if (big_strips && F.nrow32 > 0) {   // + the 128 x 128 tiles of block column c + 256 (two tile columns)
-            const int64_t ts = (J.c + 2 * BN) / BM;
-            a.nchain += (F.ntm - ts) + (F.ntm - ts - 1);
-        }
-        if (F.nrow32 > 0)
-            flops += static_cast<double>(below) * (1.5 * 4.0 * BN * BN + 2.0 * 2 * BN * static_cast<double>(J.c + 2 * BN - J.strip_from));
-    }
-    a.ndiag = a.nfilms;   // every film of a round has a diagonal block
-    a.chain_pos = (chain_pos < 0 || chain_pos > a.ntiles) ? a.ntiles : chain_pos;
-    a.wg_times = (wg_times != nullptr && a.ndiag + a.ntiles + a.nchain <= wg_capacity) ? wg_times : nullptr;
-    constexpr size_t diag_lds = sizeof(cholk2::Smem<cholk2::factor_t<T>>);
-    const size_t base = sizeof(OpSmemF64) > diag_lds ? sizeof(OpSmemF64) : diag_lds;
-    static_assert(sizeof(SmallSmemN<kFusedChainStages>) <= sizeof(OpSmemF64), "the chain's ring must not cost the tiles a workgroup per CU");
-    static DeviceFlags flags;
-    if (raise_dynamic_lds(flags, {{reinterpret_cast<const void *>(&chol_fused_round_kernel<T>), kExclusiveLds}}) != SSA_OK)
-        return SSA_ERR_HIP;
-    ProfileScope scope(sizeof(T) == 8, kProfileRound, flops, st);
-    hipLaunchKernelGGL((chol_fused_round_kernel<T>), dim3(static_cast<unsigned>(a.ndiag + a.ntiles + a.nchain)),
-                       dim3(kGemmThreads), exclusive ? kExclusiveLds : base, st, a);
-    SSA_RETURN_IF_LAUNCH_FAILED();
-    return SSA_OK;
-}
-int chol_fused_round_f64(int nfilms, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big_strips, hipStream_t st,
-                         unsigned long long *wg_times, int64_t wg_capacity) {
-    return chol_fused_round<double>(nfilms, jobs, exclusive, chain_pos, big_strips, st, wg_times, wg_capacity);
-}
-int chol_fused_round_f32(int nfilms, const FusedRoundJob *jobs, int exclusive, int64_t chain_pos, int big_strips, hipStream_t st,
-                         unsigned long long *wg_times, int64_t wg_capacity) {
-    return chol_fused_round<float>(nfilms, jobs, exclusive, chain_pos, big_strips, st, wg_times, wg_capacity);
 }
 
 // used by chol.hip

@@ -553,66 +553,6 @@ def test_cholesky_lookahead_depth_does_not_change_the_factor(K, dtype, monkeypat
     assert float((got - x).abs().max() / x.abs().max()) < (1e-11 if dtype == "float64" else 2e-3)
 
 
-@pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_cholesky_round_forms_give_the_same_factor(K, dtype, monkeypatch):
-    """The last 10 240 columns of a factorization run as rounds.  Round 6: ONE launch per round whose workgroups hand
-    over through device-side flags (diagonal block -> panel rows -> next block column) and whose tiles serve the far
-    block columns every other round with K = 512 (a per-block-column level).  Every element still takes its panels in
-    ascending order: in float64 the factor and the block inverses are the same bits for the three-launch rounds of
-    rounds 4-5 (fuse=0), for every service depth and position of the chain workgroups in the grid, for no rounds at
-    all, and for two matrices of different order in one schedule; float32 to rounding."""
-    tdt = torch.float64 if dtype == "float64" else torch.float32
-    g = torch.Generator(device="cuda").manual_seed(11)
-    mats = []
-    for n in (12801, 9100):       # the larger one spends 10 rounds in the stream part, the smaller joins the rounds late
-        U = torch.randn(n, 24, dtype=torch.float64, device="cuda", generator=g)
-        S = U @ U.T / 24
-        S.diagonal().add_(2.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
-        mats.append(S.to(tdt))
-
-    def run(debug, which):
-        if debug:
-            monkeypatch.setenv("SSA_CHOL_DEBUG", debug)
-        else:
-            monkeypatch.delenv("SSA_CHOL_DEBUG", raising=False)
-        bufs = []
-        for S in which:
-            n = S.shape[0]
-            npad = K.chol_padded_n(n)
-            t = torch.zeros((npad, K.padded_ld(npad, dtype)), dtype=tdt, device="cuda")
-            t[:n, :n] = torch.tril(S)
-            bufs.append((t, n))
-        out = K.chol_factor_batch(bufs)
-        torch.cuda.synchronize()
-        assert all(f.info == 0 for f in out)
-        return out
-
-    def same(a, b, S, what):
-        n = S.shape[0]
-        used = 2 * ((K.chol_padded_n(n) + 4095) // 4096) * 4096 * 4096
-        if dtype == "float64":
-            assert torch.equal(a.L[:n, :n], b.L[:n, :n]), what
-            assert torch.equal(a.aux[:used], b.aux[:used]), what
-        else:
-            scale = float(b.L[:n, :n].abs().max())
-            assert float((a.L[:n, :n] - b.L[:n, :n]).abs().max()) < 1e-5 * scale, what
-
-    ref = run("fuse=0", mats)
-    for debug in ("", "kdepth=1", "kdepth=3,cpos=0,big=0", "kdepth=4,cpos=100000,big=100000", "cpos=300,big=700", "tail=0",
-                  "tail=16384", "tail=6144,kdepth=1,excl=0"):
-        got = run(debug, mats)
-        for a, b, S in zip(got, ref, mats):
-            same(a, b, S, debug)
-    alone = run("", mats[:1])
-    same(alone[0], ref[0], mats[0], "alone")
-    monkeypatch.delenv("SSA_CHOL_DEBUG", raising=False)
-    for f, S in zip(run("", mats), mats):
-        n = S.shape[0]
-        x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
-        got = K.chol_solve(f, (S.double() @ x).to(tdt)).double()
-        assert float((got - x).abs().max() / x.abs().max()) < (1e-11 if dtype == "float64" else 2e-3)
-
-
 def test_cholesky_full_size_residual(K):
     """BASELINE.json size (n_i = 20 419): S x = b to rounding, by a residual check that needs no
     O(n^3) host work (S = D + U U^T built on the GPU)."""
