@@ -272,6 +272,40 @@ def cpu_baseline(K: int, iterations: int, budget_s: float, gpu_solutions=None, g
         parity = None
         if gpu_solutions is not None:
             parity = oracle_parity(orc, cpu_kernels, films, gpu_field_mT, iterations, gpu_solutions)
+        # ---- the reference's DEFAULT precision (solve_dtype="float32", device/device.py:57; BASELINE.md section 3 asks for
+        # both): Q is still assembled in float64 and cast (solver/utils.py:290-292), A, sgetrf / sgetrs and Q @ (w g)
+        # run in float32.  The float64 films are dropped first (their Q / A / LU are ~ 14 GB of host memory).
+        f32 = None
+        try:
+            for f in films:
+                f.A = f.lu_piv = None
+            films32, t_a32, t_lu32, lu32_flops = [], 0.0, 0.0, 0.0
+            for name, holes, z0 in (("washer", {"hole": in_hole}, 0.0), ("disk", {}, 0.5)):
+                t0 = time.perf_counter()
+                f = orc.make_film(name, mesh, z0=z0, Lambda=0.1, in_film=in_film, holes_mask=holes, factorize=False,
+                                  dtype="float32")
+                t_a32 += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                f.lu_piv = la.lu_factor(-f.A, check_finite=False)      # sgetrf
+                t_lu32 += time.perf_counter() - t0
+                lu32_flops += (2 / 3) * len(f.film_indices) ** 3
+                films32.append(f)
+            applied32 = {f.name: (conv * np.ones(n)).astype(np.float32) for f in films32}
+            t0 = time.perf_counter()
+            for f in films32:
+                orc.solve_film(f, applied32[f.name], field_conversion=conv)
+            t_pass32 = time.perf_counter() - t0
+            per_solve32 = 2 * t_q + t_a32 + t_lu32 + (iterations + 1) * t_pass32 + iterations * t_cpl
+            f32 = {"value": 1.0 / per_solve32, "unit": "solves/s", "seconds_per_solve": per_solve32,
+                   "sample_seconds": {"q_assembly_per_film_float64": t_q, "cast_and_a_assembly_both_films": t_a32,
+                                      "lu_both_films": t_lu32, "solve_pass_both_films": t_pass32,
+                                      "coupling_round_float64": t_cpl},
+                   "lu_GFLOPs": lu32_flops / t_lu32 / 1e9, "threads_used": threads,
+                   "note": "one run per phase; Q assembly and the coupling sums are float64 in the reference whatever the "
+                           "solve_dtype (distance.py:101, solver/solve.py:508-515)"}
+            del films32
+        except MemoryError as exc:   # (a small host)
+            f32 = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     # the device has one mesh per film (device.meshes, device/device.py): Q is built per film
     per_solve = 2 * t_q + t_a + t_lu + (iterations + 1) * t_pass + iterations * t_cpl
     return {
@@ -295,6 +329,12 @@ def cpu_baseline(K: int, iterations: int, budget_s: float, gpu_solutions=None, g
         "physical_cores": phys,
         "lu_thread_sweep_GFLOPs_n6000": {str(k): v for k, v in sweep.items()},
         "lu_GFLOPs_by_threads_at_size": {str(k): v for k, v in sweep_at_size.items()},
+        # BASELINE.md section 3 says "all cores": this host's LAPACK is SLOWER on all of its cores than on the best
+        # count (oversubscribed OpenBLAS threads), so the baseline above uses the best count and the all-cores rate is
+        # printed beside it
+        "all_cores": {"threads": phys, "lu_GFLOPs_n6000": sweep.get(phys), "best_threads_n6000": max(sweep, key=sweep.get),
+                      "lu_GFLOPs_n6000_best_threads": max(sweep.values())},
+        "float32": f32,
     }
 
 
@@ -530,6 +570,69 @@ def configH_float32(sc, torch, K, iterations, steps=6):
             "configH_float32_factorization_frac_of_fp32_matrix_peak": flops / (t_fact * 1e-3) / 1e12 / 157.3,
             "configH_float32_note": "reference default solve_dtype; parity of this precision: "
                                     "tests/test_headline_gpu.py::test_configH_float32_no_worse_than_the_reference_in_float32"}
+
+
+def configH_mixed(sc, torch, device, iterations, ref_sols, ref_field_mT, steps=6):
+    """Config H with ``factorize_model(method="mixed")`` -- an opt-in extension, NOT the headline (which stays pure
+    float64): diag(w) A factored in FLOAT32, every solve refined to float64 against the matrix-free system
+    (superscreen_amd/solver.py::_mixed_solve).  Reports the cold step and, for the applied field of the headline's last
+    timed step, its distance from that float64 solution (stream functions of every iterate, the fluxoid ring of
+    ``fluxoid_parity``) -- the headline's own distance from the CPU oracle is ``parity`` (1e-13)."""
+    from superscreen_amd import Polygon, synthetic
+
+    def cold(field):
+        model = sc.factorize_model(device=device, current_units="uA", method="mixed")
+        return model, sc.solve(model=model, applied_field=sc.ConstantField(field), field_units="mT", iterations=iterations,
+                               progress_bar=False)
+
+    model = sols = None
+    for i in range(2):
+        model = sols = None
+        model, sols = cold(0.1 * (i + 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model = sols = None
+        model, sols = cold(0.1 * (i + 3))
+    torch.cuda.synchronize()
+    ms_step = (time.perf_counter() - t0) / steps * 1e3
+    tf = []
+    for _ in range(5):
+        model = sols = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model = sc.factorize_model(device=device, current_units="uA", method="mixed")
+        torch.cuda.synchronize()
+        tf.append((time.perf_counter() - t1) * 1e3)
+    t1 = time.perf_counter()
+    sols = sc.solve(model=model, applied_field=sc.ConstantField(ref_field_mT), field_units="mT", iterations=iterations,
+                    progress_bar=False)
+    torch.cuda.synchronize()
+    t_solve = (time.perf_counter() - t1) * 1e3
+    err_g = err_f = 0.0
+    names = list(ref_sols[0].film_solutions)
+    film_poly = device.films[names[0]].points
+    r_film = float(np.max(np.hypot(film_poly[:, 0], film_poly[:, 1])))
+    holes = list(device.holes.values())
+    r_hole = float(np.max(np.hypot(holes[0].points[:, 0], holes[0].points[:, 1]))) if holes else 0.0
+    ring = Polygon(points=synthetic.circle_points(0.5 * (r_hole + r_film), 301)).points
+    for a, b in zip(sols, ref_sols):
+        for nm in names:
+            ga, gb = a.film_solutions[nm].stream, b.film_solutions[nm].stream
+            err_g = max(err_g, float(np.max(np.abs(ga - gb)) / np.max(np.abs(gb))))
+            fa = a.polygon_fluxoid(ring, film=nm, units="mT * um**2", with_units=False)
+            fb = b.polygon_fluxoid(ring, film=nm, units="mT * um**2", with_units=False)
+            scale = max(abs(fb.flux_part), abs(fb.supercurrent_part))
+            err_f = max(err_f, max(abs(fa.flux_part - fb.flux_part), abs(fa.supercurrent_part - fb.supercurrent_part)) / scale)
+    del model, sols
+    torch.cuda.empty_cache()
+    return {"configH_mixed_ms_per_step": ms_step, "configH_mixed_solves_per_s": 1e3 / ms_step,
+            "configH_mixed_factorization_ms": float(np.median(tf)), "configH_mixed_solve_ms": t_solve,
+            "configH_mixed_max_rel_err_stream_vs_float64": err_g, "configH_mixed_max_rel_err_fluxoid_vs_float64": err_f,
+            "configH_mixed_note": "opt-in factorize_model(method='mixed'): float32 Cholesky + 2 float64 refinement sweeps per "
+                                  "solve against the matrix-free system; errors = distance from the headline's float64 "
+                                  "solution of the same field, all iterates (north_star tolerance 1e-6); parity vs the "
+                                  "oracle: tests/test_solve_gpu.py::test_mixed_precision_factorization_refined_to_float64"}
 
 
 def pipelined_cold_solves(sc, torch, device, iterations, steps=8):
@@ -1124,6 +1227,12 @@ def main():
                 "unknowns": unknowns,
                 "iterations": args.iterations,
                 "parallelism": f"independent solves x{world} (one per rank and step; no data-path collective)",
+                # the reference evaluates self_field = Q @ (w g) (solve_film.py:565); the passes of this line take it
+                # from the solved London system on the unknowns' rows and from the all-pairs sum on the others
+                # (factorize_model(self_field="auto"): float64 and uniform Lambda only; other devices and
+                # self_field="matrix_free" pay the all-pairs sum on every row).  It is an output, not an input of the
+                # next iterate; its difference from the reference's value is parity.max_rel_err_self_field.
+                "self_field_mode": "auto: London identity on the unknowns' rows, all-pairs sum on the other rows",
             },
             "roofline": {
                 "kernel": dom_label + ", v_mfma_f64_16x16x4_f64",
@@ -1175,6 +1284,8 @@ def main():
         extras.update(guarded("config2", lambda: config2_single_film(sc, torch, kernels)))
         extras.update(guarded("pipelined", lambda: pipelined_cold_solves(sc, torch, device, args.iterations)))
         extras.update(guarded("configH_float32", lambda: configH_float32(sc, torch, args.K, args.iterations)))
+        extras.update(guarded("configH_mixed", lambda: configH_mixed(sc, torch, device, args.iterations, parity_sols,
+                                                                     parity_field)))
         extras.update(guarded("configH_alt_2x50k", lambda: configH_alt_2x50k(sc, torch, args.iterations)))
         extras.update(guarded("configH_own_meshes", lambda: configH_own_meshes(sc, torch, args.iterations)))
 

@@ -532,7 +532,11 @@ class Device:
         return device
 
     def translate(self, dx: float = 0, dy: float = 0, dz: float = 0, inplace: bool = False) -> "Device":
-        """Moves polygons, mesh sites and (``dz``) layers; the mesh survives (``device/device.py:334-365``)."""
+        """Moves polygons, mesh sites and (``dz``) layers; the mesh survives (``device/device.py:334-365``).
+
+        What the path keeps per mesh follows the move: the GPU copies of the geometry (``operators._device_cache``: the
+        kernels only use coordinate DIFFERENCES inside a film, but the coupling sums between films use both films'
+        absolute positions) and the point-in-polygon results (``_contains_cache``) are dropped and rebuilt on next use."""
         device = self if inplace else self.copy(with_mesh=True, copy_mesh=True)
         for polygon in device.get_polygons():
             polygon.translate(dx, dy, inplace=True)
@@ -540,6 +544,10 @@ class Device:
             mesh.sites += np.array([[dx, dy]], dtype=float)
             mesh.triangle_centroids += np.array([[dx, dy]], dtype=float)
             mesh._triangulation = None
+            if dx or dy:
+                if mesh.operators is not None:
+                    mesh.operators._device_cache.clear()
+                mesh.__dict__.pop("_contains_cache", None)
         if dz:
             for layer in device.layers.values():
                 layer.z0 += dz

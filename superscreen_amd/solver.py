@@ -387,9 +387,17 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     ``method``: ``"lu"`` factors ``-A`` like the reference (LAPACK getrf semantics);
     ``"cholesky"`` / ``"auto"`` factor the symmetric positive definite ``diag(w) A`` instead
     (half the flops, same solution to rounding), ``"auto"`` falling back to LU if a pivot is
-    not positive."""
-    if method not in ("auto", "cholesky", "lu"):
+    not positive.  ``"mixed"`` (float64 devices, uniform Lambda, no terminals): the Cholesky factor of ``diag(w) A`` in
+    FLOAT32 -- half the factorization time and half the bytes per triangular solve -- and every solve refined in float64
+    against the matrix-free ``diag(w) A`` (``MIXED_REFINEMENT_SWEEPS`` sweeps of residual + correction,
+    :func:`_mixed_solve`)."""
+    if method not in ("auto", "cholesky", "lu", "mixed"):
         raise ValueError(f"Unknown factorization method {method!r}.")
+    if method == "mixed":
+        if np.dtype(device.solve_dtype) != np.float64:
+            raise ValueError("method='mixed' refines a float32 factorization to float64: it needs solve_dtype='float64'.")
+        if device.terminals:
+            raise NotImplementedError("method='mixed' does not handle films with terminals.")
     import torch
 
     from . import _hip, kernels
@@ -496,10 +504,15 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
                 pending.append(((name, role), interior, ix_d, 0, None, None, lambda: np.zeros((0, 0), dtype=dtype), fd,
                                 grad_Lambda_term))
                 continue
-            if inhomogeneous and method == "cholesky":
+            if inhomogeneous and method in ("cholesky", "mixed"):
                 raise ValueError(f"Film {name!r}: Lambda(x, y) makes diag(w) A non-symmetric; "
                                  "use method='auto' or 'lu'.")
-            if method in ("auto", "cholesky") and not inhomogeneous:
+            if method == "mixed":
+                npad = kernels.chol_padded_n(ni)
+                S = kernels.system_assemble(fd.xy, fd.w, fd.qdiag, fd.Lambda, *fd.lap, ix_d, ix_d, sign=1.0,
+                                            dtype="float32", row_scale=fd.w, lower_only=True,
+                                            ld=kernels.padded_ld(npad, "float32"), alloc_rows=npad)
+            elif method in ("auto", "cholesky") and not inhomogeneous:
                 # S = diag(w) A is symmetric positive definite for a homogeneous film: Cholesky,
                 # (1/3) n^3 flops, no pivoting; gf = -S^-1 (w[ix] * h)   (see chol.hip)
                 npad = kernels.chol_padded_n(ni)
@@ -523,7 +536,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     # the films that take the LU route (method="lu", Lambda(x, y), a failed Cholesky) are factored together,
     # one stream per film: the panel chain of one film runs beside the trailing updates of the others
     lu_keys = [p[0] for p in pending if p[3] > 0 and (chols.get(p[0]) is None or chols[p[0]].info != 0)]
-    if method == "cholesky" and any(chols.get(k) is not None for k in lu_keys):
+    if method in ("cholesky", "mixed") and any(chols.get(k) is not None for k in lu_keys):
         bad = [k[0] for k in lu_keys if chols.get(k) is not None]
         raise RuntimeError(f"diag(w) A of film {bad[0]!r} is not positive definite.")
     # First the no-interchange route (look-ahead, one schedule for all films): it applies whenever LAPACK's
@@ -659,6 +672,8 @@ class FactorizedModel:
             fd = self.film_data[film]
             ni = len(system.indices)
             e = torch.zeros(ni, dtype=fd.tdtype, device=fd.device)
+            if system.chol is not None and system.chol.dtype != fd.tdtype:
+                raise NotImplementedError("method='mixed' does not handle trapped vortices.")
             if system.chol is not None:
                 # A = diag(1/w) S  ->  inv(A) e_j = w_j inv(S) e_j ;  neg_w holds -w[ix]
                 e[j_film] = -system.neg_w_device[j_film]
@@ -691,7 +706,8 @@ def factorize_model(*, device: Device, current_units: str,
     of a mesh); it agrees with the all-pairs value to the residual of the solve (2e-12 relative at
     25k vertices per film, float64).  ``"auto"`` (default) = ``"london"`` for float64 films with a
     uniform Lambda and no vortices or terminals, ``"matrix_free"`` otherwise.
-    ``method`` (extension): ``"auto"`` (default) / ``"cholesky"`` / ``"lu"``, see
+    ``method`` (extension): ``"auto"`` (default) / ``"cholesky"`` / ``"lu"`` / ``"mixed"`` (float32 factor, float64
+    answers by iterative refinement: half the factorization time of a float64 device), see
     :func:`factorize_linear_systems`.
     ``placement`` (extension): a :class:`superscreen_amd.parallel.FilmPlacement`; this rank then
     assembles and factors only the films it owns (pass the same object to :func:`solve`).
@@ -868,16 +884,9 @@ def _solve_film_device(model: FactorizedModel, name: str, applied_d, other_d,
                        check_inversion: bool, vortex_flux_value: float = 0.0,
                        defer_exterior: bool = False) -> _DeviceFilmResult:
     """Device part of ``solve_film`` (``solver/solve_film.py:486-565``) for one film: ``_solve_film_steps`` with its
-    Cholesky solve done on the spot."""
-    from . import kernels
-
-    steps = _solve_film_steps(model, name, applied_d, other_d, check_inversion, vortex_flux_value, defer_exterior)
-    try:
-        factor, rhs = next(steps)
-        steps.send(kernels.chol_solve_batch([factor], [rhs], padded=True)[0])
-    except StopIteration as stop:
-        return stop.value
-    raise RuntimeError("_solve_film_steps asked for more than one solve.")
+    Cholesky solve(s) done on the spot."""
+    return _solve_films_device(model, [name], {name: applied_d}, None if other_d is None else {name: other_d},
+                               check_inversion, vortex_flux_value, defer_exterior)[name]
 
 
 def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d, other_d, check_inversion: bool,
@@ -885,7 +894,8 @@ def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d,
                         pass_cache: Optional[dict] = None) -> Dict[str, _DeviceFilmResult]:
     """``_solve_film_device`` for several films of one pass (independent of each other, ``solver/solve.py:517-536``):
     the Cholesky solves of all of them go out together (``kernels.chol_solve_batch``: the block steps of the
-    triangular solves side by side in one launch each)."""
+    triangular solves side by side in one launch each).  A film asks for one solve (several with ``method="mixed"``:
+    one per refinement sweep); the films that still wait for one are served together, round after round."""
     from . import kernels
 
     results, waiting = {}, []
@@ -896,18 +906,18 @@ def _solve_films_device(model: FactorizedModel, names: Sequence[str], applied_d,
             waiting.append((name, steps) + tuple(next(steps)))
         except StopIteration as stop:
             results[name] = stop.value
-    by_dtype: Dict[object, list] = {}
-    for item in waiting:
-        by_dtype.setdefault(item[2].dtype, []).append(item)
-    for group in by_dtype.values():
-        solved = kernels.chol_solve_batch([item[2] for item in group], [item[3] for item in group], padded=True)
-        for (name, steps, _, _), gf in zip(group, solved):
-            try:
-                steps.send(gf)
-            except StopIteration as stop:
-                results[name] = stop.value
-            else:
-                raise RuntimeError("_solve_film_steps asked for more than one solve.")
+    while waiting:
+        by_dtype: Dict[object, list] = {}
+        for item in waiting:
+            by_dtype.setdefault(item[2].dtype, []).append(item)
+        waiting = []
+        for group in by_dtype.values():
+            solved = kernels.chol_solve_batch([item[2] for item in group], [item[3] for item in group], padded=True)
+            for (name, steps, _, _), gf in zip(group, solved):
+                try:
+                    waiting.append((name, steps) + tuple(steps.send(gf)))
+                except StopIteration as stop:
+                    results[name] = stop.value
     return {name: results[name] for name in names}
 
 
@@ -961,7 +971,12 @@ def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
             if pass_cache is not None:
                 pass_cache[("rhs", name)] = rhs
         kernels.row_scale(h_nat, system.neg_w_device, out=rhs[:system.chol.n])
-        gf = yield system.chol, rhs
+        if system.chol.dtype != fd.tdtype:   # method="mixed": float32 factor, float64 answer
+            if info.vortices:
+                raise NotImplementedError("method='mixed' does not handle trapped vortices.")
+            gf = yield from _mixed_solve(fd, system, rhs, pass_cache, name)
+        else:
+            gf = yield system.chol, rhs
     else:
         h = kernels.film_rhs(applied_d, other_d, ha_eff, system.rhs_indices_device)
         if check_inversion:
@@ -1013,6 +1028,43 @@ def _solve_film_steps(model: FactorizedModel, name: str, applied_d, other_d,
     else:
         sf = kernels.self_field(fd.xy, fd.w, fd.qdiag, g)
     return _DeviceFilmResult(g=g, J=J, self_field=sf)
+
+
+MIXED_REFINEMENT_SWEEPS = 2   # each sweep shrinks the error of the float32 solve by ~ 1e-4 (measured, config H)
+
+
+def _mixed_solve(fd: "FilmDeviceData", system: LinearSystem, rhs, pass_cache: Optional[dict], name: str):
+    """``S x = rhs`` with ``S = diag(w) A`` factored in FLOAT32 (``factorize_model(method="mixed")``) and the answer
+    refined in float64: ``x <- x + S32^-1 (rhs - S x)``, the residual against the EXACT float64 ``S`` -- evaluated matrix
+    free, as the assembly kernel would: ``(S x)_i = w_i ((Q (w x))_i - (Del2 (Lambda x))_i)`` on the unknowns' rows, the
+    all-pairs sum (``ssa_self_field_rows``) and the sparse Laplacian product (``ssa_london_field_rows``).  A generator
+    like :func:`_solve_film_steps`: yields ``(factor, padded float32 right-hand side)``, is sent the solution."""
+    import torch
+
+    from . import kernels
+
+    n, npad = system.chol.n, rhs.numel()
+    ix = system.indices_device
+    keep = {} if pass_cache is None else pass_cache.setdefault(("mixed", name), {})
+    if not keep:
+        keep.update(rhs32=torch.zeros(npad, dtype=torch.float32, device=fd.device),
+                    full=torch.zeros(fd.n, dtype=torch.float64, device=fd.device),
+                    q=torch.empty(fd.n, dtype=torch.float64, device=fd.device),
+                    lap=torch.empty(fd.n, dtype=torch.float64, device=fd.device),
+                    zero=torch.zeros(fd.n, dtype=torch.float64, device=fd.device),
+                    w_ix=(-system.neg_w_device).to(torch.float64))
+    rhs32, full = keep["rhs32"], keep["full"]
+    rhs32.copy_(rhs)
+    x = (yield system.chol, rhs32).to(torch.float64)          # (a view of rhs32's first n elements -> a new tensor)
+    for _ in range(MIXED_REFINEMENT_SWEEPS):
+        full.zero_()
+        full[ix] = x
+        kernels.self_field_rows(fd.xy, fd.w, fd.qdiag, full, ix, keep["q"])
+        kernels.london_field_rows(*fd.lap, fd.Lambda, full, keep["zero"], None, ix, keep["lap"])
+        residual = rhs[:n] - keep["w_ix"] * (keep["q"][ix] - keep["lap"][ix])
+        rhs32[:n] = residual
+        x = x + (yield system.chol, rhs32).to(torch.float64)
+    return x
 
 
 _copy_streams: Dict[int, object] = {}

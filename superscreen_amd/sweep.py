@@ -59,6 +59,8 @@ def solve_sweep(model, applied_fields: Sequence[Union[float, Callable]], *, fiel
         raise NotImplementedError("solve_sweep does not handle films with terminals; loop over solve().")
     if any(info.vortices for info in model.film_info.values()):
         raise NotImplementedError("solve_sweep does not handle vortices; loop over solve().")
+    if getattr(model, "method", "auto") == "mixed":
+        raise NotImplementedError("solve_sweep does not refine a float32 factorization (method='mixed'); loop over solve().")
     fields = [f if callable(f) else ConstantField(float(f)) for f in applied_fields]
     nvec = len(fields)
     if nvec == 0:

@@ -10,6 +10,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The stream -> hardware-queue mapping bench.py runs under (it sets the same before the HIP runtime starts; subprocess
+# workers inherit it): the suite exercises the schedules with the queue setting the benchmark is measured with.
+# SSA_TEST_HW_QUEUES=<n> runs the suite under another setting (the HIP default is 4).
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("SSA_TEST_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES", "8"))
+
 # SSA_POISON=nan|big: every uninitialised device buffer the host layer allocates comes back filled (tools/poison.py):
 # a kernel that reads memory this run never wrote then shows, instead of finding the previous run's values there.
 if os.environ.get("SSA_POISON"):

@@ -153,7 +153,7 @@ def test_no_barrier_with_lds_operations_in_flight():
     from superscreen_amd import _hip
 
     if not os.path.exists(isa_lint.LLVM + "/llvm-objdump"):
-        pytest.skip("no llvm-objdump")
+        pytest.skip(f"no llvm-objdump under {isa_lint.LLVM} (set ROCM_PATH): the static check did NOT run")
     if not os.path.exists(_hip.LIB_PATH):
         pytest.skip("library not built")
     problems, kernels, barriers = isa_lint.lint_library(_hip.LIB_PATH)
@@ -166,16 +166,19 @@ def test_no_barrier_with_lds_operations_in_flight():
 
 
 def test_final_gate_log_belongs_to_this_tree():
-    """``profiles/r05_final_gate.txt`` is the log of the last full GPU run of the round (``tools/final_gate.sh``: the
+    """``profiles/rNN_final_gate.txt`` (the newest) is the log of the last full GPU run of a round (``tools/final_gate.sh``: the
     suite as the driver runs it, smoke(), a driver-style bench).  It records a digest of everything that run
     depended on; a tree that has moved on since (a kernel edited after the last GPU run -- how round 4 ended red) is
     reported here as a SKIP with the reason, a log whose run failed as a failure."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import final_gate
 
-    path = os.path.join(ROOT, "profiles", "r05_final_gate.txt")
-    if not os.path.exists(path):
+    import glob
+
+    logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_final_gate.txt")))
+    if not logs:
         pytest.skip("no gate log yet")
+    path = logs[-1]
     fields = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
     assert [fields.get(k, "?").strip() for k in ("pytest_gpu_rc", "smoke_rc", "bench_rc")] == ["0", "0", "0"]
     if fields.get("tree_digest", "").strip() != final_gate.tree_digest():

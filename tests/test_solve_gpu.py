@@ -311,6 +311,66 @@ def test_two_film_vs_oracle_medium(sc, dtype, tol):
             assert relerr(sol.film_solutions[nm].current_density, ref[nm].current_density) < tol * 10
 
 
+def test_mixed_precision_factorization_refined_to_float64(sc):
+    """factorize_model(method="mixed"): diag(w) A factored in float32 (half the factorization time of a float64 device,
+    half the bytes per triangular solve), every solve refined in float64 against the matrix-free system -- the
+    stream functions, sheet currents, fields and fluxoids of a coupled two-film device (films with their own meshes)
+    against the oracle's float64 LU at 1e-9, like the float64 routes."""
+    from superscreen_amd import synthetic
+
+    spec = dict(layers=[dict(name="bottom", z0=0.0, Lambda=0.05), dict(name="top", z0=0.7, Lambda=0.3)],
+                films=[dict(name="wide", kind="washer", K=31, layer="bottom", film_radius=6.0, center=(0.0, 0.0)),
+                       dict(name="narrow", kind="washer", K=25, layer="top", film_radius=4.0, center=(-1.1, 0.6))])
+    device, geos = _mixed_device(sc, spec)
+    circ = {"hole_wide": 2.0}
+    field = sc.Parameter(synthetic.tilted_field, B0=0.6)
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents=circ, method="mixed")
+    assert all(s.chol is not None and s.chol.dtype == torch.float32 for s in model.film_systems.values())
+    sols = sc.solve(model=model, applied_field=field, field_units="mT", iterations=4)
+    films = orc.make_films(spec["layers"], spec["films"], geos)
+    trace = orc.solve(films, lambda x, y, z: synthetic.tilted_field(x, y, z, 0.6), iterations=4, circulating_currents=circ)
+    for sol, ref in zip(sols, trace):
+        for f in films:
+            nm = f.name
+            assert sol.film_solutions[nm].stream.dtype == np.float64
+            assert relerr(sol.film_solutions[nm].stream, ref[nm].stream) < TOL
+            assert relerr(sol.film_solutions[nm].self_field, ref[nm].self_field) < TOL
+            assert relerr(sol.film_solutions[nm].current_density, ref[nm].current_density) < 10 * TOL
+            poly = geos[nm]["fluxoid_polygon"]
+            got = sol.polygon_fluxoid(poly, film=nm, units="mT * um**2", with_units=False)
+            want = orc.polygon_fluxoid_mT_um2(f, ref[nm], poly, geos[nm]["film_polygon"])
+            scale = max(abs(want[0]), abs(want[1]))
+            assert max(abs(got.flux_part - want[0]), abs(got.supercurrent_part - want[1])) < TOL * scale
+    # one sweep fewer leaves the float32 error times ~ 1e-4: the refinement is what gives the digits
+    from superscreen_amd import solver as solver_mod
+
+    full = sols[-1].film_solutions["wide"].stream
+    old = solver_mod.MIXED_REFINEMENT_SWEEPS
+    try:
+        solver_mod.MIXED_REFINEMENT_SWEEPS = 0
+        raw = sc.solve(model=model, applied_field=field, field_units="mT", iterations=4)[-1].film_solutions["wide"].stream
+    finally:
+        solver_mod.MIXED_REFINEMENT_SWEEPS = old
+    assert 1e-7 < relerr(raw, full) < 5e-3
+    with pytest.raises(NotImplementedError):
+        sc.solve_sweep(model, [0.1, 0.2])
+    with pytest.raises(ValueError):
+        sc.factorize_model(device=_mixed_device(sc, spec, "float32")[0], current_units="uA", method="mixed")
+
+
+def test_translate_in_place_drops_the_cached_geometry(sc):
+    """Device.translate(inplace=True) moves the mesh sites; the GPU copies of the geometry cached on the mesh operators
+    and the cached point-in-polygon results follow (they are dropped), and a uniform field gives the same answer."""
+    device, _ = _mixed_device(sc)
+    before = sc.solve(device, applied_field=sc.ConstantField(0.4), iterations=2)[-1]
+    assert all(m.operators._device_cache for m in device.meshes.values())
+    device.translate(dx=3.0, dy=-1.5, inplace=True)
+    assert not any(m.operators._device_cache for m in device.meshes.values())
+    after = sc.solve(device, applied_field=sc.ConstantField(0.4), iterations=2)[-1]
+    for nm in device.films:
+        assert relerr(after.film_solutions[nm].stream, before.film_solutions[nm].stream) < 1e-10
+
+
 @pytest.mark.parametrize("method", ["lu", "cholesky"])
 def test_factorization_methods_agree(sc, method):
     """LU of -A (the reference's algorithm) and Cholesky of diag(w) A give the same solution."""

@@ -9,23 +9,13 @@ out=gpurun_out/${tag}_gate; mkdir -p $out
 log=$out/gate.txt; : > $log
 echo "gate $(date -u +%FT%TZ) tag=$tag" >> $log
 python - >> $log <<'PY'
-import hashlib, os, subprocess, sys
+import os, sys
 sys.path.insert(0, os.getcwd())
 from superscreen_amd import build
 print("library_source_digest", build.source_digest())
 print("library_is_current", build.is_current())
-h = hashlib.sha256()
-for root in ("superscreen_amd", "tests", "oracle", "include"):
-    for d, _, files in sorted(os.walk(root)):
-        if "__pycache__" in d or "/build" in d or d.endswith("/lib") or "_ref" in d:
-            continue
-        for f in sorted(files):
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".c", ".npz")):
-                h.update(os.path.join(d, f).encode()); h.update(open(os.path.join(d, f), "rb").read())
-for f in ("bench.py", "__graft_entry__.py"):
-    h.update(f.encode()); h.update(open(f, "rb").read())
-print("tree_digest", h.hexdigest())
 PY
+echo "tree_digest $(python tools/final_gate.py)" >> $log     # (the ONE implementation of the digest: tools/final_gate.py)
 timeout 1800 python -X faulthandler -m pytest tests -x -q -m gpu --timeout 600 > $out/pytest_gpu.log 2>&1; echo "pytest_gpu_rc $?" >> $log; tail -1 $out/pytest_gpu.log >> $log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke_rc $?" >> $log; tail -1 $out/smoke.log >> $log
 timeout 900 python -X faulthandler bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench_rc $?" >> $log

@@ -10,8 +10,11 @@ hundred of the four-film stack differed in the 10th digit).  Rule checked here, 
     every ``s_barrier`` is preceded by an ``s_waitcnt`` with ``lgkmcnt(0)`` that has no LDS instruction
     (``ds_*``) after it.
 
-(Conservative along fall-through order; branches are not followed.  Scalar memory loads share the counter, so a
-wait that covers them covers the LDS operations too.)
+A HEURISTIC, not a proof: the disassembly is read in fall-through order and only ``ds_*`` operations are tracked;
+branches are not followed, so an LDS read that reaches a barrier along another path than the textual one is not seen
+(the kernels of this library keep their LDS rings in straight-line loop bodies, which is the shape it does see: it
+flags the round-4 form of ``tile_small_nt`` and three siblings).  Scalar memory loads share the counter, so a wait
+that covers them covers the LDS operations too.
 
     python tools/isa_lint.py [path/to/libsuperscreen_hip.so]      exit status 1 if a barrier violates the rule
 """
@@ -22,7 +25,20 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _llvm_bin() -> str:
+    """The ROCm LLVM tools: $ROCM_PATH/lib/llvm/bin, /opt/rocm/lib/llvm/bin, or wherever llvm-objdump is on PATH."""
+    import shutil
+
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root and os.path.exists(os.path.join(root, "lib", "llvm", "bin", "llvm-objdump")):
+            return os.path.join(root, "lib", "llvm", "bin")
+    found = shutil.which("llvm-objdump")
+    return os.path.dirname(found) if found else "/opt/rocm/lib/llvm/bin"
+
+
+LLVM = _llvm_bin()
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
