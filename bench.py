@@ -67,8 +67,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (vendor nominal)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILES = ("r05_syrk_pmc.json", "r04_syrk_pmc.json", "r03_syrk_pmc.json", "r02b_syrk_pmc.json")
-PMC_MFMA_FILES = ("r05_syrk_mfma_pmc.json", "r04_syrk_mfma_pmc.json", "r03_syrk_mfma_pmc.json", "r02b_syrk_mfma_pmc.json")
+PMC_TRAFFIC_FILES = ("r06_syrk_pmc.json", "r05_syrk_pmc.json", "r04_syrk_pmc.json", "r03_syrk_pmc.json", "r02b_syrk_pmc.json")
+PMC_MFMA_FILES = ("r06_syrk_mfma_pmc.json", "r05_syrk_mfma_pmc.json", "r04_syrk_mfma_pmc.json", "r03_syrk_mfma_pmc.json", "r02b_syrk_mfma_pmc.json")
 
 
 def chol_schedule(unknowns, elem=8):

@@ -16,6 +16,7 @@
 #   qform            tools/q_form_timing.py: Q assembly, one-shot pieces against strips
 #   timeline:<kind>  rocprofv3 kernel trace of tools/fact_timeline.py run <kind> (float64|float32|stack4|single), then its
 #                    `table` (SYRK launches in situ / alone / beside) and `rounds` listings
+#   passes           rocprofv3 kernel trace of three warm solves of config H (tools/pass_trace.py) and its per-kernel listing
 #   ab:<args>        tools/ab_knobs.py <args> (SSA_CHOL_DEBUG variants taking turns in one process)
 #   py:<script and args>   any tool, e.g. "py:tools/fact_single.py 129"
 #   env:<NAME=VALUE>       exported for the steps that follow (e.g. env:SSA_CHOL_DEBUG=late=1)
@@ -50,6 +51,10 @@ for step in "$@"; do
               timeout 600 python tools/fact_timeline.py rounds $td $nf > $out/round_timeline_$kind.txt 2>&1
               [ "$kind" != float32 ] && timeout 900 python tools/fact_timeline.py table $td $unk > $out/syrk_launch_table_$kind.txt 2>&1
               echo "timeline[$kind] $(tail -2 $out/syrk_launch_table_$kind.txt 2>/dev/null | head -1)" >> $sum ;;
+    passes)   td=/tmp/ssa_pt_${tag}; rm -rf $td; here=$PWD
+              (cd /tmp && TMPDIR=/tmp timeout 900 rocprofv3 --kernel-trace --output-format csv -d $td -- python3 $here/tools/pass_trace.py) > $out/pass_trace_run.log 2>&1
+              timeout 300 python tools/pass_trace.py analyse $td > $out/pass_trace.txt 2>&1
+              echo "passes rc=$? $(head -1 $out/pass_trace.txt)" >> $sum ;;
     ab)       log=$out/ab_$(echo "$arg" | tr ' /="' '____' | cut -c1-60).log
               eval "timeout 1500 python -X faulthandler tools/ab_knobs.py $arg" > $log 2>&1
               echo "ab[$arg] rc=$?" >> $sum; cat $log >> $sum ;;
