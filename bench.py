@@ -504,7 +504,7 @@ def config3_two_films(sc, torch, iterations):
     device = synthetic.make_stack_device(K3, ("washer", "disk"), solve_dtype="float64")
 
     def cold(**kw):
-        model = sc.factorize_model(device=device, current_units="uA")
+        model = sc.factorize_model(device=device, current_units="uA", expected_passes=kw.get("iterations", 0) + 1)
         return sc.solve(model=model, applied_field=sc.ConstantField(1.0), progress_bar=False, **kw)
 
     cold(iterations=iterations)                                    # warm-up
@@ -534,7 +534,7 @@ def configH_float32(sc, torch, K, iterations, steps=6):
     device = synthetic.make_stack_device(K, ("washer", "disk"), solve_dtype="float32")
 
     def cold(field):
-        model = sc.factorize_model(device=device, current_units="uA")
+        model = sc.factorize_model(device=device, current_units="uA", expected_passes=iterations + 1)
         return model, sc.solve(model=model, applied_field=sc.ConstantField(field), field_units="mT",
                                iterations=iterations, progress_bar=False)
 
@@ -581,7 +581,7 @@ def configH_mixed(sc, torch, device, iterations, ref_sols, ref_field_mT, steps=6
     from superscreen_amd import Polygon, synthetic
 
     def cold(field):
-        model = sc.factorize_model(device=device, current_units="uA", method="mixed")
+        model = sc.factorize_model(device=device, current_units="uA", method="mixed", expected_passes=iterations + 1)
         return model, sc.solve(model=model, applied_field=sc.ConstantField(field), field_units="mT", iterations=iterations,
                                progress_bar=False)
 
@@ -703,7 +703,7 @@ def configH_alt_2x50k(sc, torch, iterations):
     device = synthetic.make_stack_device(Ka, ("washer", "disk"), solve_dtype="float64")
 
     def cold():
-        model = sc.factorize_model(device=device, current_units="uA")
+        model = sc.factorize_model(device=device, current_units="uA", expected_passes=iterations + 1)
         unknowns = [int(len(s_.indices)) for s_ in model.film_systems.values()]
         return unknowns, sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=iterations,
                                   progress_bar=False)
@@ -742,7 +742,7 @@ def configH_own_meshes(sc, torch, iterations):
     field = sc.Parameter(synthetic.tilted_field, B0=1.0)
 
     def cold():
-        model = sc.factorize_model(device=device, current_units="uA")
+        model = sc.factorize_model(device=device, current_units="uA", expected_passes=iterations + 1)
         return [int(len(s_.indices)) for s_ in model.film_systems.values()], \
             sc.solve(model=model, applied_field=field, field_units="mT", iterations=iterations, progress_bar=False)
 
@@ -891,7 +891,7 @@ def config5_stack(sc, torch, dist, rank, world, iterations, steps=2):
             dist.barrier()
 
     def step():
-        model = sc.factorize_model(device=device, current_units="uA", placement=placement)
+        model = sc.factorize_model(device=device, current_units="uA", placement=placement, expected_passes=iterations + 1)
         sols = sc.solve(model=model, applied_field=sc.ConstantField(1.0), iterations=iterations,
                         placement=placement, coupling=coupling)
         return model, sols
@@ -1012,7 +1012,9 @@ def main():
 
     def step(i):
         field = 0.1 * (1 + rank + world * i)  # mT; every rank / step solves a different field
-        model = sc.factorize_model(device=device, current_units="uA")
+        # a cold solve: the factorization serves this solve's iterations + 1 passes and says so, which is what the
+        # reference's plain `solve(device=...)` call does here too (solver.py: expected_passes -> 2048-row solve blocks)
+        model = sc.factorize_model(device=device, current_units="uA", expected_passes=args.iterations + 1)
         sols = sc.solve(model=model, applied_field=sc.ConstantField(field), field_units="mT",
                         iterations=args.iterations, progress_bar=False)
         return model, sols

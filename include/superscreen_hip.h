@@ -47,7 +47,7 @@ extern "C" {
 #define SSA_ERR_UNSUPPORTED_SIZE (-4)
 #define SSA_ERR_RCCL (-5) /* librccl missing, or an RCCL call failed */
 
-#define SSA_ABI_VERSION 5
+#define SSA_ABI_VERSION 6
 
 /* Library / device introspection (host-side, no reference counterpart). */
 int ssa_abi_version(void);
@@ -192,6 +192,21 @@ int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void 
 int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
                          const void *const *aux, void *const *B, int b_is_padded, int dtype, void *const *workspace,
                          const size_t *workspace_bytes, void *stream);
+/* The `_blk` forms (ABI 6) take the row count of the solves' diagonal blocks: SSA_CHOL_SOLVE_BLOCK_DEFAULT (4096, what
+ * the forms above use) or a smaller power-of-two multiple of 256.  A factorization only builds the levels of its block
+ * inverses BELOW that size -- at 2048 a quarter of the block-inverse flops (config H: 3-4 ms of a 95 ms
+ * factorization) -- and a solve then takes twice the dependent launches (config H: + 0.12 ms per pass): the choice
+ * for a factorization that serves few solves, e.g. the one inside the reference's plain cold call
+ * `solve(device=...)` (solver/solve.py:380-399).  The SAME value must be passed to the solves of a factorization.
+ * aux layout and ssa_chol_aux_bytes do not depend on it. */
+#define SSA_CHOL_SOLVE_BLOCK_DEFAULT 4096
+int ssa_chol_factor_batch_blk(int count, void *const *S, const int64_t *n, const int64_t *lda,
+                              int32_t *const *info, void *const *aux, int dtype, int solve_block, void *stream);
+int ssa_chol_solve_blk(const void *L, int64_t n, int64_t lda, const void *aux, void *B, int64_t nrhs,
+                       int64_t ldb, int dtype, void *workspace, size_t workspace_bytes, int solve_block, void *stream);
+int ssa_chol_solve_batch_blk(int count, const void *const *L, const int64_t *n, const int64_t *lda,
+                             const void *const *aux, void *const *B, int b_is_padded, int dtype,
+                             void *const *workspace, const size_t *workspace_bytes, int solve_block, void *stream);
 /*
  * Diagnostics of the factorization schedule (no reference counterpart).  The panel chains run on internal
  * high-priority streams; which hardware queue / command-processor pipe the runtime gives a stream decides what a

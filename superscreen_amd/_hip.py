@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SSA_LIB_PATH") or os.path.join(_PKG, "lib", "libsuper
 
 SSA_F32 = 0
 SSA_F64 = 1
-ABI_VERSION = 5   # SSA_ABI_VERSION of include/superscreen_hip.h
+ABI_VERSION = 6   # SSA_ABI_VERSION of include/superscreen_hip.h
 
 
 class HipLibraryError(RuntimeError):
@@ -44,6 +44,9 @@ SIGNATURES = {
     "ssa_chol_solve": (c_int, [P, I64, I64, P, P, I64, I64, c_int, P, c_size_t, P]),
     "ssa_chol_chain_stream_costs": (c_int, [P, P, c_int]),
     "ssa_chol_solve_batch": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, P]),
+    "ssa_chol_factor_batch_blk": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P]),
+    "ssa_chol_solve_blk": (c_int, [P, I64, I64, P, P, I64, I64, c_int, P, c_size_t, c_int, P]),
+    "ssa_chol_solve_batch_blk": (c_int, [c_int, P, P, P, P, P, c_int, c_int, P, P, c_int, P]),
     "ssa_gemm_ex": (c_int, [c_int, c_int, c_int, I64, I64, I64, c_double, P, I64, P, I64, c_double,
                             P, I64, c_int, P]),
     "ssa_profile_read": (c_int, [c_int, P, P, P]),

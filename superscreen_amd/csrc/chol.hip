@@ -208,6 +208,14 @@ inline AuxLayout aux_layout(int64_t n) {
     return a;
 }
 
+// The triangular solves work on diagonal blocks of `sblk` rows: SNB (4096, the default) or a smaller power-of-two
+// multiple of 256 (2048: ssa_chol_factor_batch_blk).  The STORAGE is the same -- an inverse block of sblk rows sits on
+// the block diagonal of its SNB x SNB buffer, leading dimension SNB -- but the levels of the inverse recursion from
+// sblk upwards are not built: a quarter of the block-inverse flops at sblk = 2048 (the top level is three quarters
+// of them), for twice the dependent launches per solve.  Worth it when a factorization serves few solves.
+inline bool valid_solve_block(int64_t sblk) { return sblk >= 256 && sblk <= SNB && (sblk & (sblk - 1)) == 0; }
+inline int64_t inv_block_offset(int64_t r0) { return (r0 / SNB) * SNB * SNB + (r0 % SNB) * (SNB + 1); }
+
 // inv <- inverse of the lower triangular diagonal block L[r0 : r0 + sz, r0 : r0 + sz] whose 256-leaves
 // are already inverted (chol_diag.hpp), recursively:
 //     inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]
@@ -444,6 +452,7 @@ struct FinishPlan {
     const CholJob<T> *job = nullptr;
     int64_t done = 0;   // full SNB blocks whose solve-phase data have been issued
     bool skip_all = false, skip_mirror = false;   // timing experiments only (SSA_CHOL_DEBUG finish=0 / mirror=0)
+    int64_t sblk = SNB;                           // rows of the solves' diagonal blocks: inverse levels below it are built
 
     void init(const CholJob<T> *j) {
         job = j;
@@ -461,7 +470,7 @@ struct FinishPlan {
             return SSA_OK;
         }
         int rc = SSA_OK;
-        for (int64_t h = 256; h < SNB; h *= 2) {
+        for (int64_t h = 256; h < sblk; h *= 2) {
             rc = inverse_level(J, h, false, done, upto, st, sliced);
             if (rc != SSA_OK) return rc;
             rc = inverse_level(J, h, true, done, upto, st, sliced);
@@ -489,15 +498,15 @@ struct FinishPlan {
             done = -1;
             return SSA_OK;
         }
-        for (int64_t h = 256; h < SNB; h *= 2) {
+        for (int64_t h = 256; h < sblk; h *= 2) {
             rc = inverse_level(J, h, false, first, al.nfull, st, sliced);
             if (rc != SSA_OK) return rc;
             rc = inverse_level(J, h, true, first, al.nfull, st, sliced);
             if (rc != SSA_OK) return rc;
         }
-        if (J.n % SNB != 0) {  // the last, partial block
-            const int64_t r0 = al.nfull * SNB;
-            rc = build_block_inverse(J.A, J.lda, r0, J.n - r0, J.aux + al.inv + al.nfull * SNB * SNB, SNB,
+        // the last, partial SNB block: its solve blocks one by one
+        for (int64_t r0 = al.nfull * SNB; r0 < J.n; r0 += sblk) {
+            rc = build_block_inverse(J.A, J.lda, r0, std::min(sblk, J.n - r0), J.aux + al.inv + inv_block_offset(r0), SNB,
                                      J.aux + al.tmp + al.nfull * (SNB * SNB / 4), st);
             if (rc != SSA_OK) return rc;
         }
@@ -606,8 +615,8 @@ inline CholDebug chol_debug() {
 // schedule.  The finishing passes of the blocks that are final ride beside the chain-bound rounds on the films'
 // low-priority streams, in slices (gemm_batched_sliced) so that the rounds' launches always find free slots.
 template <typename T>
-int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
-    if (count <= 0 || count > kMaxLanes) return SSA_ERR_INVALID_ARGUMENT;
+int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st, int64_t sblk = SNB) {
+    if (count <= 0 || count > kMaxLanes || !valid_solve_block(sblk)) return SSA_ERR_INVALID_ARGUMENT;
     // the lanes (side streams + events) are shared per device: one schedule per device is enqueued at a time
     LaneSet *lane_set = nullptr;
     int rc = get_lanes(count, st, &lane_set);
@@ -662,6 +671,7 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
         const CholJob<T> &J = jobs[i];
         CholLane &ln = lanes[i];
         plans[i].init(&jobs[i]);
+        plans[i].sblk = sblk;
         plans[i].skip_all = dbg.finish == 0;
         plans[i].skip_mirror = dbg.mirror == 0;
         if (J.n % CNB != 0) return SSA_ERR_INVALID_ARGUMENT;  // callers pad (potrf_padded_batch)
@@ -942,15 +952,16 @@ int potrf_batch(const CholJob<T> *jobs, int count, hipStream_t st) {
 // several: the same recurrence on the MFMA GEMM.
 template <typename T>
 int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb, T *X,
-          T *partial, hipStream_t st) {
+          T *partial, hipStream_t st, int64_t sblk = SNB) {
+    if (!valid_solve_block(sblk)) return SSA_ERR_INVALID_ARGUMENT;
     const AuxLayout al = aux_layout(n);
-    const int64_t ldx = nrhs;
+    const int64_t ldx = nrhs, nblk = ceil_div(n, sblk);
     const bool vec = (nrhs == 1 && ldb == 1);
     int rc;
-    for (int64_t k = 0; k < al.nblk; ++k) {  // forward: L y = b
-        const int64_t r0 = k * SNB, kb = (n - r0 < SNB) ? n - r0 : SNB;
+    for (int64_t k = 0; k < nblk; ++k) {  // forward: L y = b
+        const int64_t r0 = k * sblk, kb = (n - r0 < sblk) ? n - r0 : sblk;
         const int64_t below = n - r0 - kb;
-        const T *inv = aux + al.inv + k * SNB * SNB;
+        const T *inv = aux + al.inv + inv_block_offset(r0);
         if (vec) {
             rc = trmv_t(inv, kb, kb, SNB, B + r0, X + r0, 1.0, 0.0, 1, st);
             if (rc == SSA_OK && below > 0)
@@ -963,9 +974,9 @@ int potrs(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, 
         }
         if (rc != SSA_OK) return rc;
     }
-    for (int64_t k = al.nblk - 1; k >= 0; --k) {  // backward: L^T x = y   (y lives in X, x goes to B)
-        const int64_t r0 = k * SNB, kb = (n - r0 < SNB) ? n - r0 : SNB;
-        const T *invT = aux + al.invT + k * SNB * SNB;
+    for (int64_t k = nblk - 1; k >= 0; --k) {  // backward: L^T x = y   (y lives in X, x goes to B)
+        const int64_t r0 = k * sblk, kb = (n - r0 < sblk) ? n - r0 : sblk;
+        const T *invT = aux + al.invT + inv_block_offset(r0);
         const T *U = L + r0;  // rows 0 .. r0-1 of L^T, columns of this block
         if (vec) {
             rc = trmv_t(invT, kb, kb, SNB, X + r0, B + r0, 1.0, 0.0, 2, st);
@@ -1014,7 +1025,7 @@ __global__ void pad_identity_kernel(T *A, int64_t lda, int64_t n, int64_t np) {
 }
 template <typename T>
 int potrf_padded_batch(int count, void *const *A, const int64_t *n, const int64_t *lda, int32_t *const *info,
-                       void *const *aux, hipStream_t st) {
+                       void *const *aux, hipStream_t st, int64_t sblk) {
     CholJob<T> jobs[kMaxLanes];
     for (int i = 0; i < count; ++i) {
         const int64_t np = ssa_chol_padded_n(n[i]);
@@ -1027,11 +1038,11 @@ int potrf_padded_batch(int count, void *const *A, const int64_t *n, const int64_
         }
         jobs[i] = CholJob<T>{Ai, np, lda[i], info[i], static_cast<T *>(aux[i])};
     }
-    return potrf_batch<T>(jobs, count, st);
+    return potrf_batch<T>(jobs, count, st, sblk);
 }
 template <typename T>
 int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t nrhs, int64_t ldb,
-                 T *ws, hipStream_t st) {
+                 T *ws, hipStream_t st, int64_t sblk = SNB) {
     const int64_t np = ssa_chol_padded_n(n);
     T *X = ws, *Bp = ws + np * nrhs;
     if (hipMemcpy2DAsync(Bp, nrhs * sizeof(T), B, ldb * sizeof(T), nrhs * sizeof(T), n, hipMemcpyDeviceToDevice,
@@ -1039,7 +1050,7 @@ int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t
         return SSA_ERR_HIP;
     if (np > n && hipMemsetAsync(Bp + n * nrhs, 0, (np - n) * nrhs * sizeof(T), st) != hipSuccess)
         return SSA_ERR_HIP;
-    const int rc = potrs<T>(L, np, lda, aux, Bp, nrhs, nrhs, X, ws + 2 * np * nrhs, st);
+    const int rc = potrs<T>(L, np, lda, aux, Bp, nrhs, nrhs, X, ws + 2 * np * nrhs, st, sblk);
     if (rc != SSA_OK) return rc;
     if (hipMemcpy2DAsync(B, ldb * sizeof(T), Bp, nrhs * sizeof(T), nrhs * sizeof(T), n, hipMemcpyDeviceToDevice,
                          st) != hipSuccess)
@@ -1052,10 +1063,11 @@ int potrs_padded(const T *L, int64_t n, int64_t lda, const T *aux, T *B, int64_t
 constexpr int kSolveBatchMax = 8;
 template <typename T>
 int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_t *lda, const T *const *aux, T *const *B,
-                    T *const *X, hipStream_t st) {
+                    T *const *X, hipStream_t st, int64_t sblk = SNB) {
+    if (!valid_solve_block(sblk)) return SSA_ERR_INVALID_ARGUMENT;
     int64_t nblk[kSolveBatchMax], maxblk = 0;
     for (int i = 0; i < count; ++i) {
-        nblk[i] = aux_layout(n[i]).nblk;
+        nblk[i] = ceil_div(n[i], sblk);
         if (nblk[i] > maxblk) maxblk = nblk[i];
     }
     const T *M[kSolveBatchMax];
@@ -1068,8 +1080,8 @@ int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_
         for (int i = 0; i < count; ++i) {
             if (s >= nblk[i]) continue;
             const AuxLayout al = aux_layout(n[i]);
-            const int64_t r0 = s * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB;
-            M[m] = aux[i] + al.inv + s * SNB * SNB;
+            const int64_t r0 = s * sblk, kb = (n[i] - r0 < sblk) ? n[i] - r0 : sblk;
+            M[m] = aux[i] + al.inv + inv_block_offset(r0);
             nr[m] = nc[m] = kb;
             ld[m] = SNB;
             x[m] = B[i] + r0;
@@ -1081,7 +1093,7 @@ int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_
         m = 0;
         for (int i = 0; i < count; ++i) {
             if (s >= nblk[i]) continue;
-            const int64_t r0 = s * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB, below = n[i] - r0 - kb;
+            const int64_t r0 = s * sblk, kb = (n[i] - r0 < sblk) ? n[i] - r0 : sblk, below = n[i] - r0 - kb;
             if (below <= 0) continue;
             M[m] = L[i] + (r0 + kb) * lda[i] + r0;
             nr[m] = below;
@@ -1100,8 +1112,8 @@ int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_
             const int64_t k = nblk[i] - 1 - s;
             if (k < 0) continue;
             const AuxLayout al = aux_layout(n[i]);
-            const int64_t r0 = k * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB;
-            M[m] = aux[i] + al.invT + k * SNB * SNB;
+            const int64_t r0 = k * sblk, kb = (n[i] - r0 < sblk) ? n[i] - r0 : sblk;
+            M[m] = aux[i] + al.invT + inv_block_offset(r0);
             nr[m] = nc[m] = kb;
             ld[m] = SNB;
             x[m] = X[i] + r0;
@@ -1114,7 +1126,7 @@ int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_
         for (int i = 0; i < count; ++i) {
             const int64_t k = nblk[i] - 1 - s;
             if (k <= 0) continue;
-            const int64_t r0 = k * SNB, kb = (n[i] - r0 < SNB) ? n[i] - r0 : SNB;
+            const int64_t r0 = k * sblk, kb = (n[i] - r0 < sblk) ? n[i] - r0 : sblk;
             M[m] = L[i] + r0;   // rows 0 .. r0-1 of L^T, columns of this block
             nr[m] = r0;
             nc[m] = kb;
@@ -1131,7 +1143,7 @@ int potrs_vec_batch(int count, const T *const *L, const int64_t *n, const int64_
 
 template <typename T>
 int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda, const void *const *aux,
-                           void *const *B, void *const *workspace, bool padded, hipStream_t st) {
+                           void *const *B, void *const *workspace, bool padded, hipStream_t st, int64_t sblk) {
     const T *Lp[kSolveBatchMax];
     const T *auxp[kSolveBatchMax];
     T *Bp[kSolveBatchMax], *Xp[kSolveBatchMax];
@@ -1150,7 +1162,7 @@ int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, co
         if (np[i] > n[i] && hipMemsetAsync(Bp[i] + n[i], 0, (np[i] - n[i]) * sizeof(T), st) != hipSuccess)
             return SSA_ERR_HIP;
     }
-    const int rc = potrs_vec_batch<T>(count, Lp, np, lda, auxp, Bp, Xp, st);
+    const int rc = potrs_vec_batch<T>(count, Lp, np, lda, auxp, Bp, Xp, st, sblk);
     if (rc != SSA_OK || padded) return rc;
     for (int i = 0; i < count; ++i)
         if (hipMemcpyAsync(B[i], Bp[i], n[i] * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return SSA_ERR_HIP;
@@ -1162,7 +1174,16 @@ int potrs_padded_vec_batch(int count, const void *const *L, const int64_t *n, co
 extern "C" int ssa_chol_solve_batch(int count, const void *const *L, const int64_t *n, const int64_t *lda,
                                     const void *const *aux, void *const *B, int b_is_padded, int dtype,
                                     void *const *workspace, const size_t *workspace_bytes, void *stream) {
+    return ssa_chol_solve_batch_blk(count, L, n, lda, aux, B, b_is_padded, dtype, workspace, workspace_bytes,
+                                    SSA_CHOL_SOLVE_BLOCK_DEFAULT, stream);
+}
+
+extern "C" int ssa_chol_solve_batch_blk(int count, const void *const *L, const int64_t *n, const int64_t *lda,
+                                        const void *const *aux, void *const *B, int b_is_padded, int dtype,
+                                        void *const *workspace, const size_t *workspace_bytes, int solve_block,
+                                        void *stream) {
     if (count <= 0 || !L || !n || !lda || !aux || !B || !workspace || !workspace_bytes) return SSA_ERR_INVALID_ARGUMENT;
+    if (!valid_solve_block(solve_block)) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < count; ++i) {
         if (!L[i] || !aux[i] || !B[i] || n[i] <= 0 || lda[i] < n[i]) return SSA_ERR_INVALID_ARGUMENT;
@@ -1173,9 +1194,9 @@ extern "C" int ssa_chol_solve_batch(int count, const void *const *L, const int64
         const int c = (count - first < kSolveBatchMax) ? count - first : kSolveBatchMax;
         const int rc = (dtype == SSA_F64)
                            ? potrs_padded_vec_batch<double>(c, L + first, n + first, lda + first, aux + first, B + first,
-                                                            workspace + first, b_is_padded != 0, as_stream(stream))
+                                                            workspace + first, b_is_padded != 0, as_stream(stream), solve_block)
                            : potrs_padded_vec_batch<float>(c, L + first, n + first, lda + first, aux + first, B + first,
-                                                           workspace + first, b_is_padded != 0, as_stream(stream));
+                                                           workspace + first, b_is_padded != 0, as_stream(stream), solve_block);
         if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
@@ -1183,7 +1204,13 @@ extern "C" int ssa_chol_solve_batch(int count, const void *const *L, const int64
 
 extern "C" int ssa_chol_factor_batch(int count, void *const *A, const int64_t *n, const int64_t *lda,
                                      int32_t *const *info, void *const *aux, int dtype, void *stream) {
+    return ssa_chol_factor_batch_blk(count, A, n, lda, info, aux, dtype, SSA_CHOL_SOLVE_BLOCK_DEFAULT, stream);
+}
+
+extern "C" int ssa_chol_factor_batch_blk(int count, void *const *A, const int64_t *n, const int64_t *lda,
+                                         int32_t *const *info, void *const *aux, int dtype, int solve_block, void *stream) {
     if (count <= 0 || !A || !n || !lda || !info || !aux) return SSA_ERR_INVALID_ARGUMENT;
+    if (!valid_solve_block(solve_block)) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < count; ++i)
         if (!A[i] || !info[i] || !aux[i] || n[i] <= 0 || lda[i] < ssa_chol_padded_n(n[i]))
@@ -1193,9 +1220,9 @@ extern "C" int ssa_chol_factor_batch(int count, void *const *A, const int64_t *n
         const int c = (count - first < kMaxLanes) ? count - first : kMaxLanes;
         const int rc = (dtype == SSA_F64)
                            ? potrf_padded_batch<double>(c, A + first, n + first, lda + first, info + first,
-                                                        aux + first, as_stream(stream))
+                                                        aux + first, as_stream(stream), solve_block)
                            : potrf_padded_batch<float>(c, A + first, n + first, lda + first, info + first,
-                                                       aux + first, as_stream(stream));
+                                                       aux + first, as_stream(stream), solve_block);
         if (rc != SSA_OK) return rc;
     }
     return SSA_OK;
@@ -1216,15 +1243,23 @@ extern "C" size_t ssa_chol_solve_workspace_bytes(int64_t n, int64_t nrhs, int dt
 extern "C" int ssa_chol_solve(const void *L, int64_t n, int64_t lda, const void *aux, void *B,
                               int64_t nrhs, int64_t ldb, int dtype, void *workspace,
                               size_t workspace_bytes, void *stream) {
+    return ssa_chol_solve_blk(L, n, lda, aux, B, nrhs, ldb, dtype, workspace, workspace_bytes, SSA_CHOL_SOLVE_BLOCK_DEFAULT,
+                              stream);
+}
+
+extern "C" int ssa_chol_solve_blk(const void *L, int64_t n, int64_t lda, const void *aux, void *B,
+                                  int64_t nrhs, int64_t ldb, int dtype, void *workspace,
+                                  size_t workspace_bytes, int solve_block, void *stream) {
     if (!L || !aux || !B || n <= 0 || nrhs <= 0 || lda < n || ldb < nrhs) return SSA_ERR_INVALID_ARGUMENT;
+    if (!valid_solve_block(solve_block)) return SSA_ERR_INVALID_ARGUMENT;
     if (dtype != SSA_F32 && dtype != SSA_F64) return SSA_ERR_INVALID_ARGUMENT;
     if (!workspace || workspace_bytes < ssa_chol_solve_workspace_bytes(n, nrhs, dtype))
         return SSA_ERR_WORKSPACE_TOO_SMALL;
     if (dtype == SSA_F64)
         return potrs_padded<double>(static_cast<const double *>(L), n, lda, static_cast<const double *>(aux),
                                     static_cast<double *>(B), nrhs, ldb, static_cast<double *>(workspace),
-                                    as_stream(stream));
+                                    as_stream(stream), solve_block);
     return potrs_padded<float>(static_cast<const float *>(L), n, lda, static_cast<const float *>(aux),
                                static_cast<float *>(B), nrhs, ldb, static_cast<float *>(workspace),
-                               as_stream(stream));
+                               as_stream(stream), solve_block);
 }

@@ -86,8 +86,10 @@ class CholFactors:
     ``info`` (LAPACK ?potrf convention) is fetched from the device on first access, so several
     factorizations can be enqueued before the host waits for any of them."""
 
-    def __init__(self, L: torch.Tensor, n: int, aux: torch.Tensor, info_device: torch.Tensor):
+    def __init__(self, L: torch.Tensor, n: int, aux: torch.Tensor, info_device: torch.Tensor,
+                 solve_block: int = 4096):
         self.L, self.n, self.aux, self.info_device = L, n, aux, info_device
+        self.solve_block = int(solve_block)   # rows of the solves' diagonal blocks (ssa_chol_*_blk)
         self.dtype = L.dtype
         self._info: Optional[int] = None
 
@@ -115,9 +117,11 @@ def chol_padded_n(n: int) -> int:
     return int(load_library().ssa_chol_padded_n(n))
 
 
-def chol_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[CholFactors]:
+def chol_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]], solve_block: int = 4096) -> List[CholFactors]:
     """In-place Cholesky of several symmetric positive definite matrices ``(S, n)`` (the films
-    of a device) in one interleaved schedule (``ssa_chol_factor_batch``)."""
+    of a device) in one interleaved schedule (``ssa_chol_factor_batch_blk``).  ``solve_block``: rows of the
+    diagonal blocks of the triangular solves (4096, or 2048 for a factorization that serves few solves: a quarter of
+    the block-inverse flops, twice the launches per solve); the factors remember it."""
     import ctypes
 
     lib = load_library()
@@ -133,12 +137,12 @@ def chol_factor_batch(systems: Sequence[Tuple[torch.Tensor, int]]) -> List[CholF
             raise ValueError("chol_factor_batch: all matrices must have the same dtype.")
         info = torch.zeros(1, dtype=torch.int32, device=S.device)
         aux = torch.empty(lib.ssa_chol_aux_bytes(n, dt) // S.element_size(), dtype=S.dtype, device=S.device)
-        out.append(CholFactors(S, n, aux, info))
+        out.append(CholFactors(S, n, aux, info, solve_block))
     PtrArr, I64Arr = ctypes.c_void_p * count, ctypes.c_int64 * count
-    check(lib.ssa_chol_factor_batch(
+    check(lib.ssa_chol_factor_batch_blk(
         count, PtrArr(*[f.L.data_ptr() for f in out]), I64Arr(*[f.n for f in out]),
         I64Arr(*[f.lda for f in out]), PtrArr(*[f.info_device.data_ptr() for f in out]),
-        PtrArr(*[f.aux.data_ptr() for f in out]), dt, current_stream()), "ssa_chol_factor_batch")
+        PtrArr(*[f.aux.data_ptr() for f in out]), dt, int(solve_block), current_stream()), "ssa_chol_factor_batch_blk")
     return out
 
 
@@ -154,10 +158,10 @@ def chol_chain_stream_costs() -> Tuple[List[float], List[int]]:
     return [float(us[i]) for i in range(k)], [int(grp[i]) for i in range(k)]
 
 
-def chol_factor(S: torch.Tensor, n: int) -> CholFactors:
+def chol_factor(S: torch.Tensor, n: int, solve_block: int = 4096) -> CholFactors:
     """In-place Cholesky of the symmetric positive definite ``S`` (lower triangle given in the
     leading ``n x n`` part of a ``[chol_padded_n(n), lda >= chol_padded_n(n)]`` buffer)."""
-    return chol_factor_batch([(S, n)])[0]
+    return chol_factor_batch([(S, n)], solve_block)[0]
 
 
 def chol_solve(f: CholFactors, B: torch.Tensor) -> torch.Tensor:
@@ -167,8 +171,8 @@ def chol_solve(f: CholFactors, B: torch.Tensor) -> torch.Tensor:
     nrhs = 1 if B.dim() == 1 else B.shape[1]
     nbytes = lib.ssa_chol_solve_workspace_bytes(f.n, nrhs, dt)
     ws = _ws(nbytes, B.device)
-    check(lib.ssa_chol_solve(ptr(f.L), f.n, f.lda, ptr(f.aux), ptr(B), nrhs, nrhs, dt, ptr(ws), nbytes,
-                             current_stream()), "ssa_chol_solve")
+    check(lib.ssa_chol_solve_blk(ptr(f.L), f.n, f.lda, ptr(f.aux), ptr(B), nrhs, nrhs, dt, ptr(ws), nbytes,
+                                 f.solve_block, current_stream()), "ssa_chol_solve_blk")
     return B
 
 
@@ -186,17 +190,19 @@ def chol_solve_batch(factors: Sequence[CholFactors], rhs: Sequence[torch.Tensor]
     dt = dtype_code(factors[0].dtype)
     if any(dtype_code(f.dtype) != dt for f in factors) or any(b.dim() != 1 or not b.is_contiguous() for b in rhs):
         raise ValueError("chol_solve_batch: one contiguous vector per factor, all of the same dtype.")
+    if any(f.solve_block != factors[0].solve_block for f in factors):
+        raise ValueError("chol_solve_batch: all factors must have the same solve_block.")
     for f, b in zip(factors, rhs):
         if b.numel() != (chol_padded_n(f.n) if padded else f.n):
             raise ValueError("chol_solve_batch: a right-hand side has the wrong length.")
     nbytes = [lib.ssa_chol_solve_workspace_bytes(f.n, 1, dt) for f in factors]
     ws = [_ws(nb, rhs[0].device) for nb in nbytes]
     PtrArr, I64Arr, SizeArr = ctypes.c_void_p * count, ctypes.c_int64 * count, ctypes.c_size_t * count
-    check(lib.ssa_chol_solve_batch(
+    check(lib.ssa_chol_solve_batch_blk(
         count, PtrArr(*[f.L.data_ptr() for f in factors]), I64Arr(*[f.n for f in factors]),
         I64Arr(*[f.lda for f in factors]), PtrArr(*[f.aux.data_ptr() for f in factors]),
         PtrArr(*[b.data_ptr() for b in rhs]), int(bool(padded)), dt, PtrArr(*[w.data_ptr() for w in ws]),
-        SizeArr(*nbytes), current_stream()), "ssa_chol_solve_batch")
+        SizeArr(*nbytes), factors[0].solve_block, current_stream()), "ssa_chol_solve_batch_blk")
     return [b[:f.n] for f, b in zip(factors, rhs)] if padded else list(rhs)
 
 

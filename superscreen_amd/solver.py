@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import copy as _copy
 import itertools
+import os
 import logging
 import numbers
 from dataclasses import dataclass, field
@@ -380,7 +381,7 @@ class TerminalSystems:
 
 def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo], *,
                              store_Q: bool = False, method: str = "auto",
-                             owned: Optional[Sequence[str]] = None):
+                             owned: Optional[Sequence[str]] = None, solve_block: int = 4096):
     """``factorize_linear_systems`` (``solver/solve_film.py:151-282``) on the GPU.
     Returns ``(film_systems, hole_systems, terminal_systems, film_data)``.
 
@@ -524,7 +525,7 @@ def factorize_linear_systems(device: Device, film_info_dict: Dict[str, FilmInfo]
     # trailing updates of the films alternate on the stream, each film's panel chain hides behind
     # the other films' updates.
     with_S = [p for p in pending if p[4] is not None]
-    chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S])))
+    chols = dict(zip((p[0] for p in with_S), kernels.chol_factor_batch([(p[4], p[3]) for p in with_S], solve_block)))
     # what the Cholesky systems need besides the factor is enqueued BEFORE the host waits for the pivot reports
     # (one device-to-host copy for all films): nothing is left to launch between the factorization and the solve
     neg_w = {p[0]: (-p[7].w_t[p[2]]).contiguous() for p in with_S}
@@ -689,13 +690,24 @@ class FactorizedModel:
         return _copy.copy(self)
 
 
+# passes up to which a factorization is cheaper overall with 2048-row solve blocks (config H: the factorization saves
+# 3-4 ms, a pass costs 0.12 ms more: break-even near 30)
+FEW_PASSES = int(os.environ.get("SSA_FEW_PASSES", "24"))   # (0: never; an A/B aid)
+
+
 def factorize_model(*, device: Device, current_units: str,
                     terminal_currents: Optional[Dict[str, Dict[str, Union[float, str]]]] = None,
                     circulating_currents: Optional[Dict[str, Union[float, str]]] = None,
                     vortices: Optional[Sequence[Vortex]] = None,
                     self_field: str = "auto", method: str = "auto",
-                    placement: Optional[object] = None) -> FactorizedModel:
+                    placement: Optional[object] = None, expected_passes: Optional[int] = None) -> FactorizedModel:
     """``factorize_model`` (``solver/solve.py:223-287``).
+
+    ``expected_passes`` (extension): how many ``solve_film`` passes per film the model is going to serve, if the
+    caller knows (``solve(device=...)`` does: ``iterations + 1``).  Up to :data:`FEW_PASSES` the Cholesky factorization
+    prepares its triangular solves on 2048-row diagonal blocks instead of 4096-row ones -- a quarter of the
+    block-inverse flops (config H: 3-4 ms less factorization) for twice the dependent launches per solve (+ 0.12 ms
+    per pass): ``include/superscreen_hip.h``, ``ssa_chol_factor_batch_blk``.  ``None``: a model for reuse, 4096.
 
     ``self_field`` (extension): how ``Q @ (w * g)`` (``solve_film.py:565``) is evaluated.
     ``"matrix_free"`` regenerates q_ij on the fly (2.2x faster than streaming a stored Q at n = 50k,
@@ -738,8 +750,11 @@ def factorize_model(*, device: Device, current_units: str,
                                    circulating_currents=circulating_currents,
                                    terminal_currents=terminal_currents)
         owned = None if placement is None else placement.mine(list(device.films))
+        # (method="mixed" runs 1 + MIXED_REFINEMENT_SWEEPS triangular solves per pass)
+        solves = None if expected_passes is None else expected_passes * (1 + MIXED_REFINEMENT_SWEEPS if method == "mixed" else 1)
+        solve_block = 2048 if (solves is not None and solves <= FEW_PASSES) else 4096
         film_systems, hole_systems, terminal_systems, film_data = factorize_linear_systems(
-            device, film_info, store_Q=(self_field == "dense"), method=method, owned=owned)
+            device, film_info, store_Q=(self_field == "dense"), method=method, owned=owned, solve_block=solve_block)
     finally:
         for name in mine_first:
             FilmDeviceData.drop_row_sums(device.meshes[name], device.solve_dtype)
@@ -1157,9 +1172,11 @@ def solve(device: Optional[Device] = None, *, model: Optional[FactorizedModel] =
     if model is None:
         if device is None:
             raise ValueError("Either a model or a device must be provided.")
+        # (the plain cold call of the reference: the factorization serves this solve only -- and says so)
         model = factorize_model(device=device, current_units=current_units,
                                 terminal_currents=terminal_currents,
-                                circulating_currents=circulating_currents, vortices=vortices)
+                                circulating_currents=circulating_currents, vortices=vortices,
+                                expected_passes=(iterations + 1) if len(device.films) > 1 else 1)
     else:
         if (device is not None or terminal_currents is not None
                 or circulating_currents is not None or vortices is not None):

@@ -133,7 +133,7 @@ def test_library_exports_every_declared_symbol():
 
         hip_build.build(force=False, verbose=False)  # cross-compiles for gfx950 without a GPU
     lib = _hip.load_library()  # checks every symbol; no compute call is made without a GPU
-    assert lib.ssa_abi_version() == _hip.ABI_VERSION == 5
+    assert lib.ssa_abi_version() == _hip.ABI_VERSION == 6
     assert lib.ssa_error_string(-3).decode().startswith("workspace")
     perm = np.empty(4, dtype=np.int64)
     ipiv = np.array([2, 1, 3, 3], dtype=np.int32)

@@ -277,6 +277,54 @@ def test_cholesky_factor_solve(K, dtype, tol, n):
     assert K.chol_factor(Sd2, n).info > 0
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-3)])
+@pytest.mark.parametrize("n", [5000, 9300])
+def test_cholesky_solve_block_sizes_agree(K, dtype, tol, n):
+    """ssa_chol_factor_batch_blk / ssa_chol_solve*_blk (ABI 6): the triangular solves on 4096-row diagonal blocks
+    (default) or on smaller ones -- 2048 is what a factorization that serves few solves uses: the inverse levels from
+    the block size upwards are then not built.  Same factor (bit for bit in float64: the schedule does not depend on
+    it), same solutions to rounding for 1 and several right-hand sides, single and batched; a last block that is
+    partial at either size (n = 5 000: 904 rows beyond 4096; n = 9 300: 1 108 beyond 8 192)."""
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(n)
+    U = torch.randn(n, 24, dtype=torch.float64, device="cuda", generator=g)
+    S = U @ U.T / 24
+    S.diagonal().add_(2.0 + torch.rand(n, dtype=torch.float64, device="cuda", generator=g))
+
+    def factor(block):
+        npad = K.chol_padded_n(n)
+        t = torch.zeros((npad, K.padded_ld(npad, dtype)), dtype=tdt, device="cuda")
+        t[:n, :n] = torch.tril(S).to(tdt)
+        f = K.chol_factor(t, n, solve_block=block)
+        assert f.info == 0 and f.solve_block == block
+        return f
+
+    ref = factor(4096)
+    x = torch.randn(n, 3, dtype=torch.float64, device="cuda", generator=g)
+    B = (S @ x).to(tdt)
+    want1 = K.chol_solve(ref, B[:, 0].contiguous().clone()).double()
+    want3 = K.chol_solve(ref, B.clone()).double()
+    assert float((want3 - x).abs().max() / x.abs().max()) < tol
+    for block in (2048, 1024, 256):
+        f = factor(block)
+        if dtype == "float64":
+            assert torch.equal(f.L[:n, :n], ref.L[:n, :n])
+        got1 = K.chol_solve(f, B[:, 0].contiguous().clone()).double()
+        got3 = K.chol_solve(f, B.clone()).double()
+        npad = K.chol_padded_n(n)
+        padded = torch.zeros(npad, dtype=tdt, device="cuda")
+        padded[:n] = B[:, 1]
+        gotb = K.chol_solve_batch([f], [padded], padded=True)[0].double()
+        scale = float(x.abs().max())
+        assert float((got1 - want1).abs().max()) / scale < tol * 1e-2 + 1e-13
+        assert float((got3 - want3).abs().max()) / scale < tol * 1e-2 + 1e-13
+        assert float((gotb - want3[:, 1]).abs().max()) / scale < tol * 1e-2 + 1e-13
+    with pytest.raises(Exception):
+        factor(3000)           # not a power-of-two multiple of 256
+    with pytest.raises(ValueError):
+        K.chol_solve_batch([factor(2048), ref], [torch.zeros(K.chol_padded_n(n), dtype=tdt, device="cuda")] * 2, padded=True)
+
+
 def test_system_assemble_symmetric_scaled(K, disk):
     """S = diag(w) A is symmetric; the lower_only assembly equals tril(w_i * A_ij)."""
     sites, elements, mesh = disk

@@ -358,6 +358,35 @@ def test_mixed_precision_factorization_refined_to_float64(sc):
         sc.factorize_model(device=_mixed_device(sc, spec, "float32")[0], current_units="uA", method="mixed")
 
 
+def test_cold_solve_uses_small_solve_blocks_and_agrees(sc, golden):
+    """``solve(device=...)`` -- the reference's plain cold call -- knows that its factorization serves iterations + 1
+    passes and has the triangular solves prepared on 2048-row blocks (``factorize_model(expected_passes=...)``); a
+    model made for reuse keeps 4096.  Same Solutions to rounding, and the reference's fixture holds for both."""
+    from superscreen_amd import synthetic
+
+    device = synthetic.make_stack_device(34, ("washer", "disk"), solve_dtype="float64")      # 3 571 vertices per film
+    cold = sc.solve(device, applied_field=sc.ConstantField(0.7), field_units="mT", current_units="uA", iterations=3)
+    reuse = sc.factorize_model(device=device, current_units="uA")
+    few = sc.factorize_model(device=device, current_units="uA", expected_passes=4)
+    many = sc.factorize_model(device=device, current_units="uA", expected_passes=400)
+    assert {s.chol.solve_block for s in reuse.film_systems.values()} == {4096}
+    assert {s.chol.solve_block for s in few.film_systems.values()} == {2048}
+    assert {s.chol.solve_block for s in many.film_systems.values()} == {4096}
+    warm = sc.solve(model=reuse, applied_field=sc.ConstantField(0.7), field_units="mT", iterations=3)
+    for a, b in zip(cold, warm):
+        for nm in device.films:
+            assert relerr(a.film_solutions[nm].stream, b.film_solutions[nm].stream) < 1e-12
+            assert relerr(a.film_solutions[nm].self_field, b.film_solutions[nm].self_field) < 1e-11
+    # the reference's own iterates through the cold call (films on their own meshes)
+    d = golden("rings_mixed.npz")
+    mixed, _ = _mixed_device(sc)
+    sols = sc.solve(mixed, applied_field=sc.Parameter(synthetic.tilted_field, B0=float(d["field_mT"])), field_units="mT",
+                    current_units="uA", circulating_currents=_mixed_circ(d), iterations=int(d["iterations"]))
+    for it, sol in enumerate(sols):
+        for nm in mixed.films:
+            assert relerr(sol.film_solutions[nm].stream, d[f"g_{nm}_it{it}"]) < TOL
+
+
 def test_translate_in_place_drops_the_cached_geometry(sc):
     """Device.translate(inplace=True) moves the mesh sites; the GPU copies of the geometry cached on the mesh operators
     and the cached point-in-polygon results follow (they are dropped), and a uniform field gives the same answer."""
