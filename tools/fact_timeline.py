@@ -184,10 +184,32 @@ def rounds(d, nf):
               (f"   beside: {dict(oth)}" if oth else ""))
 
 
+def head(d, nf):
+    """Every kernel from the first row-sum kernel of the last factorization to its first trailing update."""
+    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        r["k"] = short(r["Kernel_Name"])
+    rows.sort(key=lambda r: r["s"])
+    asm = [i for i, r in enumerate(rows) if r["k"] == "assemble"]
+    first_asm = asm[-nf]
+    start = first_asm
+    while start > 0 and rows[first_asm]["s"] - rows[start - 1]["s"] < 3_000_000 and rows[start - 1]["k"] != "transpose":
+        start -= 1
+    t0 = rows[start]["s"]
+    for r in rows[start:]:
+        print(f"{(r['s'] - t0) / 1e3:9.1f} us  +{(r['e'] - r['s']) / 1e3:8.1f} us  queue {r['Queue_Id']:>3}  {r['k']}")
+        if r["k"] == "SYRK":
+            break
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "run":
         run(sys.argv[2] if len(sys.argv) > 2 else "float64")
+    elif mode == "head":
+        head(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 2)
     elif mode == "table":
         table(sys.argv[2], [int(a) for a in sys.argv[3:]] or [18150, 20419])
     else:

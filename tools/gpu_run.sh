@@ -49,6 +49,7 @@ for step in "$@"; do
               echo "timeline[$kind] trace rc=$?" >> $sum
               nf=2; unk=""; [ "$kind" = stack4 ] && { nf=4; unk="24571 24571 24571 24571"; }; [ "$kind" = single ] && { nf=1; unk="41419"; }
               timeout 600 python tools/fact_timeline.py rounds $td $nf > $out/round_timeline_$kind.txt 2>&1
+              timeout 600 python tools/fact_timeline.py head $td $nf > $out/head_timeline_$kind.txt 2>&1
               [ "$kind" != float32 ] && timeout 900 python tools/fact_timeline.py table $td $unk > $out/syrk_launch_table_$kind.txt 2>&1
               echo "timeline[$kind] $(tail -2 $out/syrk_launch_table_$kind.txt 2>/dev/null | head -1)" >> $sum ;;
     passes)   td=/tmp/ssa_pt_${tag}; rm -rf $td; here=$PWD
