@@ -1045,6 +1045,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     parity_sols, parity_field = sols, 0.1 * (1 + rank + world * (args.steps - 1))   # last timed step, for the oracle
+    parity_model_solve_block = max((s.chol.solve_block for s in model.film_systems.values() if s.chol is not None), default=0)
     prof = {}
     for kind, label in ((0, "ssa::gemm_kernel<double, true> (NN: LU trailing / in-panel updates)"),
                         (1, "ssa::gemm_op_kernel<double, 0, 1, true> (SYRK on the lower tiles: Cholesky trailing update)"),
@@ -1080,6 +1081,7 @@ def main():
     value = total_solves / elapsed
     unknowns = [int(len(s.indices)) for s in model.film_systems.values()]
     used_chol = all(s.chol is not None for s in model.film_systems.values())
+    solve_block = parity_model_solve_block
 
     extras = {}
     if rank == 0:
@@ -1235,6 +1237,11 @@ def main():
                 # self_field="matrix_free" pay the all-pairs sum on every row).  It is an output, not an input of the
                 # next iterate; its difference from the reference's value is parity.max_rel_err_self_field.
                 "self_field_mode": "auto: London identity on the unknowns' rows, all-pairs sum on the other rows",
+                # every step factorizes for ITS passes: factorize_model(expected_passes=iterations + 1), what the
+                # reference's plain cold call solve(device=...) does in this package -- the triangular solves then run
+                # on 2048-row diagonal blocks (a model made for reuse: 4096)
+                "factorization": ("cholesky of diag(w) A" if used_chol else "lu of -A") +
+                                 f", solve blocks of {solve_block} rows",
             },
             "roofline": {
                 "kernel": dom_label + ", v_mfma_f64_16x16x4_f64",
