@@ -641,7 +641,7 @@ def mutual_fixture(K, kinds, z0s, Lambda, iterations, fname, I_circ=1000.0):
     print("wrote", fname, "n =", n, "holes", hole_names)
 
 
-def _mixed_setup(spec, circ_by_hole):
+def _mixed_setup(spec, circ_by_hole, lambda_funcs=None, vortices=()):
     """Reference-side objects of a device whose films have their own meshes (superscreen_amd.synthetic.make_device
     builds the same device for the GPU path): one reference ``Mesh`` per film, ``FilmInfo`` per film with ITS layer's
     Lambda and ITS polygons."""
@@ -656,8 +656,11 @@ def _mixed_setup(spec, circ_by_hole):
     for f in spec["films"]:
         nm = f["name"]
         holes = {} if geos[nm]["hole_polygon"] is None else {"hole_" + nm: geos[nm]["hole_polygon"]}
-        infos[nm] = make_film_info(nm, f["layer"], meshes[nm], geos[nm]["film_polygon"], holes,
-                                   layer[f["layer"]]["Lambda"], circ_by_hole, "float64")
+        Lam = layer[f["layer"]]["Lambda"]
+        if lambda_funcs and f["layer"] in lambda_funcs:      # Lambda(x, y) on this film's own sites (solver/utils.py:263-266)
+            Lam = lambda_funcs[f["layer"]](meshes[nm].sites[:, 0], meshes[nm].sites[:, 1])
+        infos[nm] = make_film_info(nm, f["layer"], meshes[nm], geos[nm]["film_polygon"], holes, Lam, circ_by_hole, "float64")
+        infos[nm].vortices = tuple(v for v in vortices if v.film == nm)    # get_holes_and_vortices_by_film
         z0[nm] = layer[f["layer"]]["z0"]
     return names, geos, meshes, infos, z0
 
@@ -712,15 +715,19 @@ def _fluxoid_raw(geo, mesh, sol, Lambda):
     Jp[~contains(geo["film_polygon"], poly)] = 0
     Jp[~np.isfinite(Jp).all(axis=1)] = 0
     dl = np.diff(poly, axis=0)
-    int_J = np.trapezoid(Lambda * np.ones(len(poly))[:-1] * np.sum(Jp[:-1] * dl, axis=1))
+    Lam = Lambda(poly[:, 0], poly[:, 1]) if callable(Lambda) else Lambda * np.ones(len(poly))   # solution.py:548-552
+    int_J = np.trapezoid(Lam[:-1] * np.sum(Jp[:-1] * dl, axis=1))
     return flux_part, int_J
 
 
-def mixed_mesh_fixture(spec, iterations, fname, circ, field_mT):
+def mixed_mesh_fixture(spec, iterations, fname, circ, field_mT, lambda_funcs=None, vortices=()):
     """Coupled films with DIFFERENT meshes (different vertex counts, a lateral offset, per-layer Lambda including 0,
     two films in one layer): every Jacobi iterate and the fluxoid parts of every washer -- the general case of
     solver/solve.py:495-515 that the coaxial shared-mesh stacks above never reach."""
-    names, geos, meshes, infos, z0 = _mixed_setup(spec, circ)
+    from superscreen.solution import Vortex  # the reference's dataclass
+
+    vortices = [Vortex(x=x, y=y, film=film, nPhi0=n) for x, y, film, n in vortices]
+    names, geos, meshes, infos, z0 = _mixed_setup(spec, circ, lambda_funcs, vortices)
     layer = {l["name"]: l for l in spec["layers"]}
     applied = {}
     for nm in names:
@@ -740,7 +747,7 @@ def mixed_mesh_fixture(spec, iterations, fname, circ, field_mT):
             if s[nm].field_from_other_films is not None:
                 out[f"other_{nm}_it{it}"] = s[nm].field_from_other_films
             if geos[nm]["hole_polygon"] is not None:
-                Lam = layer[infos[nm].layer]["Lambda"]
+                Lam = (lambda_funcs or {}).get(infos[nm].layer, layer[infos[nm].layer]["Lambda"])
                 out[f"flux_part_raw_{nm}_it{it}"], out[f"int_J_raw_{nm}_it{it}"] = \
                     _fluxoid_raw(geos[nm], meshes[nm], s[nm], Lam)
     np.savez_compressed(os.path.join(GOLDEN, fname), **out)
@@ -777,6 +784,8 @@ if __name__ == "__main__":
     if "--only-mixed" in sys.argv:
         mixed_mesh_fixture(synthetic.RINGS_MIXED, 4, "rings_mixed.npz",
                            {"hole_big_ring": 3.0, "hole_little_ring": -1.5}, 0.8)
+        mixed_mesh_fixture(synthetic.RINGS_MIXED, 3, "rings_mixed_extras.npz", {"hole_big_ring": 1.0, "hole_little_ring": 2.0},
+                           0.5, lambda_funcs={"layer1": synthetic.lambda_ramp}, vortices=synthetic.RINGS_MIXED_VORTICES)
         mixed_mutual_fixture(synthetic.RINGS_MIXED, 3, "mutual_rings_mixed.npz")
         sys.exit(0)
     if "--only-vortex" in sys.argv:
@@ -807,6 +816,8 @@ if __name__ == "__main__":
     mixed_mesh_fixture(synthetic.RINGS_MIXED, 4, "rings_mixed.npz",
                        {"hole_big_ring": 3.0, "hole_little_ring": -1.5}, 0.8)
     mixed_mutual_fixture(synthetic.RINGS_MIXED, 3, "mutual_rings_mixed.npz")
+    mixed_mesh_fixture(synthetic.RINGS_MIXED, 3, "rings_mixed_extras.npz", {"hole_big_ring": 1.0, "hole_little_ring": 2.0},
+                       0.5, lambda_funcs={"layer1": synthetic.lambda_ramp}, vortices=synthetic.RINGS_MIXED_VORTICES)
     sheet_field_fixture("sheet_field.npz")
     potential_and_flux_fixture("potential_flux.npz")
     vortex_fixture(13, False, "vortex_disk_K13.npz")

@@ -366,14 +366,16 @@ def make_film(name: str, mesh: OracleMesh, *, z0: float, Lambda, in_film: np.nda
 
 
 def make_films(layers: Sequence[dict], films: Sequence[dict], geometries: Dict[str, dict],
-               dtype="float64", meshes: Optional[Dict[str, OracleMesh]] = None) -> List[OracleFilm]:
+               dtype="float64", meshes: Optional[Dict[str, OracleMesh]] = None,
+               lambda_funcs: Optional[Dict[str, object]] = None) -> List[OracleFilm]:
     """The films of a device in which EVERY film has its own mesh (the general case of ``make_film_info``,
     solver/utils.py:244-246: ``mesh = device.meshes[name]``, ``layer = device.layers[film.layer]``).
 
     ``layers``: ``dict(name=, z0=, Lambda=)``; ``films``: ``dict(name=, layer=, ...)``; ``geometries[name]``:
     ``dict(sites=, elements=, film_polygon=, hole_polygon= | None)`` (what
     ``superscreen_amd.synthetic.film_geometry`` returns -- data only).  A film's hole is ``"hole_" + name``; hole
-    membership is ``Polygon.contains_points`` = matplotlib ``Path.contains_points`` (device/polygon.py:159)."""
+    membership is ``Polygon.contains_points`` = matplotlib ``Path.contains_points`` (device/polygon.py:159).
+    ``lambda_funcs[layer]``: a ``Lambda(x, y)`` evaluated on the film's own sites (solver/utils.py:263-266)."""
     from matplotlib.path import Path
 
     layer = {l["name"]: l for l in layers}
@@ -384,7 +386,10 @@ def make_films(layers: Sequence[dict], films: Sequence[dict], geometries: Dict[s
         holes = {}
         if geo.get("hole_polygon") is not None:
             holes["hole_" + f["name"]] = Path(geo["hole_polygon"], closed=True).contains_points(mesh.sites)
-        out.append(make_film(f["name"], mesh, z0=layer[f["layer"]]["z0"], Lambda=layer[f["layer"]]["Lambda"],
+        Lam = layer[f["layer"]]["Lambda"]
+        if lambda_funcs and f["layer"] in lambda_funcs:
+            Lam = lambda_funcs[f["layer"]](mesh.sites[:, 0], mesh.sites[:, 1])
+        out.append(make_film(f["name"], mesh, z0=layer[f["layer"]]["z0"], Lambda=Lam,
                              in_film=Path(geo["film_polygon"], closed=True).contains_points(mesh.sites),
                              holes_mask=holes, dtype=dtype))
     return out
@@ -588,11 +593,13 @@ def biot_savart_film_to_film(*, film1_sites, film1_z0, film1_areas, film1_J, fil
 def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
           circulating_currents: Optional[Dict[str, float]] = None,
           field_conversion: Optional[float] = None,
-          biot_savart=None) -> List[Dict[str, OracleFilmSolution]]:
+          biot_savart=None, vortices: Optional[Dict[str, Sequence[Tuple[float, float, float]]]] = None
+          ) -> List[Dict[str, OracleFilmSolution]]:
     """solver/solve.py:422-547 -- first pass, then ``iterations`` Jacobi rounds.  Returns the
     per-iteration list (length ``iterations + 1``; 1 for a single film, :486-489).
 
     ``applied_field_mT``: float (uniform field in mT) or callable ``f(x, y, z)``.
+    ``vortices``: ``{film: [(x, y, nPhi0), ...]}`` -- the trapped vortices by film (solver/utils.py:205-231).
     ``biot_savart``: the film-to-film kernel to use (default: the numpy restatement above; the
     headline-size checks pass the OpenMP C port ``cpu_kernels.biot_savart_film_to_film``, which the
     CPU tests hold against the numpy form).
@@ -612,6 +619,7 @@ def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
                 f, applied[f.name], field_conversion=conv,
                 circulating_currents=circulating_currents,
                 field_from_other_films=None if other is None else other[f.name],
+                vortices=(vortices or {}).get(f.name, ()),
             )
             for f in films
         }
@@ -639,7 +647,7 @@ def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
 # Fluxoid (solution.py:484-563, 278-319) in raw units: field_units * length^2
 # --------------------------------------------------------------------------------------
 def polygon_fluxoid_raw(film: OracleFilm, sol: OracleFilmSolution, polygon_points: np.ndarray,
-                        in_polygon: np.ndarray, in_film_poly: np.ndarray) -> Tuple[float, float]:
+                        in_polygon: np.ndarray, in_film_poly: np.ndarray, lambda_func=None) -> Tuple[float, float]:
     """Returns ``(flux_part [mT um^2], int_J [uA um])``.
 
     ``flux_part = sum_{i in polygon} total_field_i w_i`` (solution.py:535-538);
@@ -661,7 +669,9 @@ def polygon_fluxoid_raw(film: OracleFilm, sol: OracleFilmSolution, polygon_point
     ]).T
     Jp[~in_film_poly] = 0
     Jp[~np.isfinite(Jp).all(axis=1)] = 0
-    Lam = float(film.Lambda[0]) * np.ones(len(polygon_points))
+    # solution.py:548-551: a Parameter Lambda is evaluated at the polygon's vertices (``lambda_func(x, y)``)
+    Lam = (np.asarray(lambda_func(xv, yv), dtype=float) if lambda_func is not None
+           else float(film.Lambda[0]) * np.ones(len(polygon_points)))
     dl = np.diff(polygon_points, axis=0)
     int_J = float(np.trapezoid(Lam[:-1] * np.sum(Jp[:-1] * dl, axis=1)))
     return flux_part, int_J

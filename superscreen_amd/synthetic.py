@@ -176,6 +176,17 @@ RINGS_MIXED = dict(
 )
 
 
+def lambda_ramp(x, y, Lambda0: float = 0.2, cx: float = 0.8, cy: float = -0.5):
+    """The Lambda(x, y) of the upper layer in the combined mixed-mesh fixture (``rings_mixed_extras.npz``): a ramp
+    across the little ring (centred at ``(cx, cy)``) with a quadratic term; positive on the whole film."""
+    x, y = np.asarray(x), np.asarray(y)
+    return Lambda0 * (1.0 + 0.08 * (x - cx) + 0.01 * (y - cy) ** 2)
+
+
+# trapped vortices of the combined fixture: (x, y, film, nPhi0)
+RINGS_MIXED_VORTICES = ((5.5, 1.0, "big_ring", 1), (12.3, 3.2, "side_disk", -1))
+
+
 def tilted_field(x, y, z, B0: float = 1.0):
     """The applied field of the mixed-mesh fixtures: not uniform, so that a film's position matters."""
     return B0 * (1.0 + 0.04 * np.asarray(x) - 0.03 * np.asarray(y) + 0.1 * np.asarray(z))

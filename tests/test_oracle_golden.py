@@ -239,6 +239,44 @@ def test_jacobi_trace_and_fluxoids_films_with_their_own_meshes(golden):
                 assert abs(int_J - float(d[f"int_J_raw_{nm}_it{it}"])) <= 1e-10 * abs(float(d[f"int_J_raw_{nm}_it{it}"]))
 
 
+def test_vortices_and_lambda_xy_in_coupled_films_with_their_own_meshes(golden):
+    """The branches of solve_film that the single-film fixtures pin one at a time, together inside the Jacobi loop of
+    three films on their own meshes (tests/golden/rings_mixed_extras.npz): Lambda(x, y) in the upper layer (the
+    grad-Lambda term, solve_film.py:181-185; the fluxoid's Lambda at the polygon's vertices, solution.py:548-551),
+    one trapped vortex in the big ring (Lambda = 0) and one in the side disk (solve_film.py:541-554), circulating
+    currents in both rings."""
+    d = golden("rings_mixed_extras.npz")
+    syn = _synthetic()
+    spec = syn.RINGS_MIXED
+    geos = {f["name"]: syn.film_geometry(f["kind"], f["K"], film_radius=f["film_radius"], center=f["center"])
+            for f in spec["films"]}
+    lam = {"layer1": syn.lambda_ramp}
+    films = orc.make_films(spec["layers"], spec["films"], geos, lambda_funcs=lam)
+    vort = {}
+    for x, y, film, n in syn.RINGS_MIXED_VORTICES:
+        vort.setdefault(film, []).append((x, y, n))
+    circ = dict(zip((str(h) for h in d["circ_holes"]), d["circ_values"]))
+    B0 = float(d["field_mT"])
+    trace = orc.solve(films, lambda x, y, z: syn.tilted_field(x, y, z, B0), iterations=int(d["iterations"]),
+                      circulating_currents=circ, field_conversion=float(d["field_conversion"]), vortices=vort)
+    layer_of = {f["name"]: f["layer"] for f in spec["films"]}
+    for it, sols in enumerate(trace):
+        for f in films:
+            nm = f.name
+            assert relerr(sols[nm].stream, d[f"g_{nm}_it{it}"]) < RTOL
+            assert relerr(sols[nm].current_density, d[f"J_{nm}_it{it}"]) < RTOL
+            assert relerr(sols[nm].self_field, d[f"self_field_{nm}_it{it}"]) < RTOL
+            if it > 0:
+                assert relerr(sols[nm].field_from_other_films, d[f"other_{nm}_it{it}"]) < RTOL
+            if geos[nm]["hole_polygon"] is not None:
+                poly = geos[nm]["fluxoid_polygon"]
+                flux, int_J = orc.polygon_fluxoid_raw(f, sols[nm], poly, contains(poly, f.mesh.sites),
+                                                      contains(geos[nm]["film_polygon"], poly),
+                                                      lambda_func=lam.get(layer_of[nm]))
+                assert abs(flux - float(d[f"flux_part_raw_{nm}_it{it}"])) <= 1e-10 * abs(float(d[f"flux_part_raw_{nm}_it{it}"]))
+                assert abs(int_J - float(d[f"int_J_raw_{nm}_it{it}"])) <= 1e-10 * abs(float(d[f"int_J_raw_{nm}_it{it}"])) + 1e-300
+
+
 def test_mutual_inductance_raw_parts_films_with_their_own_meshes(golden):
     d = golden("mutual_rings_mixed.npz")
     syn = _synthetic()

@@ -186,6 +186,42 @@ def test_films_with_their_own_meshes_vs_reference_fixture(sc, golden, method):
             assert relerr(a.film_solutions[nm].stream, b.film_solutions[nm].stream) < (0 if method == "auto" else TOL) + 1e-300
 
 
+def test_vortices_and_lambda_xy_in_coupled_films_with_their_own_meshes(sc, golden):
+    """The branches the single-film fixtures pin one at a time, TOGETHER in the Jacobi loop of three films on their own
+    meshes (tests/golden/rings_mixed_extras.npz, recorded from the reference): Lambda(x, y) in the upper layer (that film
+    takes the LU route, solve_film.py:181-185), a trapped vortex in the big ring (Lambda = 0) and one in the side disk
+    (:541-554: one extra right-hand side each instead of the full inverse), circulating currents in both rings, a
+    field that is not uniform.  Every iterate; the fluxoid of the ring with Lambda(x, y) takes Lambda at the polygon's
+    vertices (solution.py:548-551)."""
+    from superscreen_amd import synthetic
+
+    d = golden("rings_mixed_extras.npz")
+    spec = {"films": synthetic.RINGS_MIXED["films"],
+            "layers": [dict(l, Lambda=(sc.Parameter(synthetic.lambda_ramp) if l["name"] == "layer1" else l["Lambda"]))
+                       for l in synthetic.RINGS_MIXED["layers"]]}
+    device, geos = _mixed_device(sc, spec)
+    vortices = [sc.Vortex(x=x, y=y, film=film, nPhi0=n) for x, y, film, n in synthetic.RINGS_MIXED_VORTICES]
+    names = [str(s) for s in d["names"]]
+    iters = int(d["iterations"])
+    sols = sc.solve(device, applied_field=sc.Parameter(synthetic.tilted_field, B0=float(d["field_mT"])), field_units="mT",
+                    current_units="uA", circulating_currents=_mixed_circ(d), vortices=vortices, iterations=iters)
+    assert len(sols) == iters + 1
+    for it, sol in enumerate(sols):
+        for nm in names:
+            fs = sol.film_solutions[nm]
+            assert relerr(fs.stream, d[f"g_{nm}_it{it}"]) < TOL
+            assert relerr(fs.current_density, d[f"J_{nm}_it{it}"]) < TOL
+            assert relerr(fs.self_field, d[f"self_field_{nm}_it{it}"]) < TOL
+            if it > 0:
+                assert relerr(fs.field_from_other_films, d[f"other_{nm}_it{it}"]) < TOL
+            if geos[nm]["hole_polygon"] is not None:
+                fl = sol.polygon_fluxoid(geos[nm]["fluxoid_polygon"], film=nm, units="mT * um**2", with_units=False)
+                ref_flux = float(d[f"flux_part_raw_{nm}_it{it}"])
+                ref_sc = orc.MU_0 * float(d[f"int_J_raw_{nm}_it{it}"]) * 1e-12 / (1e-3 * 1e-12)
+                assert abs(fl.flux_part - ref_flux) < 1e-9 * abs(ref_flux)
+                assert abs(fl.supercurrent_part - ref_sc) <= 1e-9 * abs(ref_sc)
+
+
 def test_solve_sweep_films_with_their_own_meshes(sc, golden):
     """solve_sweep (n x nvec operands per film, pair kernels between films of different size) on the mixed-mesh
     device: the column that carries the fixture's field reproduces the reference's iterates, every column equals
