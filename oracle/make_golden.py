@@ -372,6 +372,79 @@ def terminal_fixture(nx, ny, hole_radius, fname):
     print("wrote", fname, "n =", n)
 
 
+def strip_ring_fixture(fname, iterations=3, current=5.0, field_mT=0.2, circ=0.7):
+    """A film WITH TERMINALS coupled to a second film on its own mesh (a field coil under a pickup loop): the transport
+    branch of solve_film (solver/solve_film.py:505-524, 557-562) inside the Jacobi loop of solver/solve.py:491-536 --
+    the strip's sheet current, transport part included, is the source of the ring's coupling field and vice versa."""
+    _fs = importlib.util.spec_from_file_location("_fem", os.path.join(ROOT, "superscreen_amd", "fem.py"))
+    fem_mod = importlib.util.module_from_spec(_fs)
+    _fs.loader.exec_module(fem_mod)
+    spec = synthetic.STRIP_RING
+    geo = synthetic.strip_ring_geometry(spec)
+    strip, ring = geo["strip"], geo["ring"]
+    meshes = {"strip": Mesh.from_triangulation(strip["sites"], strip["elements"]),
+              "ring": Mesh.from_triangulation(ring["sites"], ring["elements"])}
+    terms = [TerminalStub(name, pts) for name, pts in strip["terminals"].items()]
+    indices = fem_mod.boundary_vertices(strip["sites"], strip["elements"])      # device/device.py:486-500
+    for t in terms:
+        t_ix = t.contains_points(strip["sites"][indices], index=True)
+        discont = np.diff(t_ix) != 1
+        if np.any(discont):
+            indices = np.roll(indices, -(np.where(discont)[0][0] + 1))
+            break
+    device_like = SimpleNamespace(terminals={"strip": terms}, meshes=meshes)
+    tc = {"source": current, "drain": -current}
+    infos = {
+        "strip": make_film_info("strip", "base", meshes["strip"], strip["film_polygon"], {}, spec["strip_Lambda"], {},
+                                "float64", boundary=indices, terminal_currents=tc),
+        "ring": make_film_info("ring", "top", meshes["ring"], ring["film_polygon"], {"hole_ring": ring["hole_polygon"]},
+                               spec["ring_Lambda"], {"hole_ring": circ}, "float64"),
+    }
+    z0 = {"strip": 0.0, "ring": spec["ring_z0"]}
+    names = ["strip", "ring"]
+    film_systems, hole_systems, terminal_systems = factorize_linear_systems(device_like, infos)
+    applied = {nm: (field_mT * FIELD_CONV) * np.ones(len(meshes[nm].sites)) for nm in names}
+
+    def run(other):
+        return {
+            nm: solve_film(
+                device=device_like, applied_field=applied[nm], film_info=infos[nm],
+                film_system=film_systems[nm], hole_systems=hole_systems[nm],
+                field_conversion=FIELD_CONV, vortex_flux=VORTEX_FLUX,
+                field_from_other_films=None if other is None else other[nm],
+                terminal_systems=terminal_systems.get(nm, None),
+            )
+            for nm in names
+        }
+
+    sols = run(None)
+    trace = [sols]
+    for it in range(iterations):
+        other = {nm: np.zeros(len(meshes[nm].sites)) for nm in names}
+        for src, tgt in itertools.product(names, repeat=2):
+            if src == tgt:
+                continue
+            other[tgt] += biot_savart_film_to_film(
+                film1_sites=meshes[src].sites, film1_z0=z0[src], film1_areas=infos[src].weights,
+                film1_J=sols[src].current_density, film2_sites=meshes[tgt].sites, film2_z0=z0[tgt],
+            )
+        sols = run(other)
+        trace.append(sols)
+    out = dict(names=np.array(names), iterations=iterations, current=current, field_mT=field_mT, circ=circ,
+               boundary_indices=indices, field_conversion=FIELD_CONV)
+    for it, s_ in enumerate(trace):
+        for nm in names:
+            out[f"g_{nm}_it{it}"] = s_[nm].stream
+            out[f"J_{nm}_it{it}"] = s_[nm].current_density
+            out[f"self_field_{nm}_it{it}"] = s_[nm].self_field
+            if s_[nm].field_from_other_films is not None:
+                out[f"other_{nm}_it{it}"] = s_[nm].field_from_other_films
+        out[f"flux_part_raw_ring_it{it}"], out[f"int_J_raw_ring_it{it}"] = \
+            _fluxoid_raw(ring, meshes["ring"], s_["ring"], spec["ring_Lambda"])
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    print("wrote", fname, "films", {nm: len(meshes[nm].sites) for nm in names})
+
+
 def lambda_xy(x, y):
     """The Lambda(x, y) of the inhomogeneous fixture (um)."""
     return 0.2 * (1.0 + 0.5 * x / 5.0 + 0.3 * (y / 5.0) ** 2)
@@ -796,6 +869,9 @@ if __name__ == "__main__":
         terminal_fixture(24, 10, 0.0, "terminals_strip.npz")
         terminal_fixture(24, 10, 0.9, "terminals_strip_hole.npz")
         sys.exit(0)
+    if "--only-strip-ring" in sys.argv:
+        strip_ring_fixture("strip_ring.npz")
+        sys.exit(0)
     if "--only-inhomogeneous" in sys.argv:
         inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")
         sys.exit(0)
@@ -825,3 +901,4 @@ if __name__ == "__main__":
     inhomogeneous_fixture(11, True, "inhomogeneous_washer_K11.npz")
     terminal_fixture(24, 10, 0.0, "terminals_strip.npz")
     terminal_fixture(24, 10, 0.9, "terminals_strip_hole.npz")
+    strip_ring_fixture("strip_ring.npz")

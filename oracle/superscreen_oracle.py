@@ -593,13 +593,14 @@ def biot_savart_film_to_film(*, film1_sites, film1_z0, film1_areas, film1_J, fil
 def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
           circulating_currents: Optional[Dict[str, float]] = None,
           field_conversion: Optional[float] = None,
-          biot_savart=None, vortices: Optional[Dict[str, Sequence[Tuple[float, float, float]]]] = None
-          ) -> List[Dict[str, OracleFilmSolution]]:
+          biot_savart=None, vortices: Optional[Dict[str, Sequence[Tuple[float, float, float]]]] = None,
+          terminal_currents: Optional[Dict[str, Dict[str, float]]] = None) -> List[Dict[str, OracleFilmSolution]]:
     """solver/solve.py:422-547 -- first pass, then ``iterations`` Jacobi rounds.  Returns the
     per-iteration list (length ``iterations + 1``; 1 for a single film, :486-489).
 
     ``applied_field_mT``: float (uniform field in mT) or callable ``f(x, y, z)``.
     ``vortices``: ``{film: [(x, y, nPhi0), ...]}`` -- the trapped vortices by film (solver/utils.py:205-231).
+    ``terminal_currents``: ``{film: {terminal: current}}`` for films made with ``terminal_masks`` (solver/solve.py:530).
     ``biot_savart``: the film-to-film kernel to use (default: the numpy restatement above; the
     headline-size checks pass the OpenMP C port ``cpu_kernels.biot_savart_film_to_film``, which the
     CPU tests hold against the numpy form).
@@ -620,6 +621,7 @@ def solve(films: Sequence[OracleFilm], applied_field_mT, *, iterations: int = 0,
                 circulating_currents=circulating_currents,
                 field_from_other_films=None if other is None else other[f.name],
                 vortices=(vortices or {}).get(f.name, ()),
+                terminal_currents=(terminal_currents or {}).get(f.name),
             )
             for f in films
         }

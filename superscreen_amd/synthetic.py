@@ -237,3 +237,56 @@ def make_strip_device(nx: int = 40, ny: int = 16, *, length: float = 10.0, width
                     terminals={"strip": [src, drn]}, length_units="um", solve_dtype=solve_dtype)
     device.meshes = {"strip": Mesh.from_triangulation(sites, elements)}
     return device
+
+
+# The coupled device of tests/golden/strip_ring.npz: a current-carrying strip (terminals) under a ring on its own mesh
+# -- a field coil and a pickup loop, the shape of the reference's susceptometer notebooks.
+STRIP_RING = dict(nx=24, ny=10, length=10.0, width=4.0, strip_Lambda=0.3, ring_K=9, ring_radius=3.0, ring_center=(1.0, 0.5),
+                  ring_z0=0.6, ring_Lambda=0.15)
+
+
+def strip_ring_geometry(spec: dict = STRIP_RING) -> dict:
+    """Meshes and polygons of the strip + ring device (data only: used by the fixture generator, the oracle tests and
+    :func:`make_strip_ring_device`)."""
+    try:
+        from .geometry import box
+    except ImportError:   # (loaded as a stand-alone file by oracle/make_golden.py and the oracle tests)
+        import importlib.util
+        import os
+
+        _spec = importlib.util.spec_from_file_location("_ssa_geometry", os.path.join(os.path.dirname(__file__), "geometry.py"))
+        _geo = importlib.util.module_from_spec(_spec)
+        _spec.loader.exec_module(_geo)
+        box = _geo.box
+
+    nx, ny, length, width = spec["nx"], spec["ny"], spec["length"], spec["width"]
+    sites, elements = strip_mesh(nx, ny, length, width)
+    eps = 1e-3 * min(length / nx, width / ny)
+    dx = length / nx
+    ring = film_geometry("washer", spec["ring_K"], film_radius=spec["ring_radius"], center=spec["ring_center"])
+    return dict(
+        strip=dict(sites=sites, elements=elements, film_polygon=box(length + 2 * eps, width + 2 * eps, points=401),
+                   terminals={"source": box(dx, width + 4 * eps, points=41, center=(-length / 2, 0.0)),
+                              "drain": box(dx, width + 4 * eps, points=41, center=(length / 2, 0.0))}),
+        ring=ring)
+
+
+def make_strip_ring_device(spec: dict = STRIP_RING, solve_dtype: str = "float64"):
+    """A strip with a ``source`` and a ``drain`` terminal in layer ``base`` (z = 0) and a ring (``hole_ring``) on its
+    own mesh in layer ``top``."""
+    from .device import Device, Layer, Polygon
+    from .mesh import Mesh
+
+    geo = strip_ring_geometry(spec)
+    strip, ring = geo["strip"], geo["ring"]
+    device = Device(
+        "strip_ring",
+        layers=[Layer("base", Lambda=spec["strip_Lambda"], z0=0.0), Layer("top", Lambda=spec["ring_Lambda"], z0=spec["ring_z0"])],
+        films=[Polygon("strip", layer="base", points=strip["film_polygon"]),
+               Polygon("ring", layer="top", points=ring["film_polygon"])],
+        holes=[Polygon("hole_ring", layer="top", points=ring["hole_polygon"])],
+        terminals={"strip": [Polygon(name, layer="base", points=pts) for name, pts in strip["terminals"].items()]},
+        length_units="um", solve_dtype=solve_dtype)
+    device.meshes = {"strip": Mesh.from_triangulation(strip["sites"], strip["elements"]),
+                     "ring": Mesh.from_triangulation(ring["sites"], ring["elements"])}
+    return device

@@ -277,6 +277,44 @@ def test_vortices_and_lambda_xy_in_coupled_films_with_their_own_meshes(golden):
                 assert abs(int_J - float(d[f"int_J_raw_{nm}_it{it}"])) <= 1e-10 * abs(float(d[f"int_J_raw_{nm}_it{it}"])) + 1e-300
 
 
+def test_film_with_terminals_coupled_to_a_ring(golden):
+    """tests/golden/strip_ring.npz (recorded from the reference): a strip carrying a transport current between two
+    terminals under a ring on its own mesh -- the terminal branch of solve_film (solve_film.py:505-524, 557-562) inside
+    the Jacobi loop (solve.py:491-536): every iterate of both films, the ring's fluxoid."""
+    d = golden("strip_ring.npz")
+    syn = _synthetic()
+    spec = syn.STRIP_RING
+    geo = syn.strip_ring_geometry(spec)
+    strip, ring = geo["strip"], geo["ring"]
+    sites = strip["sites"]
+    loop = np.asarray(d["boundary_indices"])
+    assert np.array_equal(np.sort(loop), np.sort(orc.boundary_vertices(sites, strip["elements"])))
+    smesh = orc.make_mesh(sites, strip["elements"])
+    film_s = orc.make_film("strip", smesh, z0=0.0, Lambda=spec["strip_Lambda"], in_film=contains(strip["film_polygon"], sites),
+                           boundary_indices=loop,
+                           terminal_masks={t: contains(p, sites[loop]) for t, p in strip["terminals"].items()})
+    rmesh = orc.make_mesh(ring["sites"], ring["elements"])
+    film_r = orc.make_film("ring", rmesh, z0=spec["ring_z0"], Lambda=spec["ring_Lambda"],
+                           in_film=contains(ring["film_polygon"], ring["sites"]),
+                           holes_mask={"hole_ring": contains(ring["hole_polygon"], ring["sites"])})
+    cur = float(d["current"])
+    trace = orc.solve([film_s, film_r], float(d["field_mT"]), iterations=int(d["iterations"]),
+                      circulating_currents={"hole_ring": float(d["circ"])}, field_conversion=float(d["field_conversion"]),
+                      terminal_currents={"strip": {"source": cur, "drain": -cur}})
+    for it, sols in enumerate(trace):
+        for nm in ("strip", "ring"):
+            assert relerr(sols[nm].stream, d[f"g_{nm}_it{it}"]) < RTOL
+            assert relerr(sols[nm].current_density, d[f"J_{nm}_it{it}"]) < RTOL
+            assert relerr(sols[nm].self_field, d[f"self_field_{nm}_it{it}"]) < RTOL
+            if it > 0:
+                assert relerr(sols[nm].field_from_other_films, d[f"other_{nm}_it{it}"]) < RTOL
+        poly = ring["fluxoid_polygon"]
+        flux, int_J = orc.polygon_fluxoid_raw(film_r, sols["ring"], poly, contains(poly, ring["sites"]),
+                                              contains(ring["film_polygon"], poly))
+        assert abs(flux - float(d[f"flux_part_raw_ring_it{it}"])) <= 1e-10 * abs(float(d[f"flux_part_raw_ring_it{it}"]))
+        assert abs(int_J - float(d[f"int_J_raw_ring_it{it}"])) <= 1e-10 * abs(float(d[f"int_J_raw_ring_it{it}"]))
+
+
 def test_mutual_inductance_raw_parts_films_with_their_own_meshes(golden):
     d = golden("mutual_rings_mixed.npz")
     syn = _synthetic()

@@ -222,6 +222,41 @@ def test_vortices_and_lambda_xy_in_coupled_films_with_their_own_meshes(sc, golde
                 assert abs(fl.supercurrent_part - ref_sc) <= 1e-9 * abs(ref_sc)
 
 
+@pytest.mark.parametrize("method", ["auto", "lu"])
+def test_film_with_terminals_coupled_to_a_ring(sc, golden, method):
+    """A strip carrying a transport current between two terminals under a ring on its own mesh (a field coil under a
+    pickup loop, the shape of the reference's susceptometer notebooks): the terminal branch of solve_film
+    (solve_film.py:505-524, 557-562) inside the Jacobi loop, every iterate of both films and the ring's fluxoid against
+    what the reference produced (tests/golden/strip_ring.npz)."""
+    from superscreen_amd import synthetic
+
+    d = golden("strip_ring.npz")
+    device = synthetic.make_strip_ring_device()
+    geo = synthetic.strip_ring_geometry()
+    assert np.array_equal(device.boundary_vertices("strip"), d["boundary_indices"])
+    cur = float(d["current"])
+    iters = int(d["iterations"])
+    model = sc.factorize_model(device=device, current_units="uA", circulating_currents={"hole_ring": float(d["circ"])},
+                               terminal_currents={"strip": {"source": cur, "drain": -cur}}, method=method)
+    sols = sc.solve(model=model, applied_field=sc.ConstantField(float(d["field_mT"])), field_units="mT", iterations=iters)
+    assert len(sols) == iters + 1
+    for it, sol in enumerate(sols):
+        for nm in ("strip", "ring"):
+            fs = sol.film_solutions[nm]
+            assert relerr(fs.stream, d[f"g_{nm}_it{it}"]) < TOL
+            assert relerr(fs.current_density, d[f"J_{nm}_it{it}"]) < TOL
+            assert relerr(fs.self_field, d[f"self_field_{nm}_it{it}"]) < TOL
+            if it > 0:
+                assert relerr(fs.field_from_other_films, d[f"other_{nm}_it{it}"]) < TOL
+        fl = sol.polygon_fluxoid(geo["ring"]["fluxoid_polygon"], film="ring", units="mT * um**2", with_units=False)
+        ref_flux = float(d[f"flux_part_raw_ring_it{it}"])
+        ref_sc = orc.MU_0 * float(d[f"int_J_raw_ring_it{it}"]) * 1e-12 / (1e-3 * 1e-12)
+        assert abs(fl.flux_part - ref_flux) < 1e-9 * abs(ref_flux)
+        assert abs(fl.supercurrent_part - ref_sc) < 1e-9 * abs(ref_sc)
+    with pytest.raises(NotImplementedError):
+        sc.solve_sweep(model, [0.1, 0.2])
+
+
 def test_solve_sweep_films_with_their_own_meshes(sc, golden):
     """solve_sweep (n x nvec operands per film, pair kernels between films of different size) on the mixed-mesh
     device: the column that carries the fixture's field reproduces the reference's iterates, every column equals
