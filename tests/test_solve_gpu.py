@@ -1348,10 +1348,12 @@ def test_lu_factor_batch_keeps_cooperative_panels_coresident():
 
 
 @pytest.mark.gpu
-def test_sweep_grid_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("which", ["stack", "mixed"])
+def test_sweep_grid_two_ranks_on_one_gpu(which):
     """parallel.SweepGrid (film owner x field shard, BASELINE config 4): two ranks share this GPU as the two film
     owners of one shard; each factors ONE film and exchanges the [n, nvec] result arrays with one all-reduce per
-    pass (gloo here); the scan equals the single-process ``solve_sweep`` to 1e-12."""
+    pass (gloo here); the scan equals the single-process ``solve_sweep`` to 1e-12.  ``mixed``: the two films have
+    their own meshes of different size."""
     import socket
     import subprocess
     import sys
@@ -1363,7 +1365,7 @@ def test_sweep_grid_two_ranks_on_one_gpu():
         port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), worker]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), worker] + (["mixed"] if which == "mixed" else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("sweep grid == single process") == 2

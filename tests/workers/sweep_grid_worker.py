@@ -20,8 +20,15 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    device = synthetic.make_stack_device(14, ("washer", "disk"), solve_dtype="float64")
-    fields = [0.2 * (k + 1) * (-1) ** k for k in range(10)]
+    if len(sys.argv) > 1 and sys.argv[1] == "mixed":
+        # two rings on their OWN meshes (547 and 271 vertices, the smaller one off the axis, different Lambda): the
+        # [n, nvec] arrays of the exchange differ in length, source and target of a coupling product in size
+        spec = synthetic.RINGS_MIXED
+        device = synthetic.make_device(spec["films"][:2], spec["layers"])
+        fields = [sc.Parameter(synthetic.tilted_field, B0=0.2 * (k + 1) * (-1) ** k) for k in range(10)]
+    else:
+        device = synthetic.make_stack_device(14, ("washer", "disk"), solve_dtype="float64")
+        fields = [0.2 * (k + 1) * (-1) ** k for k in range(10)]
     grid = SweepGrid(len(device.films))
     assert (grid.film_ranks, grid.shards) == (2, 1) and grid.film_slot == rank and grid.field_range(10) == (0, 10)
     worst = 0.0
